@@ -1,0 +1,230 @@
+"""
+oracle -- TEST INFRASTRUCTURE ONLY (see oracle/hnsw_oracle.c header).
+
+ctypes front-end for the C restatement of the reference CPU path.  Importable from
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from the
+product package.
+"""
+import ctypes as ct
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+_SO = _DIR / "_build" / "libhnsw_oracle.so"
+
+METRICS = {"sq_euclid": 0, "cosine": 1, "ucosine": 2}
+
+_F = ct.POINTER(ct.c_float)
+_I = ct.POINTER(ct.c_int)
+
+
+def build(force: bool = False) -> Path:
+    """Compile oracle/hnsw_oracle.c with the committed Makefile (gcc)."""
+    src = _DIR / "hnsw_oracle.c"
+    if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_DIR), "-B"], check=True, capture_output=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ct.CDLL(str(_SO))
+        L.orc_create.restype = ct.c_void_p
+        L.orc_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_int, ct.c_int, ct.c_int, ct.c_int,
+                                 ct.c_int, ct.c_int]
+        L.orc_free.argtypes = [ct.c_void_p]
+        L.orc_free.restype = None
+        L.orc_add.argtypes = [ct.c_void_p, _F, ct.c_int, _I]
+        L.orc_knn_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, _I, _F, ct.c_int]
+        for name in ("orc_count", "orc_entry_point", "orc_capacity"):
+            getattr(L, name).argtypes = [ct.c_void_p]
+        L.orc_node_max_layer.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_get_edges.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, _I, ct.c_int]
+        L.orc_n_eval.argtypes = [ct.c_void_p]
+        L.orc_n_eval.restype = ct.c_uint64
+        L.orc_reset_n_eval.argtypes = [ct.c_void_p]
+        L.orc_reset_n_eval.restype = None
+        L.orc_graph_hash.argtypes = [ct.c_void_p]
+        L.orc_graph_hash.restype = ct.c_uint64
+        L.orc_metric.argtypes = [ct.c_int, _F, _F, ct.c_int, ct.c_int]
+        L.orc_metric.restype = ct.c_float
+        L.orc_dist_query_rows.argtypes = [ct.c_int, _F, ct.c_int, _F, _I, ct.c_int, _F, ct.c_int]
+        L.orc_dist_query_rows.restype = None
+        L.orc_dist_pairs.argtypes = [ct.c_int, _F, ct.c_int, _I, _I, ct.c_int, _F, ct.c_int]
+        L.orc_dist_pairs.restype = None
+        L.orc_random_next.argtypes = [ct.c_int, ct.c_int, _I]
+        L.orc_random_next_double.argtypes = [ct.c_int, ct.c_int, ct.POINTER(ct.c_double)]
+        L.orc_random_next_single.argtypes = [ct.c_int, ct.c_int, _F]
+        L.orc_random_levels.argtypes = [ct.c_int, ct.c_double, ct.c_int, _I]
+        L.orc_sort_nd.argtypes = [_I, _F, ct.c_int]
+        L.orc_heap_script.argtypes = [ct.c_int, _I, _F, ct.c_int, _I, _F, _I, _I]
+        L.orc_search_layer.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, _F, _I, _F]
+        L.orc_find_entry_point.argtypes = [ct.c_void_p, ct.c_int, _F]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _pf(a):
+    return a.ctypes.data_as(_F)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_I)
+
+
+# ---------------------------------------------------------------- unit pieces
+def metric(name, a, b, use_avx=False) -> np.float32:
+    a, b = _f32(a), _f32(b)
+    assert a.shape == b.shape and a.ndim == 1
+    return np.float32(lib().orc_metric(METRICS[name], _pf(a), _pf(b), a.size, int(use_avx)))
+
+
+def dist_query_rows(name, rows, q, ids, use_avx=False):
+    rows, q, ids = _f32(rows), _f32(q), _i32(ids)
+    out = np.empty(ids.size, dtype=np.float32)
+    lib().orc_dist_query_rows(METRICS[name], _pf(rows), rows.shape[1], _pf(q), _pi(ids), ids.size, _pf(out),
+                              int(use_avx))
+    return out
+
+
+def dist_pairs(name, rows, a, b, use_avx=False):
+    rows, a, b = _f32(rows), _i32(a), _i32(b)
+    out = np.empty(a.size, dtype=np.float32)
+    lib().orc_dist_pairs(METRICS[name], _pf(rows), rows.shape[1], _pi(a), _pi(b), a.size, _pf(out), int(use_avx))
+    return out
+
+
+def dotnet_random_next(seed, n):
+    out = np.empty(n, dtype=np.int32)
+    lib().orc_random_next(seed, n, _pi(out))
+    return out
+
+
+def dotnet_random_double(seed, n):
+    out = np.empty(n, dtype=np.float64)
+    lib().orc_random_next_double(seed, n, out.ctypes.data_as(ct.POINTER(ct.c_double)))
+    return out
+
+
+def dotnet_random_single(seed, n):
+    out = np.empty(n, dtype=np.float32)
+    lib().orc_random_next_single(seed, n, _pf(out))
+    return out
+
+
+def random_levels(seed, rate, n):
+    out = np.empty(n, dtype=np.int32)
+    lib().orc_random_levels(seed, float(rate), n, _pi(out))
+    return out
+
+
+def dotnet_sort(ids, dists):
+    ids, dists = _i32(ids).copy(), _f32(dists).copy()
+    lib().orc_sort_nd(_pi(ids), _pf(dists), ids.size)
+    return ids, dists
+
+
+def heap_script(closer_first, ops, dists):
+    ops, dists = _i32(ops), _f32(dists)
+    n = ops.size
+    out_ids = np.empty(n, dtype=np.int32)
+    out_d = np.empty(n, dtype=np.float32)
+    popped = np.empty(n, dtype=np.int32)
+    npop = ct.c_int(0)
+    c = lib().orc_heap_script(int(closer_first), _pi(ops), _pf(dists), n, _pi(out_ids), _pf(out_d), _pi(popped),
+                              ct.byref(npop))
+    return out_ids[:c].copy(), out_d[:c].copy(), popped[:npop.value].copy()
+
+
+# ---------------------------------------------------------------- index
+class OracleIndex:
+    """Same surface as the reference's Python `Index` (bindings/bindings.py:172-521) for
+    the float32 Add/KnnQuery path, plus graph introspection for parity checks."""
+
+    def __init__(self, dim, metric="sq_euclid", *, max_edges=16, distribution_rate=None, min_nn=5,
+                 max_candidates=100, collection_size=65536, random_seed=31337, allow_removals=True, use_avx=True):
+        import math
+        if distribution_rate is None:
+            distribution_rate = 1.0 / math.log(16)  # HNSWParameters.cs:19
+        self.dim, self.metric = dim, metric
+        self._h = lib().orc_create(dim, METRICS[metric], max_edges, float(distribution_rate), min_nn, max_candidates,
+                                   collection_size, random_seed, int(allow_removals), int(use_avx))
+        if not self._h:
+            raise RuntimeError("orc_create failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_free(self._h)
+            self._h = None
+
+    def add(self, vecs):
+        a = _f32(vecs).reshape(-1, self.dim)
+        ids = np.empty(a.shape[0], dtype=np.int32)
+        lib().orc_add(self._h, _pf(a), a.shape[0], _pi(ids))
+        return ids
+
+    def knn_query(self, queries, k, threads=1):
+        q = _f32(queries).reshape(-1, self.dim)
+        n = q.shape[0]
+        ids = np.empty((n, k), dtype=np.int32)
+        d = np.empty((n, k), dtype=np.float32)
+        lib().orc_knn_query(self._h, _pf(q), n, k, _pi(ids), _pf(d), threads)
+        return ids, d
+
+    @property
+    def count(self):
+        return lib().orc_count(self._h)
+
+    @property
+    def entry_point(self):
+        return lib().orc_entry_point(self._h)
+
+    def max_layer(self, i):
+        return lib().orc_node_max_layer(self._h, int(i))
+
+    def levels(self):
+        return np.array([self.max_layer(i) for i in range(self.count)], dtype=np.int32)
+
+    def edges(self, i, layer, incoming=False):
+        buf = np.empty(4096, dtype=np.int32)
+        n = lib().orc_get_edges(self._h, int(i), int(layer), int(incoming), _pi(buf), buf.size)
+        if n < 0:
+            raise IndexError((i, layer))
+        return buf[:n].copy()
+
+    def graph_hash(self):
+        return int(lib().orc_graph_hash(self._h))
+
+    @property
+    def n_eval(self):
+        return int(lib().orc_n_eval(self._h))
+
+    def reset_n_eval(self):
+        lib().orc_reset_n_eval(self._h)
+
+    def search_layer(self, entry_id, layer, k, q):
+        q = _f32(q)
+        ids = np.empty(k, dtype=np.int32)
+        d = np.empty(k, dtype=np.float32)
+        n = lib().orc_search_layer(self._h, int(entry_id), int(layer), int(k), _pf(q), _pi(ids), _pf(d))
+        return ids[:n].copy(), d[:n].copy()
+
+    def find_entry_point(self, dst_layer, q):
+        q = _f32(q)
+        return lib().orc_find_entry_point(self._h, int(dst_layer), _pf(q))

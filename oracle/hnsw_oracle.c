@@ -1,0 +1,1023 @@
+/*
+ * oracle/hnsw_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C) of the HNSWIndex.Net v1.6.0 hot path: the three float32
+ * metrics in the exact lane/rounding order of the reference's AVX(+FMA) branch, and
+ * the host-side traversal/link logic that consumes them (heaps, visited list, level
+ * RNG, relative-neighbour pruning, Add, KnnQuery).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product
+ * (hnswindex.net_amd/) never links, imports or calls it.
+ *
+ * PARITY STATUS
+ *   - metric arithmetic: follows the reference source line by line (citations below);
+ *     pinned by the reference's own tolerances (MetricsTests.cs:7-92, 1e-6 vs scalar;
+ *     bindings/__tests__/metric_test.py:34-96, atol 1e-5 vs float64) in
+ *     tests/test_oracle_metrics.py.
+ *   - System.Random(seed): restated from the public .NET runtime algorithm (Knuth
+ *     subtractive generator, "Net5CompatSeedImpl"); pinned by publicly known outputs
+ *     (new Random(0).Next()==1559595546, new Random(42).Next()==1434747710,
+ *     new Random(1).Next()==534011718) in tests/test_oracle_dotnet.py.  The reference
+ *     itself holds no level-sequence fixture.
+ *   - Span.Sort (introsort) tie order, and therefore bit-exact neighbour ids on inputs
+ *     with equal distances: PARITY UNPINNED -- restated from knowledge of the .NET BCL;
+ *     the reference cannot be compiled or run here (no dotnet toolchain) and ships no
+ *     golden vectors.  See DESIGN.md "Oracle".
+ *
+ * All citations are relative to /root/reference/.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#define ORC_HAVE_AVX2 1
+#else
+#define ORC_HAVE_AVX2 0
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+enum { ORC_SQ_EUCLID = 0, ORC_COSINE = 1, ORC_UCOSINE = 2 };
+
+typedef struct { int id; float dist; } nd_t; /* src/HNSWIndex/NodeDistance.cs:5-14 */
+
+/* ------------------------------------------------------------------------------------
+ * Metrics, "spec" form: eight scalar partial sums standing for the eight AVX lanes.
+ * Compiled with -ffp-contract=off so that a*b+c is never fused unless fmaf() is written.
+ * ---------------------------------------------------------------------------------- */
+
+/* src/HNSWIndex/Metrics/EuclideanMetric.cs:19-60 (AVX+FMA branch). */
+static float sq_euclid_spec(const float *a, const float *b, int n)
+{
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int stop = n & ~7; /* :23 */
+    int i = 0;
+    for (; i < stop; i += 8) /* :25-43, one accumulator, lane j <- elements j, j+8, ... */
+        for (int j = 0; j < 8; j++) {
+            float d = a[i + j] - b[i + j]; /* Avx.Subtract :29 */
+            acc[j] = fmaf(d, d, acc[j]);   /* Fma.MultiplyAdd :30 */
+        }
+    /* :45-50  lower+upper, hadd, hadd  => ((p0+p4)+(p1+p5)) + ((p2+p6)+(p3+p7)) */
+    float t0 = acc[0] + acc[4], t1 = acc[1] + acc[5], t2 = acc[2] + acc[6], t3 = acc[3] + acc[7];
+    float s = (t0 + t1) + (t2 + t3);
+    for (; i < n; i++) { /* :53-57 scalar tail: separate multiply and add */
+        float d = a[i] - b[i];
+        float m = d * d;
+        s = s + m;
+    }
+    return s;
+}
+
+/* CosineMetric.HorizontalSum256/128, src/HNSWIndex/Metrics/CosineMetric.cs:145-171:
+ * u_j = p_j + p_{j+4}; movehl add; shuffle-0x55 add  => (u0+u2) + (u1+u3). */
+static float hsum_cos(const float *p)
+{
+    float u0 = p[0] + p[4], u1 = p[1] + p[5], u2 = p[2] + p[6], u3 = p[3] + p[7];
+    return (u0 + u2) + (u1 + u3);
+}
+
+/* src/HNSWIndex/Metrics/CosineMetric.cs:95-142 (UnitCompute, AVX branch): mul then add. */
+static float ucosine_spec(const float *a, const float *b, int n)
+{
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int stop = n - 8 + 1; /* :108 */
+    int i = 0;
+    for (; i < stop; i += 8)
+        for (int j = 0; j < 8; j++) {
+            float p = a[i + j] * b[i + j]; /* Avx.Multiply :114 */
+            acc[j] = acc[j] + p;           /* Avx.Add :115 */
+        }
+    float dot = hsum_cos(acc); /* :117 */
+    for (; i < n; i++) {       /* :135-138 */
+        float p = a[i] * b[i];
+        dot = dot + p;
+    }
+    return 1.0f - dot; /* :141 */
+}
+
+/* src/HNSWIndex/Metrics/CosineMetric.cs:10-92 (Compute, AVX branch). */
+static float cosine_spec(const float *a, const float *b, int n)
+{
+    float dA[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nA[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int stop = n - 8 + 1; /* :30 */
+    int i = 0;
+    for (; i < stop; i += 8)
+        for (int j = 0; j < 8; j++) {
+            float va = a[i + j], vb = b[i + j];
+            float p = va * vb;  dA[j] = dA[j] + p; /* :37-38 */
+            float sa = va * va; nA[j] = nA[j] + sa; /* :40-41 */
+            float sb = vb * vb; nB[j] = nB[j] + sb; /* :43-44 */
+        }
+    float dot = hsum_cos(dA), na = hsum_cos(nA), nb = hsum_cos(nB); /* :46-48 */
+    for (; i < n; i++) { /* :78-85 */
+        float va = a[i], vb = b[i];
+        float p = va * vb;  dot = dot + p;
+        float sa = va * va; na = na + sa;
+        float sb = vb * vb; nb = nb + sb;
+    }
+    float denom = (float)(sqrt((double)na) * sqrt((double)nb)); /* :88 */
+    if (denom < 1e-30f) return 1.0f;                            /* :89-90 */
+    return 1.0f - dot / denom;                                  /* :91 */
+}
+
+#if ORC_HAVE_AVX2
+/* The same three functions with the x86 instructions the reference's intrinsics map to
+ * 1:1 (System.Runtime.Intrinsics.X86 -> <immintrin.h>).  Must agree bit for bit with the
+ * spec forms (tests/test_oracle_metrics.py); used for the cpu_baseline timing. */
+static float sq_euclid_avx(const float *a, const float *b, int n)
+{
+    __m256 acc = _mm256_setzero_ps();
+    int stop = n & ~7, i = 0;
+    for (; i + 16 <= stop; i += 16) { /* EuclideanMetric.cs:25-36 */
+        __m256 d0 = _mm256_sub_ps(_mm256_loadu_ps(a + i), _mm256_loadu_ps(b + i));
+        acc = _mm256_fmadd_ps(d0, d0, acc);
+        __m256 d1 = _mm256_sub_ps(_mm256_loadu_ps(a + i + 8), _mm256_loadu_ps(b + i + 8));
+        acc = _mm256_fmadd_ps(d1, d1, acc);
+    }
+    for (; i < stop; i += 8) { /* :37-43 */
+        __m256 d0 = _mm256_sub_ps(_mm256_loadu_ps(a + i), _mm256_loadu_ps(b + i));
+        acc = _mm256_fmadd_ps(d0, d0, acc);
+    }
+    __m128 s = _mm_add_ps(_mm256_castps256_ps128(acc), _mm256_extractf128_ps(acc, 1)); /* :45-47 */
+    s = _mm_hadd_ps(s, s); /* :48 */
+    s = _mm_hadd_ps(s, s); /* :49 */
+    float r = _mm_cvtss_f32(s);
+    for (; i < n; i++) {
+        float d = a[i] - b[i];
+        float m = d * d;
+        r = r + m;
+    }
+    return r;
+}
+
+static inline float hsum_cos_avx(__m256 acc)
+{
+    __m128 s = _mm_add_ps(_mm256_extractf128_ps(acc, 0), _mm256_extractf128_ps(acc, 1)); /* CosineMetric.cs:147-150 */
+    __m128 t = _mm_add_ps(s, _mm_movehl_ps(s, s));                                        /* :158 */
+    __m128 t2 = _mm_add_ps(t, _mm_shuffle_ps(t, t, 0x55));                                /* :159 */
+    return _mm_cvtss_f32(t2);
+}
+
+static float ucosine_avx(const float *a, const float *b, int n)
+{
+    __m256 acc = _mm256_setzero_ps();
+    int stop = n - 8 + 1, i = 0;
+    for (; i < stop; i += 8)
+        acc = _mm256_add_ps(acc, _mm256_mul_ps(_mm256_loadu_ps(a + i), _mm256_loadu_ps(b + i)));
+    float dot = hsum_cos_avx(acc);
+    for (; i < n; i++) {
+        float p = a[i] * b[i];
+        dot = dot + p;
+    }
+    return 1.0f - dot;
+}
+
+static float cosine_avx(const float *a, const float *b, int n)
+{
+    __m256 d = _mm256_setzero_ps(), na = _mm256_setzero_ps(), nb = _mm256_setzero_ps();
+    int stop = n - 8 + 1, i = 0;
+    for (; i < stop; i += 8) {
+        __m256 va = _mm256_loadu_ps(a + i), vb = _mm256_loadu_ps(b + i);
+        d = _mm256_add_ps(d, _mm256_mul_ps(va, vb));
+        na = _mm256_add_ps(na, _mm256_mul_ps(va, va));
+        nb = _mm256_add_ps(nb, _mm256_mul_ps(vb, vb));
+    }
+    float dot = hsum_cos_avx(d), sa = hsum_cos_avx(na), sb = hsum_cos_avx(nb);
+    for (; i < n; i++) {
+        float va = a[i], vb = b[i];
+        float p = va * vb;  dot = dot + p;
+        float x = va * va;  sa = sa + x;
+        float y = vb * vb;  sb = sb + y;
+    }
+    float denom = (float)(sqrt((double)sa) * sqrt((double)sb));
+    if (denom < 1e-30f) return 1.0f;
+    return 1.0f - dot / denom;
+}
+#endif
+
+typedef float (*metric_fn)(const float *, const float *, int);
+
+static int cpu_has_avx2_fma(void)
+{
+#if ORC_HAVE_AVX2
+    return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+#else
+    return 0;
+#endif
+}
+
+static metric_fn pick_metric(int metric, int want_avx)
+{
+#if ORC_HAVE_AVX2
+    if (want_avx && cpu_has_avx2_fma()) {
+        if (metric == ORC_SQ_EUCLID) return sq_euclid_avx;
+        if (metric == ORC_COSINE) return cosine_avx;
+        return ucosine_avx;
+    }
+#endif
+    (void)want_avx;
+    if (metric == ORC_SQ_EUCLID) return sq_euclid_spec;
+    if (metric == ORC_COSINE) return cosine_spec;
+    return ucosine_spec;
+}
+
+/* ------------------------------------------------------------------------------------
+ * System.Random(int seed) -- .NET's seeded-compatibility generator.  NOT in /root/reference
+ * (BCL); restated from the public dotnet/runtime algorithm.  Used by
+ * src/HNSWIndex/GraphData.cs:42 (new Random(seed)) and :216 (NextSingle()).
+ * ---------------------------------------------------------------------------------- */
+typedef struct { int sa[56]; int inext, inextp; } dotnet_rng;
+
+static void rng_init(dotnet_rng *r, int seed)
+{
+    int subtraction = (seed == INT32_MIN) ? INT32_MAX : abs(seed);
+    int mj = 161803398 - subtraction;
+    memset(r->sa, 0, sizeof r->sa);
+    r->sa[55] = mj;
+    int mk = 1, ii = 0;
+    for (int i = 1; i < 55; i++) {
+        if ((ii += 21) >= 55) ii -= 55;
+        r->sa[ii] = mk;
+        mk = mj - mk;
+        if (mk < 0) mk += INT32_MAX;
+        mj = r->sa[ii];
+    }
+    for (int k = 1; k < 5; k++)
+        for (int i = 1; i < 56; i++) {
+            int n = i + 30;
+            if (n >= 55) n -= 55;
+            /* wrap-around subtraction exactly as C# unchecked int arithmetic */
+            r->sa[i] = (int)((uint32_t)r->sa[i] - (uint32_t)r->sa[1 + n]);
+            if (r->sa[i] < 0) r->sa[i] += INT32_MAX;
+        }
+    r->inext = 0;
+    r->inextp = 21;
+}
+
+static int rng_internal_sample(dotnet_rng *r)
+{
+    int li = r->inext, lp = r->inextp;
+    if (++li >= 56) li = 1;
+    if (++lp >= 56) lp = 1;
+    int ret = (int)((uint32_t)r->sa[li] - (uint32_t)r->sa[lp]);
+    if (ret == INT32_MAX) ret--;
+    if (ret < 0) ret += INT32_MAX;
+    r->sa[li] = ret;
+    r->inext = li;
+    r->inextp = lp;
+    return ret;
+}
+
+static double rng_sample(dotnet_rng *r) { return rng_internal_sample(r) * (1.0 / INT32_MAX); }
+static float rng_next_single(dotnet_rng *r) { return (float)rng_sample(r); }
+
+/* src/HNSWIndex/GraphData.cs:211-219: (int)(-Math.Log(random) * distRate).
+ * A non-finite or out-of-range product (random == 0) is returned as -1, which is what
+ * the reference's "topLayer < 0 => return -1" path (GraphData.cs:82) sees on x64
+ * runtimes that convert +inf to int.MinValue. */
+static int level_from_uniform(float random, double dist_rate)
+{
+    double v = -log((double)random) * dist_rate;
+    if (!(v < 2147483648.0) || !(v > -2147483649.0)) return -1;
+    return (int)v;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Comparers -- src/HNSWIndex/DistanceComparer.cs:6-25.  float.CompareTo: NaN sorts
+ * below every number, NaN == NaN.
+ * ---------------------------------------------------------------------------------- */
+static inline int float_compare_to(float x, float y)
+{
+    if (x < y) return -1;
+    if (x > y) return 1;
+    if (x == y) return 0;
+    if (isnan(x)) return isnan(y) ? 0 : -1;
+    return 1;
+}
+static inline int cmp_far(nd_t x, nd_t y) /* DistanceComparer :9-14 */
+{
+    if (x.dist < y.dist) return -1;
+    if (x.dist > y.dist) return 1;
+    return float_compare_to(x.dist, y.dist);
+}
+static inline int cmp_close(nd_t x, nd_t y) /* ReverseDistanceComparer :20-25 */
+{
+    if (x.dist > y.dist) return -1;
+    if (x.dist < y.dist) return 1;
+    return float_compare_to(y.dist, x.dist);
+}
+
+/* ------------------------------------------------------------------------------------
+ * BinaryHeap -- src/HNSWIndex/BinaryHeap.cs:30-107.  `rev` selects the comparer.
+ * ---------------------------------------------------------------------------------- */
+typedef struct { nd_t *buf; int count, cap, rev; } heap_t;
+
+static inline int heap_cmp(const heap_t *h, nd_t x, nd_t y) { return h->rev ? cmp_close(x, y) : cmp_far(x, y); }
+
+static void heap_init(heap_t *h, int capacity, int rev)
+{
+    h->cap = capacity > 0 ? capacity : 0;
+    h->buf = h->cap ? (nd_t *)malloc(sizeof(nd_t) * (size_t)h->cap) : NULL;
+    h->count = 0;
+    h->rev = rev;
+}
+static void heap_free(heap_t *h) { free(h->buf); h->buf = NULL; }
+
+static void heap_sift_up(heap_t *h, int i, nd_t item) /* :89-107 */
+{
+    nd_t *b = h->buf;
+    while (i > 0) {
+        int p = (i - 1) >> 1;
+        nd_t parent = b[p];
+        if (heap_cmp(h, item, parent) <= 0) break;
+        b[i] = parent;
+        i = p;
+    }
+    b[i] = item;
+}
+static void heap_sift_down(heap_t *h, int i, nd_t item, int count) /* :67-87 */
+{
+    nd_t *b = h->buf;
+    int half = count >> 1;
+    while (i < half) {
+        int left = (i << 1) + 1, right = left + 1;
+        int mc = (right < count && heap_cmp(h, b[left], b[right]) < 0) ? right : left;
+        if (heap_cmp(h, b[mc], item) <= 0) break;
+        b[i] = b[mc];
+        i = mc;
+    }
+    b[i] = item;
+}
+static void heap_push(heap_t *h, nd_t item) /* :30-34, growth :109-113 */
+{
+    if (h->count == h->cap) {
+        h->cap = h->cap == 0 ? 16 : h->cap * 2;
+        h->buf = (nd_t *)realloc(h->buf, sizeof(nd_t) * (size_t)h->cap);
+    }
+    heap_sift_up(h, h->count++, item);
+}
+static nd_t heap_pop(heap_t *h) /* :53-65 */
+{
+    nd_t result = h->buf[0];
+    int jc = --h->count;
+    nd_t last = h->buf[jc];
+    if (jc != 0) heap_sift_down(h, 0, last, jc);
+    return result;
+}
+
+/* ------------------------------------------------------------------------------------
+ * MemoryExtensions.Sort(Span<NodeDistance>, DistanceComparer) -- BCL introsort, called at
+ * src/HNSWIndex/Heuristic.cs:22.  NOT in /root/reference; restated from the public
+ * dotnet/runtime ArraySortHelper<T> (threshold 16, median-of-three, heapsort fallback,
+ * depth limit 2*(floor(log2 n)+1)).  Tie order: PARITY UNPINNED.
+ * ---------------------------------------------------------------------------------- */
+static inline void nd_swap(nd_t *k, int i, int j) { nd_t t = k[i]; k[i] = k[j]; k[j] = t; }
+static inline void swap_if_greater(nd_t *k, int i, int j)
+{
+    if (cmp_far(k[i], k[j]) > 0) nd_swap(k, i, j);
+}
+static void insertion_sort(nd_t *k, int n)
+{
+    for (int i = 0; i < n - 1; i++) {
+        nd_t t = k[i + 1];
+        int j = i;
+        while (j >= 0 && cmp_far(t, k[j]) < 0) {
+            k[j + 1] = k[j];
+            j--;
+        }
+        k[j + 1] = t;
+    }
+}
+static void down_heap(nd_t *k, int i, int n)
+{
+    nd_t d = k[i - 1];
+    while (i <= (n >> 1)) {
+        int child = 2 * i;
+        if (child < n && cmp_far(k[child - 1], k[child]) < 0) child++;
+        if (!(cmp_far(d, k[child - 1]) < 0)) break;
+        k[i - 1] = k[child - 1];
+        i = child;
+    }
+    k[i - 1] = d;
+}
+static void heap_sort(nd_t *k, int n)
+{
+    for (int i = n >> 1; i >= 1; i--) down_heap(k, i, n);
+    for (int i = n; i > 1; i--) {
+        nd_swap(k, 0, i - 1);
+        down_heap(k, 1, i - 1);
+    }
+}
+static int pick_pivot_and_partition(nd_t *k, int n)
+{
+    int hi = n - 1, middle = hi >> 1;
+    swap_if_greater(k, 0, middle);
+    swap_if_greater(k, 0, hi);
+    swap_if_greater(k, middle, hi);
+    nd_t pivot = k[middle];
+    nd_swap(k, middle, hi - 1);
+    int left = 0, right = hi - 1;
+    while (left < right) {
+        while (cmp_far(k[++left], pivot) < 0) {}
+        while (cmp_far(pivot, k[--right]) < 0) {}
+        if (left >= right) break;
+        nd_swap(k, left, right);
+    }
+    if (left != hi - 1) nd_swap(k, left, hi - 1);
+    return left;
+}
+static void intro_sort(nd_t *k, int n, int depth_limit)
+{
+    int ps = n;
+    while (ps > 1) {
+        if (ps <= 16) {
+            if (ps == 2) { swap_if_greater(k, 0, 1); return; }
+            if (ps == 3) { swap_if_greater(k, 0, 1); swap_if_greater(k, 0, 2); swap_if_greater(k, 1, 2); return; }
+            insertion_sort(k, ps);
+            return;
+        }
+        if (depth_limit == 0) { heap_sort(k, ps); return; }
+        depth_limit--;
+        int p = pick_pivot_and_partition(k, ps);
+        intro_sort(k + p + 1, ps - (p + 1), depth_limit);
+        ps = p;
+    }
+}
+static void dotnet_sort_nd(nd_t *k, int n)
+{
+    if (n > 1) {
+        int lg = 31 - __builtin_clz((unsigned)n);
+        intro_sort(k, n, 2 * (lg + 1));
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * EdgeList / Node -- src/HNSWIndex/Node.cs:31-107 (append; swap-with-last removal).
+ * ---------------------------------------------------------------------------------- */
+typedef struct { int *buf; int count, cap; } edges_t;
+typedef struct { int max_layer; edges_t *out, *in; } node_t;
+
+static edges_t edges_new(int cap)
+{
+    edges_t e;
+    e.cap = cap > 0 ? cap : 0;
+    e.buf = e.cap ? (int *)malloc(sizeof(int) * (size_t)e.cap) : NULL;
+    e.count = 0;
+    return e;
+}
+static void edges_add(edges_t *e, int v) /* :66-76, growth :96-106 */
+{
+    if (e->cap < e->count + 1) {
+        int nc = e->cap < 16 ? 16 : e->cap * 2;
+        if (nc < e->count + 1) nc = e->count + 1;
+        e->buf = (int *)realloc(e->buf, sizeof(int) * (size_t)nc);
+        e->cap = nc;
+    }
+    e->buf[e->count++] = v;
+}
+static int edges_remove(edges_t *e, int v) /* :79-93 */
+{
+    for (int i = 0; i < e->count; i++)
+        if (e->buf[i] == v) {
+            int last = --e->count;
+            if (i != last) e->buf[i] = e->buf[last];
+            return 1;
+        }
+    return 0;
+}
+static edges_t edges_copy(const edges_t *o) /* EdgeList(EdgeList other) :42-47 */
+{
+    edges_t e = edges_new(o->count);
+    memcpy(e.buf, o->buf, sizeof(int) * (size_t)o->count);
+    e.count = o->count;
+    return e;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Index
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+    uint16_t *ver; int len; uint16_t cur; /* src/HNSWIndex/VisitedListPool.cs:10-67 (set semantics only) */
+} visited_t;
+
+typedef struct {
+    int dim, metric;
+    int max_edges, min_nn, max_candidates, seed, allow_removals;
+    double dist_rate;
+    int capacity, length, count, entry;
+    float *items; /* row-major length x dim: Items[id] (GraphData.cs:18) */
+    node_t *nodes;
+    dotnet_rng rng;
+    metric_fn dist;
+    visited_t vis;          /* used by the single-threaded paths */
+    uint64_t n_eval;        /* distance evaluations (SURVEY 8d N_eval) */
+} index_t;
+
+typedef struct { index_t *ix; visited_t *vis; uint64_t n_eval; } sctx_t;
+
+static void visited_init(visited_t *v, int n) { v->ver = (uint16_t *)calloc((size_t)(n > 0 ? n : 1), 2); v->len = n > 0 ? n : 1; v->cur = 0; }
+static void visited_free(visited_t *v) { free(v->ver); v->ver = NULL; }
+static void visited_next(visited_t *v, int need)
+{
+    if (v->len < need) {
+        free(v->ver);
+        v->ver = (uint16_t *)calloc((size_t)need, 2);
+        v->len = need;
+        v->cur = 0;
+    }
+    v->cur++;
+    if (v->cur == 0) { memset(v->ver, 0, (size_t)v->len * 2); v->cur++; }
+}
+static inline int visited_has(const visited_t *v, int id) { return id < v->len && v->ver[id] == v->cur; }
+static inline void visited_add(visited_t *v, int id) { v->ver[id] = v->cur; }
+
+static inline int max_edges_at(const index_t *ix, int layer) { return layer == 0 ? ix->max_edges * 2 : ix->max_edges; } /* GraphData.cs:247-250 */
+static inline const float *item(const index_t *ix, int id) { return ix->items + (size_t)id * (size_t)ix->dim; }
+
+/* GraphData.Distance(int, TVector) :274 */
+static inline float dist_iq(sctx_t *c, int id, const float *q)
+{
+    c->n_eval++;
+    return c->ix->dist(item(c->ix, id), q, c->ix->dim);
+}
+/* GraphData.Distance(int, int) :256 */
+static inline float dist_ii(sctx_t *c, int a, int b)
+{
+    c->n_eval++;
+    return c->ix->dist(item(c->ix, a), item(c->ix, b), c->ix->dim);
+}
+
+/* src/HNSWIndex/GraphNavigator.cs:51-82 (FindEntryAtLayer; no filter). */
+static int find_entry_at_layer(sctx_t *c, int layer, int start, const float *q)
+{
+    index_t *ix = c->ix;
+    int best = start;
+    float cur = dist_iq(c, best, q); /* :57 */
+    int changed = 1;
+    while (changed) {
+        changed = 0;
+        /* :65 the span is taken once per pass: `best` may move mid-scan, the span does not */
+        const edges_t *e = &ix->nodes[best].out[layer];
+        const int *conn = e->buf;
+        int n = e->count;
+        for (int i = 0; i < n; i++) {
+            int cand = conn[i];
+            float d = dist_iq(c, cand, q); /* :70 */
+            if (d < cur) {                 /* :71 */
+                cur = d;
+                best = cand;
+                changed = 1;
+            }
+        }
+    }
+    return best;
+}
+
+/* GraphNavigator.cs:27-33 / :39-45 */
+static int find_entry_point(sctx_t *c, int dst_layer, const float *q)
+{
+    index_t *ix = c->ix;
+    int best = ix->entry;
+    for (int layer = ix->nodes[best].max_layer; layer > dst_layer; layer--)
+        best = find_entry_at_layer(c, layer, best, q);
+    return best;
+}
+
+/* GraphNavigator.cs:123-189 (SearchLayer) == :194-256 (SearchLayerQuery) minus locks.
+ * Returns the top-candidate heap's buffer prefix (heap order) in *out (malloc'd). */
+static int search_layer(sctx_t *c, int entry_id, int layer, int k, const float *q, nd_t **out)
+{
+    index_t *ix = c->ix;
+    heap_t top, cand;
+    heap_init(&top, k, 0);      /* :126 fartherFirst */
+    heap_init(&cand, k * 2, 1); /* :127 closerFirst */
+    nd_t entry = {entry_id, dist_iq(c, entry_id, q)}; /* :129 */
+    heap_push(&top, entry);     /* :134 */
+    float farthest = entry.dist; /* :135 */
+    heap_push(&cand, entry);    /* :138 */
+    visited_next(c->vis, ix->capacity);
+    visited_add(c->vis, entry_id); /* :140 */
+    while (cand.count > 0) {
+        nd_t closest = heap_pop(&cand);                         /* :146 */
+        if (closest.dist > farthest && top.count >= k) break;   /* :147 */
+        const edges_t *e = &ix->nodes[closest.id].out[layer];
+        for (int i = 0; i < e->count; ++i) {
+            int nb = e->buf[i];
+            if (visited_has(c->vis, nb)) continue;              /* :161 */
+            float d = dist_iq(c, nb, q);                        /* :163 */
+            if (top.count < k || d < farthest) {                /* :165 */
+                nd_t sel = {nb, d};
+                heap_push(&cand, sel);                          /* :168 */
+                heap_push(&top, sel);                           /* :171 */
+                if (top.count > k) heap_pop(&top);              /* :173-174 */
+                if (top.count > 0) farthest = top.buf[0].dist;  /* :176-177 */
+            }
+            visited_add(c->vis, nb);                            /* :181 */
+        }
+    }
+    int n = top.count;
+    *out = top.buf; /* ToArray(): buffer prefix, BinaryHeap.cs:41-44 */
+    heap_free(&cand);
+    return n;
+}
+
+/* src/HNSWIndex/Heuristic.cs:11-46.  `cands` is sorted in place (as the reference's span). */
+static edges_t relative_neighbor_pruning(sctx_t *c, nd_t *cands, int n, int max_edges)
+{
+    if (n < max_edges) { /* :13-18: ids in input order, unsorted */
+        edges_t ids = edges_new(n);
+        for (int i = 0; i < n; i++) edges_add(&ids, cands[i].id);
+        return ids;
+    }
+    int rc = 0;
+    nd_t *res = (nd_t *)malloc(sizeof(nd_t) * (size_t)(max_edges + 1));
+    dotnet_sort_nd(cands, n); /* :22 */
+    for (int i = 0; i < n && rc < max_edges; i++) {
+        nd_t cand = cands[i];
+        int ok = 1;
+        for (int j = 0; j < rc; j++)
+            if (dist_ii(c, res[j].id, cand.id) < cand.dist) { ok = 0; break; } /* :34 */
+        if (ok) res[rc++] = cand;
+    }
+    edges_t out = edges_new(max_edges + 1);
+    for (int k = 0; k < rc; k++) edges_add(&out, res[k].id);
+    free(res);
+    return out;
+}
+
+/* src/HNSWIndex/GraphConnector.cs:222-262 */
+static void prune_overflow(sctx_t *c, int node_id, int layer)
+{
+    index_t *ix = c->ix;
+    node_t *node = &ix->nodes[node_id];
+    edges_t old = node->out[layer];
+    nd_t *cd = (nd_t *)malloc(sizeof(nd_t) * (size_t)old.count);
+    for (int i = 0; i < old.count; i++) {
+        cd[i].id = old.buf[i];
+        cd[i].dist = dist_ii(c, old.buf[i], node_id); /* :233 */
+    }
+    edges_t nw = relative_neighbor_pruning(c, cd, old.count, max_edges_at(ix, layer)); /* :235 */
+    node->out[layer] = nw;
+    free(cd);
+    if (ix->allow_removals) { /* :239-261 */
+        for (int i = 0; i < old.count; i++) {
+            int id = old.buf[i], keep = 0;
+            for (int j = 0; j < nw.count; j++)
+                if (nw.buf[j] == id) { keep = 1; break; }
+            if (!keep) edges_remove(&ix->nodes[id].in[layer], node_id);
+        }
+    }
+    free(old.buf);
+}
+
+/* src/HNSWIndex/GraphConnector.cs:187-217 */
+static int connect_at_layer(sctx_t *c, int cur_id, int best_peer, int layer)
+{
+    index_t *ix = c->ix;
+    nd_t *topc;
+    int n = search_layer(c, best_peer, layer, ix->max_candidates, item(ix, cur_id), &topc); /* :189 */
+    edges_t best = relative_neighbor_pruning(c, topc, n, max_edges_at(ix, layer));          /* :190 */
+    free(topc);
+    node_t *cur = &ix->nodes[cur_id];
+    free(cur->out[layer].buf);
+    cur->out[layer] = best; /* :192 */
+    if (ix->allow_removals) { /* :193 */
+        free(cur->in[layer].buf);
+        cur->in[layer] = edges_copy(&best);
+    }
+    int first = best.buf[0];
+    int cnt = best.count;
+    for (int i = 0; i < cnt; ++i) {
+        /* re-read through the node: `best` aliases cur->out[layer], which a prune of a
+         * neighbour never touches (cur is not yet anyone's overflow victim) */
+        int nb_id = ix->nodes[cur_id].out[layer].buf[i];
+        node_t *nb = &ix->nodes[nb_id];
+        if (ix->allow_removals) edges_add(&nb->in[layer], cur_id); /* :204 */
+        edges_add(&nb->out[layer], cur_id);                        /* :207 */
+        if (nb->out[layer].count > max_edges_at(ix, layer)) prune_overflow(c, nb_id, layer); /* :209-212 */
+    }
+    return first; /* :216 */
+}
+
+/* GraphData.NewNode :224-242 */
+static void node_init(index_t *ix, node_t *nd, int top_layer)
+{
+    nd->max_layer = top_layer;
+    nd->out = (edges_t *)malloc(sizeof(edges_t) * (size_t)(top_layer + 1));
+    nd->in = ix->allow_removals ? (edges_t *)malloc(sizeof(edges_t) * (size_t)(top_layer + 1)) : NULL;
+    for (int l = 0; l <= top_layer; l++) {
+        nd->out[l] = edges_new(max_edges_at(ix, l) + 1);
+        if (ix->allow_removals) nd->in[l] = edges_new(max_edges_at(ix, l) + 1);
+    }
+}
+
+static void grow(index_t *ix) /* GraphData.cs:98-111 */
+{
+    int nc = ix->capacity * 2;
+    if (nc < 1) nc = 1;
+    ix->items = (float *)realloc(ix->items, sizeof(float) * (size_t)nc * (size_t)ix->dim);
+    ix->nodes = (node_t *)realloc(ix->nodes, sizeof(node_t) * (size_t)nc);
+    memset(ix->nodes + ix->capacity, 0, sizeof(node_t) * (size_t)(nc - ix->capacity));
+    ix->capacity = nc;
+}
+
+/* HNSWIndex.Add(item) src/HNSWIndex/HNSWIndex.cs:55-65 -> GraphData.AddItem :79-118 ->
+ * GraphConnector.ConnectNewNode :24-47 -> AddNewConnections :172-181. */
+static int add_one(sctx_t *c, const float *v)
+{
+    index_t *ix = c->ix;
+    int top_layer = level_from_uniform(rng_next_single(&ix->rng), ix->dist_rate); /* :81 */
+    if (top_layer < 0) return -1;                                                 /* :82 */
+    int id = ix->length++;
+    if (ix->length > ix->capacity) grow(ix);
+    node_init(ix, &ix->nodes[id], top_layer);
+    memcpy(ix->items + (size_t)id * (size_t)ix->dim, v, sizeof(float) * (size_t)ix->dim);
+    ix->count++;
+    if (ix->entry < 0) { ix->entry = id; return id; } /* GraphConnector.cs:28-33 */
+    node_t *cur = &ix->nodes[id];
+    int top = ix->nodes[ix->entry].max_layer; /* GetTopLayer :195-198 */
+    int new_ep = cur->max_layer > top;        /* :36 */
+    /* AddNewConnections */
+    int best = find_entry_point(c, cur->max_layer, item(ix, id)); /* :174 */
+    int start = cur->max_layer < top ? cur->max_layer : top;      /* :176 */
+    for (int layer = start; layer >= 0; --layer)
+        best = connect_at_layer(c, id, best, layer); /* :178-179 */
+    if (new_ep) ix->entry = id; /* :39 */
+    return id;
+}
+
+/* ------------------------------------------------------------------------------------
+ * C API (ctypes)
+ * ---------------------------------------------------------------------------------- */
+ORC_API void *orc_create(int dim, int metric, int max_edges, double dist_rate, int min_nn, int max_candidates,
+                         int collection_size, int seed, int allow_removals, int use_avx)
+{
+    if (dim <= 0 || metric < 0 || metric > 2) return NULL;
+    index_t *ix = (index_t *)calloc(1, sizeof(index_t));
+    ix->dim = dim; ix->metric = metric; ix->max_edges = max_edges; ix->dist_rate = dist_rate;
+    ix->min_nn = min_nn; ix->max_candidates = max_candidates; ix->seed = seed; ix->allow_removals = allow_removals;
+    ix->capacity = collection_size > 0 ? collection_size : 1;
+    ix->items = (float *)malloc(sizeof(float) * (size_t)ix->capacity * (size_t)dim);
+    ix->nodes = (node_t *)calloc((size_t)ix->capacity, sizeof(node_t));
+    ix->entry = -1;
+    /* RandomSeed < 0 => unseeded Random() (GraphData.cs:42): not reproducible by design;
+     * the oracle seeds with |seed| so that runs stay deterministic. */
+    rng_init(&ix->rng, seed < 0 ? -seed : seed);
+    ix->dist = pick_metric(metric, use_avx);
+    visited_init(&ix->vis, ix->capacity);
+    return ix;
+}
+
+ORC_API void orc_free(void *h)
+{
+    index_t *ix = (index_t *)h;
+    if (!ix) return;
+    for (int i = 0; i < ix->length; i++) {
+        node_t *nd = &ix->nodes[i];
+        for (int l = 0; l <= nd->max_layer; l++) {
+            free(nd->out[l].buf);
+            if (nd->in) free(nd->in[l].buf);
+        }
+        free(nd->out);
+        free(nd->in);
+    }
+    free(ix->nodes);
+    free(ix->items);
+    visited_free(&ix->vis);
+    free(ix);
+}
+
+/* Sequential, in input order: the deterministic schedule the reference's own determinism
+ * test uses (bindings/__tests__/parameters_test.py:65-68, one add() per vector). */
+ORC_API int orc_add(void *h, const float *v, int n, int *out_ids)
+{
+    index_t *ix = (index_t *)h;
+    if (!ix || !v || n <= 0) return 0;
+    sctx_t c = {ix, &ix->vis, 0};
+    for (int i = 0; i < n; i++) {
+        int id = add_one(&c, v + (size_t)i * (size_t)ix->dim);
+        if (out_ids) out_ids[i] = id;
+    }
+    ix->n_eval += c.n_eval;
+    return n;
+}
+
+/* src/HNSWIndex/HNSWIndex.cs:107-124 (layer 0, no filter) + export padding
+ * bindings/HNSWIndex.Native/HNSWIndexExports.cs:135-145. */
+static void knn_one(sctx_t *c, const float *q, int k, int *out_ids, float *out_d)
+{
+    index_t *ix = c->ix;
+    int n = 0;
+    nd_t *res = NULL;
+    if (ix->count > 0 && k >= 1) {
+        int ef = ix->min_nn > k ? ix->min_nn : k;     /* :115 */
+        int ep = find_entry_point(c, 0, q);          /* :116 */
+        n = search_layer(c, ep, 0, ef, q, &res);     /* :117 */
+        /* LINQ OrderBy(c => c.Dist) (:121) is a STABLE sort, key order float.CompareTo:
+         * insertion sort (stable) over the heap-order array; n <= ef. */
+        for (int i = 1; i < n; i++) {
+            nd_t t = res[i];
+            int j = i - 1;
+            while (j >= 0 && float_compare_to(t.dist, res[j].dist) < 0) { res[j + 1] = res[j]; j--; }
+            res[j + 1] = t;
+        }
+    }
+    int m = n < k ? n : k;
+    for (int j = 0; j < m; j++) { out_ids[j] = res[j].id; out_d[j] = res[j].dist; }
+    for (int j = m; j < k; j++) { out_ids[j] = -1; out_d[j] = NAN; }
+    free(res);
+}
+
+typedef struct {
+    index_t *ix; const float *q; int n, k; int *ids; float *d;
+    volatile int *next; uint64_t n_eval;
+} qjob_t;
+
+static void *query_worker(void *arg)
+{
+    qjob_t *j = (qjob_t *)arg;
+    visited_t vis;
+    visited_init(&vis, j->ix->capacity);
+    sctx_t c = {j->ix, &vis, 0};
+    for (;;) {
+        int i0 = __atomic_fetch_add(j->next, 16, __ATOMIC_RELAXED);
+        if (i0 >= j->n) break;
+        int i1 = i0 + 16 < j->n ? i0 + 16 : j->n;
+        for (int i = i0; i < i1; i++)
+            knn_one(&c, j->q + (size_t)i * (size_t)j->ix->dim, j->k, j->ids + (size_t)i * (size_t)j->k,
+                    j->d + (size_t)i * (size_t)j->k);
+    }
+    j->n_eval = c.n_eval;
+    visited_free(&vis);
+    return NULL;
+}
+
+/* hnsw_knn_query -> BatchKnnQuery (Parallel.For over queries, HNSWIndex.cs:129-137).
+ * threads <= 1: plain loop. */
+ORC_API int orc_knn_query(void *h, const float *q, int n, int k, int *out_ids, float *out_d, int threads)
+{
+    index_t *ix = (index_t *)h;
+    if (!ix) return 0;
+    if (n <= 0 || k <= 0) return 0;
+    if (threads <= 1) {
+        sctx_t c = {ix, &ix->vis, 0};
+        for (int i = 0; i < n; i++)
+            knn_one(&c, q + (size_t)i * (size_t)ix->dim, k, out_ids + (size_t)i * (size_t)k, out_d + (size_t)i * (size_t)k);
+        ix->n_eval += c.n_eval;
+        return 0;
+    }
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    qjob_t jobs[256];
+    volatile int next = 0;
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (qjob_t){ix, q, n, k, out_ids, out_d, &next, 0};
+        pthread_create(&th[t], NULL, query_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        ix->n_eval += jobs[t].n_eval;
+    }
+    return 0;
+}
+
+/* --- introspection for parity checks --- */
+ORC_API int orc_count(void *h) { return ((index_t *)h)->count; }
+ORC_API int orc_entry_point(void *h) { return ((index_t *)h)->entry; }
+ORC_API int orc_capacity(void *h) { return ((index_t *)h)->capacity; }
+ORC_API int orc_node_max_layer(void *h, int id)
+{
+    index_t *ix = (index_t *)h;
+    return (id < 0 || id >= ix->length) ? -1 : ix->nodes[id].max_layer;
+}
+ORC_API int orc_get_edges(void *h, int id, int layer, int incoming, int *out, int cap)
+{
+    index_t *ix = (index_t *)h;
+    if (id < 0 || id >= ix->length || layer < 0 || layer > ix->nodes[id].max_layer) return -1;
+    if (incoming && !ix->nodes[id].in) return 0;
+    const edges_t *e = incoming ? &ix->nodes[id].in[layer] : &ix->nodes[id].out[layer];
+    int n = e->count < cap ? e->count : cap;
+    memcpy(out, e->buf, sizeof(int) * (size_t)n);
+    return e->count;
+}
+ORC_API uint64_t orc_n_eval(void *h) { return ((index_t *)h)->n_eval; }
+ORC_API void orc_reset_n_eval(void *h) { ((index_t *)h)->n_eval = 0; }
+ORC_API const float *orc_items(void *h) { return ((index_t *)h)->items; }
+
+/* FNV-1a over (max_layer, per-layer out-edge lists) of every node: one number that pins
+ * the whole graph (levels + adjacency + adjacency order). */
+ORC_API uint64_t orc_graph_hash(void *h)
+{
+    index_t *ix = (index_t *)h;
+    uint64_t x = 1469598103934665603ULL;
+#define MIX(v) do { uint32_t _v = (uint32_t)(v); for (int _b = 0; _b < 4; _b++) { x ^= (_v >> (8 * _b)) & 0xff; x *= 1099511628211ULL; } } while (0)
+    MIX(ix->entry);
+    for (int i = 0; i < ix->length; i++) {
+        node_t *nd = &ix->nodes[i];
+        MIX(nd->max_layer);
+        for (int l = 0; l <= nd->max_layer; l++) {
+            MIX(nd->out[l].count);
+            for (int e = 0; e < nd->out[l].count; e++) MIX(nd->out[l].buf[e]);
+        }
+    }
+#undef MIX
+    return x;
+}
+
+/* --- unit pieces --- */
+ORC_API float orc_metric(int metric, const float *a, const float *b, int n, int use_avx)
+{
+    return pick_metric(metric, use_avx)(a, b, n);
+}
+ORC_API int orc_has_avx2(void) { return cpu_has_avx2_fma(); }
+
+/* one query vs many rows: out[i] = metric(rows[ids[i]], q) -- the checker for the HIP
+ * gather-distance kernel */
+ORC_API void orc_dist_query_rows(int metric, const float *rows, int dim, const float *q, const int *ids, int n,
+                                 float *out, int use_avx)
+{
+    metric_fn f = pick_metric(metric, use_avx);
+    for (int i = 0; i < n; i++) out[i] = f(rows + (size_t)ids[i] * (size_t)dim, q, dim);
+}
+ORC_API void orc_dist_pairs(int metric, const float *rows, int dim, const int *a, const int *b, int n, float *out,
+                            int use_avx)
+{
+    metric_fn f = pick_metric(metric, use_avx);
+    for (int i = 0; i < n; i++) out[i] = f(rows + (size_t)a[i] * (size_t)dim, rows + (size_t)b[i] * (size_t)dim, dim);
+}
+
+ORC_API void orc_random_next(int seed, int n, int *out)
+{
+    dotnet_rng r;
+    rng_init(&r, seed);
+    for (int i = 0; i < n; i++) out[i] = rng_internal_sample(&r);
+}
+ORC_API void orc_random_next_double(int seed, int n, double *out)
+{
+    dotnet_rng r;
+    rng_init(&r, seed);
+    for (int i = 0; i < n; i++) out[i] = rng_sample(&r);
+}
+ORC_API void orc_random_next_single(int seed, int n, float *out)
+{
+    dotnet_rng r;
+    rng_init(&r, seed);
+    for (int i = 0; i < n; i++) out[i] = rng_next_single(&r);
+}
+ORC_API void orc_random_levels(int seed, double rate, int n, int *out)
+{
+    dotnet_rng r;
+    rng_init(&r, seed);
+    for (int i = 0; i < n; i++) out[i] = level_from_uniform(rng_next_single(&r), rate);
+}
+ORC_API void orc_sort_nd(int *ids, float *dists, int n)
+{
+    nd_t *k = (nd_t *)malloc(sizeof(nd_t) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) { k[i].id = ids[i]; k[i].dist = dists[i]; }
+    dotnet_sort_nd(k, n);
+    for (int i = 0; i < n; i++) { ids[i] = k[i].id; dists[i] = k[i].dist; }
+    free(k);
+}
+/* Replays a push/pop script on a BinaryHeap: ops[i] >= 0 pushes (id=ops[i], dist=d[i]);
+ * ops[i] < 0 pops.  Writes the final buffer prefix; returns its length. */
+ORC_API int orc_heap_script(int closer_first, const int *ops, const float *d, int n, int *out_ids, float *out_d,
+                            int *popped_ids, int *n_popped)
+{
+    heap_t h;
+    heap_init(&h, 4, closer_first);
+    int np = 0;
+    for (int i = 0; i < n; i++) {
+        if (ops[i] >= 0) { nd_t v = {ops[i], d[i]}; heap_push(&h, v); }
+        else if (h.count > 0) { nd_t v = heap_pop(&h); if (popped_ids) popped_ids[np] = v.id; np++; }
+    }
+    for (int i = 0; i < h.count; i++) { out_ids[i] = h.buf[i].id; out_d[i] = h.buf[i].dist; }
+    if (n_popped) *n_popped = np;
+    int c = h.count;
+    heap_free(&h);
+    return c;
+}
+
+/* SearchLayer on the built graph, result in heap order (what ConnectAtLayer consumes). */
+ORC_API int orc_search_layer(void *h, int entry_id, int layer, int k, const float *q, int *out_ids, float *out_d)
+{
+    index_t *ix = (index_t *)h;
+    sctx_t c = {ix, &ix->vis, 0};
+    nd_t *res;
+    int n = search_layer(&c, entry_id, layer, k, q, &res);
+    for (int i = 0; i < n; i++) { out_ids[i] = res[i].id; out_d[i] = res[i].dist; }
+    free(res);
+    ix->n_eval += c.n_eval;
+    return n;
+}
+ORC_API int orc_find_entry_point(void *h, int dst_layer, const float *q)
+{
+    index_t *ix = (index_t *)h;
+    sctx_t c = {ix, &ix->vis, 0};
+    int r = find_entry_point(&c, dst_layer, q);
+    ix->n_eval += c.n_eval;
+    return r;
+}
