@@ -1,0 +1,383 @@
+"""
+ctypes bindings over the C-ABI library -- the host-side mirror of the reference's Python
+interface (/root/reference/bindings/bindings.py): same `Index` class, method names, argument
+meaning, dtypes/shapes and error behaviour (RuntimeError carrying the native last-error
+string on a negative status).  `DeviceBackend` exposes the inner hnswdev_* boundary.
+"""
+import ctypes as ct
+import os
+from pathlib import Path
+from typing import List, Tuple
+
+import numpy as np
+import numpy.typing as npt
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "artifacts" / "native" / "linux-x64" / "HNSWIndex.Native.so"  # bindings.py:27-41
+
+
+def _load_lib():
+    # torch ships its own libamdhip64.so.7; load it first so that this process holds ONE
+    # HIP runtime (the library's DT_NEEDED then resolves to the copy already mapped).
+    if os.environ.get("HNSW_MI355X_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch absent: /opt/rocm's runtime is used
+            pass
+    if not LIB_PATH.exists():
+        raise FileNotFoundError(
+            f"Native library missing {LIB_PATH}: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no pure-Python or CPU fallback")
+    return ct.CDLL(str(LIB_PATH))
+
+
+lib = _load_lib()
+
+_F = ct.POINTER(ct.c_float)
+_I = ct.POINTER(ct.c_int)
+
+
+class Stats(ct.Structure):
+    """hnswdev_stats (include/hnsw_mi355x.h)."""
+    _fields_ = [("launches", ct.c_uint64), ("evals", ct.c_uint64), ("timed_launches", ct.c_uint64),
+                ("timed_evals", ct.c_uint64), ("kernel_ms", ct.c_double), ("row_bytes", ct.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# ---- (A) the reference's 16 exports: bindings.py:45-119 ---------------------------------
+lib.hnsw_create.restype = ct.c_void_p
+lib.hnsw_create.argtypes = [ct.c_char_p]
+lib.hnsw_free.restype = None
+lib.hnsw_free.argtypes = [ct.c_void_p]
+lib.hnsw_add.restype = ct.c_int
+lib.hnsw_add.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, _I]
+lib.hnsw_remove.restype = ct.c_int
+lib.hnsw_remove.argtypes = [ct.c_void_p, _I, ct.c_int]
+lib.hnsw_knn_query.restype = ct.c_int
+lib.hnsw_knn_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, ct.c_int, _I, _F]
+lib.hnsw_range_query.restype = ct.c_int
+lib.hnsw_range_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, ct.c_float, ct.POINTER(ct.c_void_p),
+                                 ct.POINTER(ct.c_void_p), _I]
+lib.hnsw_free_results.restype = None
+lib.hnsw_free_results.argtypes = [ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_p), ct.c_int]
+for _name in ("hnsw_set_collection_size", "hnsw_set_max_edges", "hnsw_set_max_candidates",
+              "hnsw_set_remove_max_candidates", "hnsw_set_random_seed", "hnsw_set_min_nn",
+              "hnsw_mi355x_set_device", "hnsw_mi355x_set_insert_batch", "hnsw_mi355x_set_search_slots",
+              "hnsw_mi355x_set_host_threads"):
+    getattr(lib, _name).restype = ct.c_int
+    getattr(lib, _name).argtypes = [ct.c_int]
+lib.hnsw_set_distribution_rate.restype = ct.c_int
+lib.hnsw_set_distribution_rate.argtypes = [ct.c_float]
+lib.hnsw_set_allow_removals.restype = ct.c_int
+lib.hnsw_set_allow_removals.argtypes = [ct.c_bool]
+lib.hnsw_get_last_error_utf8.restype = ct.c_int
+lib.hnsw_get_last_error_utf8.argtypes = [ct.c_void_p, ct.c_int]
+
+# ---- additions ---------------------------------------------------------------------------
+for _name in ("hnsw_mi355x_count", "hnsw_mi355x_entry_point", "hnsw_mi355x_reset_stats"):
+    getattr(lib, _name).restype = ct.c_int
+    getattr(lib, _name).argtypes = [ct.c_void_p]
+lib.hnsw_mi355x_node_max_layer.restype = ct.c_int
+lib.hnsw_mi355x_node_max_layer.argtypes = [ct.c_void_p, ct.c_int]
+lib.hnsw_mi355x_get_out_edges.restype = ct.c_int
+lib.hnsw_mi355x_get_out_edges.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, _I, ct.c_int]
+lib.hnsw_mi355x_graph_hash.restype = ct.c_uint64
+lib.hnsw_mi355x_graph_hash.argtypes = [ct.c_void_p]
+lib.hnsw_mi355x_get_stats.restype = ct.c_int
+lib.hnsw_mi355x_get_stats.argtypes = [ct.c_void_p, ct.POINTER(Stats)]
+lib.hnsw_mi355x_set_profiling.restype = ct.c_int
+lib.hnsw_mi355x_set_profiling.argtypes = [ct.c_void_p, ct.c_int]
+
+# ---- (B) hnswdev_* -------------------------------------------------------------------------
+lib.hnswdev_device_count.restype = ct.c_int
+lib.hnswdev_create.restype = ct.c_int
+lib.hnswdev_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_longlong, ct.POINTER(ct.c_void_p)]
+lib.hnswdev_destroy.argtypes = [ct.c_void_p]
+lib.hnswdev_reserve.argtypes = [ct.c_void_p, ct.c_longlong]
+lib.hnswdev_upload_rows.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, _F]
+lib.hnswdev_download_rows.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, _F]
+lib.hnswdev_dist_query_batch.argtypes = [ct.c_void_p, _F, ct.c_int, _I, _I, _F]
+lib.hnswdev_dist_pair_batch.argtypes = [ct.c_void_p, _I, _I, ct.c_int, _F]
+lib.hnswdev_sync.argtypes = [ct.c_void_p]
+lib.hnswdev_set_profiling.argtypes = [ct.c_void_p, ct.c_int]
+lib.hnswdev_get_stats.argtypes = [ct.c_void_p, ct.POINTER(Stats)]
+lib.hnswdev_reset_stats.argtypes = [ct.c_void_p]
+lib.hnswdev_last_error.argtypes = [ct.c_char_p, ct.c_int]
+lib.hnswdev_test_sqrt_rn.argtypes = [ct.c_int, ct.POINTER(ct.c_double), ct.POINTER(ct.c_double), ct.c_int]
+
+METRICS = {"sq_euclid": 0, "cosine": 1, "ucosine": 2}
+
+
+def last_error() -> str:
+    """bindings.py:122-128 `_last_error`."""
+    n = lib.hnsw_get_last_error_utf8(None, 0)
+    if n <= 0:
+        return ""
+    buf = ct.create_string_buffer(n + 1)
+    lib.hnsw_get_last_error_utf8(buf, len(buf))
+    return buf.value.decode("utf-8")
+
+
+def _dev_error() -> str:
+    buf = ct.create_string_buffer(1024)
+    lib.hnswdev_last_error(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
+def _as_2d_f32(x: npt.ArrayLike, dim_expected=None):
+    """bindings.py:131-139."""
+    a = np.asarray(x, dtype=np.float32)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.ndim != 2:
+        raise ValueError("expected a 2D array of shape (n, dim) or a 1D vector")
+    if dim_expected is not None and a.shape[1] != dim_expected:
+        raise ValueError(f"expected dim={dim_expected}, got {a.shape[1]}")
+    return a if a.flags["C_CONTIGUOUS"] else np.ascontiguousarray(a)
+
+
+class Index:
+    """
+    Python binding for the native HNSW index -- drop-in for the reference's `Index`
+    (bindings/bindings.py:142-597) on the float32 add / knn_query path.
+
+    The native index is created lazily on first insertion; configuration setters must be
+    called before it (they mutate the process-global pending parameters that the next
+    `hnsw_create` consumes, exactly as in the reference).
+    """
+
+    def __init__(self, dim: int, metric="sq_euclid"):
+        self.dim = dim
+        self.metric = metric
+        self._initialized = False
+        self._h = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.hnsw_free(self._h)
+            self._h = None
+
+    def _initialize(self):
+        h = lib.hnsw_create(self.metric.encode("utf-8"))
+        if not h:
+            raise RuntimeError("hnsw_create failed: " + last_error())
+        self._h = h
+        self._initialized = True
+
+    @staticmethod
+    def _check(status):
+        if status < 0:
+            raise RuntimeError(last_error())
+
+    # ---- the reference's setters (bindings.py:200-398) ----
+    def set_collection_size(self, init_size: int):
+        self._check(lib.hnsw_set_collection_size(init_size))
+
+    def set_max_edges(self, max_conn: int):
+        self._check(lib.hnsw_set_max_edges(max_conn))
+
+    def set_max_candidates(self, max_candidates: int):
+        self._check(lib.hnsw_set_max_candidates(max_candidates))
+
+    def set_remove_max_candidates(self, rem_max_candidates: int):
+        self._check(lib.hnsw_set_remove_max_candidates(rem_max_candidates))
+
+    def set_distribution_rate(self, dist_rate: float):
+        self._check(lib.hnsw_set_distribution_rate(dist_rate))
+
+    def set_random_seed(self, random_seed: int):
+        self._check(lib.hnsw_set_random_seed(random_seed))
+
+    def set_min_nn(self, min_nn: int):
+        self._check(lib.hnsw_set_min_nn(min_nn))
+
+    def set_allow_removals(self, allow_removals: bool):
+        self._check(lib.hnsw_set_allow_removals(allow_removals))
+
+    # ---- backend knobs (not in the reference) ----
+    def set_device(self, device: int):
+        self._check(lib.hnsw_mi355x_set_device(device))
+
+    def set_insert_batch(self, max_batch: int):
+        """1 = strictly sequential inserts (the reference's HNSWIndex.Add(item) semantics)."""
+        self._check(lib.hnsw_mi355x_set_insert_batch(max_batch))
+
+    def set_search_slots(self, slots: int):
+        self._check(lib.hnsw_mi355x_set_search_slots(slots))
+
+    def set_host_threads(self, threads: int):
+        self._check(lib.hnsw_mi355x_set_host_threads(threads))
+
+    # ---- data path ----
+    def add(self, vecs: npt.ArrayLike) -> npt.NDArray[np.int32]:
+        """bindings.py:400-441."""
+        if not self._initialized:
+            self._initialize()
+        a = _as_2d_f32(vecs, self.dim)
+        n, d = a.shape
+        out_ids = np.empty(n, dtype=np.int32)
+        rc = lib.hnsw_add(self._h, a.ctypes.data_as(_F), int(n), int(d), out_ids.ctypes.data_as(_I))
+        if rc < 0:
+            raise RuntimeError(last_error())
+        return out_ids[:rc].copy()
+
+    def remove(self, ids: npt.ArrayLike) -> None:
+        """bindings.py:443-472."""
+        arr = np.asarray(ids, dtype=np.int32).ravel()
+        if arr.size == 0:
+            return
+        result = lib.hnsw_remove(self._h, arr.ctypes.data_as(_I), int(arr.size))
+        if result < 0:
+            raise RuntimeError(last_error())
+
+    def knn_query(self, queries: npt.ArrayLike, k: int) -> Tuple[npt.NDArray[np.int32], npt.NDArray[np.float32]]:
+        """bindings.py:474-521."""
+        q = _as_2d_f32(queries, self.dim)
+        n = int(q.shape[0])
+        ids = np.empty((n, k), dtype=np.int32)
+        dists = np.empty((n, k), dtype=np.float32)
+        status = lib.hnsw_knn_query(self._h, q.ctypes.data_as(_F), n, self.dim, k, ids.ctypes.data_as(_I),
+                                    dists.ctypes.data_as(_F))
+        if status < 0:
+            raise RuntimeError(last_error())
+        return ids.copy(), dists.copy()
+
+    def range_query(self, queries: npt.ArrayLike, radius: float) -> Tuple[List[npt.NDArray[np.int32]], List[npt.NDArray[np.float32]]]:
+        """bindings.py:523-597 (the native call reports NotSupported this round)."""
+        q = _as_2d_f32(queries, self.dim)
+        n = int(q.shape[0])
+        ids_pp = (ct.c_void_p * n)()
+        dists_pp = (ct.c_void_p * n)()
+        counts = (ct.c_int * n)()
+        status = lib.hnsw_range_query(self._h, q.ctypes.data_as(_F), n, self.dim, radius, ids_pp, dists_pp, counts)
+        if status < 0:
+            raise RuntimeError(last_error())
+        ids, dists = [], []
+        try:
+            for i in range(n):
+                m = counts[i]
+                if m == 0:
+                    ids.append(np.empty(0, dtype=np.int32))
+                    dists.append(np.empty(0, dtype=np.float32))
+                    continue
+                ids.append(np.ctypeslib.as_array(ct.cast(ids_pp[i], _I), shape=(m,)).copy())
+                dists.append(np.ctypeslib.as_array(ct.cast(dists_pp[i], _F), shape=(m,)).copy())
+        finally:
+            lib.hnsw_free_results(ids_pp, dists_pp, n)
+        return ids, dists
+
+    # ---- introspection (parity checks, measurement) ----
+    @property
+    def count(self) -> int:
+        return lib.hnsw_mi355x_count(self._h) if self._h else 0
+
+    @property
+    def entry_point(self) -> int:
+        return lib.hnsw_mi355x_entry_point(self._h) if self._h else -1
+
+    def max_layer(self, i: int) -> int:
+        return lib.hnsw_mi355x_node_max_layer(self._h, int(i))
+
+    def levels(self):
+        return np.array([self.max_layer(i) for i in range(self.count)], dtype=np.int32)
+
+    def edges(self, i: int, layer: int):
+        buf = np.empty(4096, dtype=np.int32)
+        n = lib.hnsw_mi355x_get_out_edges(self._h, int(i), int(layer), buf.ctypes.data_as(_I), buf.size)
+        if n < 0:
+            raise IndexError((i, layer))
+        return buf[:n].copy()
+
+    def graph_hash(self) -> int:
+        return int(lib.hnsw_mi355x_graph_hash(self._h))
+
+    def set_profiling(self, on: bool):
+        if not self._initialized:
+            self._initialize()
+        lib.hnsw_mi355x_set_profiling(self._h, int(on))
+
+    def stats(self) -> dict:
+        s = Stats()
+        if self._h:
+            lib.hnsw_mi355x_get_stats(self._h, ct.byref(s))
+        return s.as_dict()
+
+    def reset_stats(self):
+        if self._h:
+            lib.hnsw_mi355x_reset_stats(self._h)
+
+
+class DeviceBackend:
+    """The inner boundary (hnswdev_*): HBM-resident row matrix + batched distance calls."""
+
+    def __init__(self, dim: int, metric="sq_euclid", capacity=1024, device=0):
+        self.dim, self.metric = dim, metric
+        ctx = ct.c_void_p()
+        if lib.hnswdev_create(device, dim, METRICS[metric], capacity, ct.byref(ctx)) != 0:
+            raise RuntimeError("hnswdev_create failed: " + _dev_error())
+        self._ctx = ctx
+
+    def __del__(self):
+        if getattr(self, "_ctx", None):
+            lib.hnswdev_destroy(self._ctx)
+            self._ctx = None
+
+    @staticmethod
+    def _check(rc):
+        if rc != 0:
+            raise RuntimeError(_dev_error())
+
+    def reserve(self, capacity: int):
+        self._check(lib.hnswdev_reserve(self._ctx, capacity))
+
+    def upload_rows(self, first_id: int, rows):
+        a = _as_2d_f32(rows, self.dim)
+        self._check(lib.hnswdev_upload_rows(self._ctx, first_id, a.shape[0], a.ctypes.data_as(_F)))
+
+    def download_rows(self, first_id: int, n: int):
+        out = np.empty((n, self.dim), dtype=np.float32)
+        self._check(lib.hnswdev_download_rows(self._ctx, first_id, n, out.ctypes.data_as(_F)))
+        return out
+
+    def dist_query_batch(self, queries, cand_offsets, cand_ids):
+        q = _as_2d_f32(queries, self.dim)
+        off = np.ascontiguousarray(cand_offsets, dtype=np.int32)
+        ids = np.ascontiguousarray(cand_ids, dtype=np.int32)
+        assert off.size == q.shape[0] + 1
+        out = np.empty(ids.size, dtype=np.float32)
+        self._check(lib.hnswdev_dist_query_batch(self._ctx, q.ctypes.data_as(_F), q.shape[0], off.ctypes.data_as(_I),
+                                                 ids.ctypes.data_as(_I), out.ctypes.data_as(_F)))
+        return out
+
+    def dist_pair_batch(self, a_ids, b_ids):
+        a = np.ascontiguousarray(a_ids, dtype=np.int32)
+        b = np.ascontiguousarray(b_ids, dtype=np.int32)
+        assert a.size == b.size
+        out = np.empty(a.size, dtype=np.float32)
+        self._check(lib.hnswdev_dist_pair_batch(self._ctx, a.ctypes.data_as(_I), b.ctypes.data_as(_I), a.size,
+                                                out.ctypes.data_as(_F)))
+        return out
+
+    def set_profiling(self, on: bool):
+        self._check(lib.hnswdev_set_profiling(self._ctx, int(on)))
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._check(lib.hnswdev_get_stats(self._ctx, ct.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._check(lib.hnswdev_reset_stats(self._ctx))
+
+
+def device_sqrt_rn(x, device=0):
+    """Test hook: the device's correctly rounded double sqrt (cosine epilogue)."""
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(a)
+    rc = lib.hnswdev_test_sqrt_rn(device, a.ctypes.data_as(ct.POINTER(ct.c_double)),
+                                  out.ctypes.data_as(ct.POINTER(ct.c_double)), a.size)
+    if rc != 0:
+        raise RuntimeError(_dev_error())
+    return out

@@ -1,0 +1,236 @@
+// exports.cpp -- C ABI (A): the reference's 16 `hnsw_*` exports
+// (/root/reference/bindings/HNSWIndex.Native/HNSWIndexExports.cs:27-273), same names,
+// signatures, return codes and padding, over the MI355X-backed HnswIndex.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hnsw_mi355x.h"
+#include "hnsw_index.h"
+
+using hnsw::HnswIndex;
+using hnsw::Params;
+
+namespace {
+// Exports.cs:11-12,16: process-global last error and pending parameters (unsynchronised in
+// the reference; a mutex here costs nothing and changes no observable behaviour).
+std::mutex g_mu;
+std::string g_last_error;
+Params g_pending;
+
+void set_error(const std::string &s)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_last_error = s;
+}
+} // namespace
+
+#define API extern "C" __attribute__((visibility("default")))
+
+API int hnsw_get_last_error_utf8(void *buf, int buf_len) // :27-39
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int need = (int)g_last_error.size();
+    if (buf_len > 0 && buf != nullptr) {
+        int to_write = std::max(0, buf_len - 1);
+        int written = std::min(need, to_write);
+        std::memcpy(buf, g_last_error.data(), (size_t)written);
+        static_cast<char *>(buf)[written] = 0;
+    }
+    return need;
+}
+
+API void *hnsw_create(const char *distance_metric) // :41-65
+{
+    int metric = -1;
+    if (distance_metric) {
+        if (!std::strcmp(distance_metric, "sq_euclid")) metric = HNSWDEV_SQ_EUCLID;
+        else if (!std::strcmp(distance_metric, "cosine")) metric = HNSWDEV_COSINE;
+        else if (!std::strcmp(distance_metric, "ucosine")) metric = HNSWDEV_UCOSINE;
+    }
+    if (metric < 0) {
+        set_error(std::string("System.ArgumentException: Unsupported distance metric: ") + (distance_metric ? distance_metric : "(null)"));
+        return nullptr;
+    }
+    Params p;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        p = g_pending;
+    }
+    std::string err;
+    HnswIndex *ix = HnswIndex::create(metric, p, err);
+    if (!ix) { set_error(err); return nullptr; }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_pending = Params(); // :61 reset parameters for next instance
+    }
+    return ix;
+}
+
+API void hnsw_free(void *handle) // :67-73
+{
+    if (!handle) return;
+    delete static_cast<HnswIndex *>(handle);
+}
+
+API int hnsw_add(void *handle, const float *vectors, int count, int dim, int *out_ids) // :75-100
+{
+    if (!handle) return 0;
+    if (!vectors || count <= 0 || dim <= 0) return 0;
+    std::string err;
+    int n = static_cast<HnswIndex *>(handle)->add(vectors, count, dim, out_ids, err);
+    if (n < 0) { set_error(err); return -1; }
+    return n;
+}
+
+API int hnsw_remove(void *handle, const int *ids, int count) // :102-117
+{
+    if (!handle) return 0;
+    if (!ids || count <= 0) return 0;
+    set_error("System.NotSupportedException: hnsw_remove is outside the accelerated Add/KnnQuery path of this backend (SURVEY.md 8f rank 4)");
+    return -1;
+}
+
+API int hnsw_knn_query(void *handle, const float *vectors, int count, int dim, int k, int *out_ids, float *out_dists) // :119-149
+{
+    if (!handle) return 0;
+    if (count <= 0) return 0;
+    if (!vectors || !out_ids || !out_dists || dim <= 0) { set_error("System.ArgumentNullException: hnsw_knn_query"); return -1; }
+    std::string err;
+    int rc = static_cast<HnswIndex *>(handle)->knn_query(vectors, count, dim, k, out_ids, out_dists, err);
+    if (rc < 0) { set_error(err); return -1; }
+    return 0;
+}
+
+API int hnsw_range_query(void *handle, const float *, int count, int, float, void **out_ids, void **out_dists, int *counts) // :151-197
+{
+    if (!handle) return 0;
+    for (int i = 0; i < count; ++i) { // the reference's failure path leaves every slot null / 0 (:186-191)
+        if (out_ids) out_ids[i] = nullptr;
+        if (out_dists) out_dists[i] = nullptr;
+        if (counts) counts[i] = 0;
+    }
+    set_error("System.NotSupportedException: hnsw_range_query is outside the accelerated Add/KnnQuery path of this backend (SURVEY.md 8f rank 3)");
+    return -1;
+}
+
+API void hnsw_free_results(void **ids_array, void **dists_array, int count) // :199-217
+{
+    if (!ids_array && !dists_array) return;
+    for (int i = 0; i < count; ++i) {
+        if (ids_array && ids_array[i]) { std::free(ids_array[i]); ids_array[i] = nullptr; }
+        if (dists_array && dists_array[i]) { std::free(dists_array[i]); dists_array[i] = nullptr; }
+    }
+}
+
+#define SETTER(name, field, type)                      \
+    API int name(type v)                               \
+    {                                                  \
+        std::lock_guard<std::mutex> lk(g_mu);          \
+        g_pending.field = v;                           \
+        return 0;                                      \
+    }
+SETTER(hnsw_set_collection_size, collection_size, int)             // :219
+SETTER(hnsw_set_max_edges, max_edges, int)                         // :226
+SETTER(hnsw_set_max_candidates, max_candidates, int)               // :233
+SETTER(hnsw_set_remove_max_candidates, remove_max_candidates, int) // :240
+SETTER(hnsw_set_random_seed, random_seed, int)                     // :254
+SETTER(hnsw_set_min_nn, min_nn, int)                               // :261
+SETTER(hnsw_set_allow_removals, allow_removals, bool)              // :268
+SETTER(hnsw_mi355x_set_device, device, int)
+SETTER(hnsw_mi355x_set_insert_batch, insert_batch, int)
+SETTER(hnsw_mi355x_set_search_slots, search_slots, int)
+SETTER(hnsw_mi355x_set_host_threads, host_threads, int)
+
+API int hnsw_set_distribution_rate(float dist_rate) // :247 -- crosses the ABI as float, widened to double
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pending.distribution_rate = (double)dist_rate;
+    return 0;
+}
+
+// ---- introspection / counters ----
+API int hnsw_mi355x_count(void *h) { return h ? static_cast<HnswIndex *>(h)->count() : 0; }
+API int hnsw_mi355x_entry_point(void *h) { return h ? static_cast<HnswIndex *>(h)->graph().entry : -1; }
+API int hnsw_mi355x_node_max_layer(void *h, int id)
+{
+    if (!h) return -1;
+    const hnsw::Graph &g = static_cast<HnswIndex *>(h)->graph();
+    return (id < 0 || id >= g.length) ? -1 : g.level[(size_t)id];
+}
+API int hnsw_mi355x_get_out_edges(void *h, int id, int layer, int *out, int cap)
+{
+    if (!h) return -1;
+    const hnsw::Graph &g = static_cast<HnswIndex *>(h)->graph();
+    if (id < 0 || id >= g.length || layer < 0 || layer > g.level[(size_t)id]) return -1;
+    const int *l = g.list(id, layer);
+    int n = std::min(l[0], cap);
+    if (out && n > 0) std::memcpy(out, l + 1, sizeof(int) * (size_t)n);
+    return l[0];
+}
+API uint64_t hnsw_mi355x_graph_hash(void *h) { return h ? static_cast<HnswIndex *>(h)->graph_hash() : 0; }
+API int hnsw_mi355x_get_stats(void *h, hnswdev_stats *out)
+{
+    if (!h || !out) return -1;
+    hnsw::Device *d = static_cast<HnswIndex *>(h)->device();
+    if (!d) { std::memset(out, 0, sizeof *out); return 0; }
+    d->get_stats(out);
+    return 0;
+}
+API int hnsw_mi355x_reset_stats(void *h)
+{
+    if (!h) return -1;
+    if (hnsw::Device *d = static_cast<HnswIndex *>(h)->device()) d->reset_stats();
+    return 0;
+}
+API int hnsw_mi355x_set_profiling(void *h, int enabled)
+{
+    if (!h) return -1;
+    static_cast<HnswIndex *>(h)->set_profiling(enabled != 0);
+    return 0;
+}
+
+// ---- host-logic test hooks (no device involved): the restated BCL pieces, so that the CPU
+// test tier can compare them with the oracle's independent restatement ----
+API void hnswhost_test_random_next(int seed, int n, int *out)
+{
+    hnsw::DotnetRandom r(seed);
+    for (int i = 0; i < n; ++i) out[i] = r.internal_sample();
+}
+API void hnswhost_test_random_levels(int seed, double rate, int n, int *out)
+{
+    hnsw::DotnetRandom r(seed);
+    for (int i = 0; i < n; ++i) out[i] = hnsw::level_from_uniform(r.next_single(), rate);
+}
+API void hnswhost_test_sort(int *ids, float *dists, int n)
+{
+    std::vector<hnsw::NodeDist> k((size_t)n);
+    for (int i = 0; i < n; ++i) k[(size_t)i] = hnsw::NodeDist{ids[i], dists[i]};
+    hnsw::dotnet_sort(k.data(), n);
+    for (int i = 0; i < n; ++i) { ids[i] = k[(size_t)i].id; dists[i] = k[(size_t)i].dist; }
+}
+API int hnswhost_test_heap_script(int closer_first, const int *ops, const float *d, int n, int *out_ids, float *out_d, int *popped_ids, int *n_popped)
+{
+    hnsw::BinaryHeap<hnsw::FartherFirst> hf;
+    hnsw::BinaryHeap<hnsw::CloserFirst> hc;
+    hf.reset(4); hc.reset(4);
+    int np = 0;
+    for (int i = 0; i < n; ++i) {
+        if (ops[i] >= 0) { hnsw::NodeDist v{ops[i], d[i]}; if (closer_first) hc.push(v); else hf.push(v); }
+        else if ((closer_first ? hc.count : hf.count) > 0) {
+            hnsw::NodeDist v = closer_first ? hc.pop() : hf.pop();
+            if (popped_ids) popped_ids[np] = v.id;
+            ++np;
+        }
+    }
+    int c = closer_first ? hc.count : hf.count;
+    for (int i = 0; i < c; ++i) {
+        const hnsw::NodeDist &v = closer_first ? hc.buf[(size_t)i] : hf.buf[(size_t)i];
+        out_ids[i] = v.id; out_d[i] = v.dist;
+    }
+    if (n_popped) *n_popped = np;
+    return c;
+}

@@ -1,0 +1,573 @@
+// hnsw_index.cpp -- Add / KnnQuery on the lock-step engine.  Citations relative to
+// /root/reference/.
+#include "hnsw_index.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+#include <thread>
+#include <unordered_map>
+
+namespace hnsw {
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// Pieces of the reference's traversal, cut at every distance evaluation.
+// ------------------------------------------------------------------------------------
+
+// GraphNavigator.FindEntryPoint / FindEntryAtLayer (src/HNSWIndex/GraphNavigator.cs:27-82):
+// greedy descent from the entry point's top layer to dst_layer (exclusive).
+struct Descent {
+    const Graph *g = nullptr;
+    int layer = 0, dst = 0, best = -1;
+    float cur = 0.f;
+    bool need_init = true;
+
+    void begin(const Graph *graph, int entry, int dst_layer)
+    {
+        g = graph;
+        best = entry;
+        layer = g->level[entry];
+        dst = dst_layer;
+        need_init = true;
+    }
+    // true: a task was emitted.  false: descent complete, (best, cur) final.
+    bool prepare(SlotIO &io)
+    {
+        if (need_init) { // :57 currDist = Distance(start, query) -- once; lower layers reuse it
+            io.ids[0] = best;
+            *io.cnt = 1;
+            return true;
+        }
+        while (layer > dst) {
+            const int *l = g->list(best, layer);
+            int n = l[0];
+            if (n == 0) { --layer; continue; } // empty span: `changed` stays false
+            std::memcpy(io.ids, l + 1, sizeof(int) * (size_t)n); // :65 span taken once per pass
+            *io.cnt = n;
+            return true;
+        }
+        return false;
+    }
+    void consume(const SlotIO &io)
+    {
+        if (need_init) { cur = io.dist[0]; need_init = false; return; }
+        bool changed = false;
+        const int n = *io.cnt;
+        for (int i = 0; i < n; ++i) { // :67-78
+            float d = io.dist[i];
+            if (d < cur) { cur = d; best = io.ids[i]; changed = true; }
+        }
+        if (!changed) --layer; // :60 loop ends; FindEntryPoint moves one layer down (:30-31)
+    }
+};
+
+// GraphNavigator.SearchLayer / SearchLayerQuery (GraphNavigator.cs:123-256), no filter.
+struct Expand {
+    const Graph *g = nullptr;
+    int layer = 0, k = 0;
+    float farthest = 0.f;
+
+    void begin(const Graph *graph, SlotScratch &sc, int capacity, int entry, float entry_dist, int at_layer, int kk)
+    {
+        g = graph;
+        layer = at_layer;
+        k = kk;
+        sc.top.reset(k);      // :126
+        sc.cand.reset(k * 2); // :127
+        NodeDist e{entry, entry_dist};
+        sc.top.push(e);       // :134
+        farthest = entry_dist; // :135
+        sc.cand.push(e);      // :138
+        sc.visited.begin(capacity);
+        sc.visited.test_and_set(entry); // :140
+    }
+    bool prepare(SlotIO &io, SlotScratch &sc)
+    {
+        while (sc.cand.count > 0) {
+            NodeDist c = sc.cand.pop();                              // :146
+            if (c.dist > farthest && sc.top.count >= k) return false; // :147-150
+            const int *l = g->list(c.id, layer);
+            int n = 0;
+            for (int i = 1; i <= l[0]; ++i) {
+                int nb = l[i];
+                if (!sc.visited.test_and_set(nb)) io.ids[n++] = nb; // :161 / :181 (lists hold no duplicates)
+            }
+            if (n > 0) { *io.cnt = n; return true; }
+        }
+        return false;
+    }
+    void consume(const SlotIO &io, SlotScratch &sc)
+    {
+        const int n = *io.cnt;
+        for (int i = 0; i < n; ++i) {
+            float d = io.dist[i];
+            if (sc.top.count < k || d < farthest) { // :165
+                NodeDist sel{io.ids[i], d};
+                sc.cand.push(sel);                  // :168
+                sc.top.push(sel);                   // :171
+                if (sc.top.count > k) sc.top.pop(); // :173-174
+                farthest = sc.top.peek().dist;      // :176-177
+            }
+        }
+    }
+};
+
+// Heuristic.RelativeNeighborPruning (src/HNSWIndex/Heuristic.cs:11-46).  One task per
+// candidate: its distances to the already accepted ids (the reference's inner loop :31-35;
+// its early break only skips evaluations, never changes the outcome).
+struct Prune {
+    std::vector<NodeDist> cands;
+    std::vector<int> acc;
+    int max_edges = 0, i = 0;
+    bool sorted_path = false;
+
+    void begin(int maxE)
+    {
+        max_edges = maxE;
+        acc.clear();
+        i = 0;
+        const int n = (int)cands.size();
+        if (n < max_edges) { // :13-18 ids in input (heap) order, unsorted
+            sorted_path = false;
+            for (const auto &c : cands) acc.push_back(c.id);
+            i = n;
+            return;
+        }
+        sorted_path = true;
+        dotnet_sort(cands.data(), n); // :22
+    }
+    bool prepare(SlotIO &io)
+    {
+        const int n = (int)cands.size();
+        while (i < n && (int)acc.size() < max_edges) { // :23
+            if (acc.empty()) { acc.push_back(cands[(size_t)i].id); ++i; continue; }
+            *io.qidx = ~cands[(size_t)i].id; // distanceFnc(s.Id, candidateId) :34
+            std::memcpy(io.ids, acc.data(), sizeof(int) * acc.size());
+            *io.cnt = (int)acc.size();
+            return true;
+        }
+        return false;
+    }
+    void consume(const SlotIO &io)
+    {
+        const NodeDist c = cands[(size_t)i];
+        bool ok = true;
+        const int n = *io.cnt;
+        for (int j = 0; j < n; ++j)
+            if (io.dist[j] < c.dist) { ok = false; break; }
+        if (ok) acc.push_back(c.id);
+        ++i;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// KnnQuery job: HNSWIndex.KnnQuery (src/HNSWIndex/HNSWIndex.cs:107-124), layer 0, no filter.
+// ------------------------------------------------------------------------------------
+struct QueryJob : Job {
+    const Graph *g;
+    int capacity, qi, ef, k;
+    int *out_ids;
+    float *out_d;
+    Descent desc;
+    Expand exp;
+    int stage = 0; // 0 descent, 1 expand
+
+    bool prepare(SlotIO &io, SlotScratch &sc) override
+    {
+        *io.qidx = qi;
+        if (stage == 0) {
+            if (desc.prepare(io)) return true;
+            exp.begin(g, sc, capacity, desc.best, desc.cur, 0, ef); // :117 (entry distance reused, same bits)
+            stage = 1;
+        }
+        return exp.prepare(io, sc);
+    }
+    void consume(const SlotIO &io, SlotScratch &sc) override
+    {
+        if (stage == 0) desc.consume(io);
+        else exp.consume(io, sc);
+    }
+    void finish(SlotScratch &sc)
+    {
+        int n = sc.top.count;
+        sc.tmp.assign(sc.top.buf.begin(), sc.top.buf.begin() + n); // ToArray(): heap order
+        stable_sort_by_dist(sc.tmp.data(), n);                     // OrderBy(c => c.Dist) :121
+        int m = std::min(n, k);
+        for (int j = 0; j < m; ++j) { out_ids[j] = sc.tmp[(size_t)j].id; out_d[j] = sc.tmp[(size_t)j].dist; }
+        for (int j = m; j < k; ++j) { out_ids[j] = -1; out_d[j] = std::numeric_limits<float>::quiet_NaN(); } // Exports.cs:144
+    }
+};
+
+struct QuerySource : JobSource {
+    std::vector<QueryJob> jobs;
+    std::atomic<int> next{0};
+    Job *acquire(SlotScratch &) override
+    {
+        int i = next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= (int)jobs.size()) return nullptr;
+        QueryJob &j = jobs[(size_t)i];
+        j.desc.begin(j.g, j.g->entry, 0); // FindEntryPointQuery(layer 0) :116
+        j.stage = 0;
+        return &j;
+    }
+    void release(Job *job, SlotScratch &sc) override { static_cast<QueryJob *>(job)->finish(sc); }
+};
+
+// ------------------------------------------------------------------------------------
+// Insert, search half: GraphConnector.AddNewConnections (src/HNSWIndex/GraphConnector.cs:172-181)
+// with ConnectAtLayer's search + heuristic (:189-190) for every layer of the new node,
+// against the graph as it stands at the start of the batch.
+// ------------------------------------------------------------------------------------
+struct InsertJob : Job {
+    const Graph *g;
+    int capacity, id, level, efc;
+    std::vector<std::vector<int>> selected; // per layer
+    Descent desc;
+    Expand exp;
+    Prune prune;
+    int stage = 0; // 0 descent, 1 expand, 2 prune
+    int layer = 0;
+
+    void start()
+    {
+        selected.assign((size_t)level + 1, {});
+        desc.begin(g, g->entry, level); // FindEntryPoint(currNode.MaxLayer, item) :174
+        stage = 0;
+        layer = std::min(level, g->top_layer()); // :176
+    }
+    bool prepare(SlotIO &io, SlotScratch &sc) override
+    {
+        for (;;) {
+            *io.qidx = ~id; // the item is already a stored row
+            if (stage == 0) {
+                if (desc.prepare(io)) return true;
+                exp.begin(g, sc, capacity, desc.best, desc.cur, layer, efc); // SearchLayer(bestPeer, layer, MaxCandidates, item) :189
+                stage = 1;
+            }
+            if (stage == 1) {
+                if (exp.prepare(io, sc)) return true;
+                prune.cands.assign(sc.top.buf.begin(), sc.top.buf.begin() + sc.top.count);
+                prune.begin(g->max_edges_at(layer)); // :190
+                stage = 2;
+            }
+            if (prune.prepare(io)) return true;
+            selected[(size_t)layer] = prune.acc;
+            if (layer == 0) return false;
+            // next layer: entry = selected[0] (:216, :179); its distance to the item is the
+            // candidate's own search distance (cands[0] in both Heuristic paths)
+            int entry = prune.acc[0];
+            float ed = prune.cands[0].dist;
+            --layer;
+            exp.begin(g, sc, capacity, entry, ed, layer, efc);
+            stage = 1;
+        }
+    }
+    void consume(const SlotIO &io, SlotScratch &sc) override
+    {
+        if (stage == 0) desc.consume(io);
+        else if (stage == 1) exp.consume(io, sc);
+        else prune.consume(io);
+    }
+};
+
+struct InsertSource : JobSource {
+    std::vector<InsertJob> jobs;
+    std::atomic<int> next{0};
+    Job *acquire(SlotScratch &) override
+    {
+        int i = next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= (int)jobs.size()) return nullptr;
+        jobs[(size_t)i].start();
+        return &jobs[(size_t)i];
+    }
+    void release(Job *, SlotScratch &) override {}
+};
+
+// ------------------------------------------------------------------------------------
+// Insert, link half: the back-edge loop of ConnectAtLayer (:196-214) and PruneOverflow
+// (:222-262), regrouped per (neighbour, layer): every append to one adjacency list, in
+// item order, with its overflow prune.  Distinct lists never interact, so the groups run
+// as independent jobs and the outcome equals the sequential loop's.
+// ------------------------------------------------------------------------------------
+struct LinkJob : Job {
+    Graph *g;
+    int nb, layer;
+    std::vector<int> items;
+    size_t idx = 0;
+    int stage = 0; // 0 idle, 1 waiting for node<->edge distances, 2 pruning
+    Prune prune;
+
+    bool prepare(SlotIO &io, SlotScratch &) override
+    {
+        const int maxE = g->max_edges_at(layer);
+        for (;;) {
+            if (stage == 2) {
+                if (prune.prepare(io)) return true;
+                int *l = g->list(nb, layer); // node.OutEdges[layer] = newOut :236
+                l[0] = (int)prune.acc.size();
+                std::memcpy(l + 1, prune.acc.data(), sizeof(int) * prune.acc.size());
+                stage = 0;
+            }
+            if (idx == items.size()) return false;
+            int *l = g->list(nb, layer);
+            l[1 + l[0]] = items[idx++]; // neighbor.OutEdges[layer].Add(currNode.Id) :207
+            l[0]++;
+            if (l[0] > maxE) { // :209
+                *io.qidx = ~nb; // Distance(cand, node.Id) :233
+                std::memcpy(io.ids, l + 1, sizeof(int) * (size_t)l[0]);
+                *io.cnt = l[0];
+                stage = 1;
+                return true;
+            }
+        }
+    }
+    void consume(const SlotIO &io, SlotScratch &) override
+    {
+        if (stage == 1) {
+            const int n = *io.cnt;
+            prune.cands.resize((size_t)n);
+            for (int i = 0; i < n; ++i) prune.cands[(size_t)i] = NodeDist{io.ids[i], io.dist[i]}; // :230-234
+            prune.begin(g->max_edges_at(layer)); // :235
+            stage = 2;
+        } else {
+            prune.consume(io);
+        }
+    }
+};
+
+struct LinkSource : JobSource {
+    std::vector<LinkJob> jobs;
+    std::atomic<int> next{0};
+    Job *acquire(SlotScratch &) override
+    {
+        int i = next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= (int)jobs.size()) return nullptr;
+        return &jobs[(size_t)i];
+    }
+    void release(Job *, SlotScratch &) override {}
+};
+
+constexpr int kBatchGrowthDiv = 32; // a snapshot batch never exceeds 1/32 of the linked graph
+
+} // namespace
+
+// ------------------------------------------------------------------------------------
+HnswIndex *HnswIndex::create(int metric, const Params &p, std::string &err)
+{
+    if (metric < 0 || metric > 2) { err = "Unsupported distance metric"; return nullptr; }
+    int ndev = hnswdev_device_count();
+    if (ndev <= 0) {
+        err = "HNSWIndex MI355X backend: no HIP device available (" + get_dev_error() +
+              "); this library has no CPU fallback";
+        return nullptr;
+    }
+    int dev = p.device;
+    if (dev < 0) {
+        const char *e = std::getenv("HNSW_MI355X_DEVICE");
+        dev = e ? std::atoi(e) : 0;
+    }
+    if (dev < 0 || dev >= ndev) { err = "HNSWIndex MI355X backend: device ordinal out of range"; return nullptr; }
+    if (p.max_edges < 1) { err = "MaxEdges must be >= 1"; return nullptr; }
+    HnswIndex *ix = new HnswIndex();
+    ix->metric_ = metric;
+    ix->p_ = p;
+    ix->device_ordinal_ = dev;
+    ix->graph_.configure(p.max_edges);
+    // RandomSeed < 0 means an unseeded Random() in the reference (GraphData.cs:42); a
+    // time-based seed reproduces that behaviour.
+    int seed = p.random_seed;
+    if (seed < 0) seed = (int)(std::chrono::steady_clock::now().time_since_epoch().count() & 0x7fffffff);
+    ix->rng_.init(seed);
+    ix->capacity_ = std::max(1, p.collection_size);
+    int th = p.host_threads;
+    if (th <= 0) {
+        const char *e = std::getenv("HNSW_MI355X_THREADS");
+        th = e ? std::atoi(e) : 0;
+    }
+    if (th <= 0) th = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    ix->threads_ = th;
+    return ix;
+}
+
+HnswIndex::~HnswIndex()
+{
+    engine_.reset(); // before the device it allocates from
+    dev_.reset();
+}
+
+bool HnswIndex::ensure_dim(int dim, std::string &err)
+{
+    if (dim_ == 0) {
+        Device *d = Device::create(device_ordinal_, dim, metric_, capacity_);
+        if (!d) { err = get_dev_error(); return false; }
+        dev_.reset(d);
+        dev_->set_profiling(profiling_);
+        dim_ = dim;
+        engine_stride_ = ((2 * p_.max_edges + 1) + 7) & ~7;
+        engine_.reset(new LockStepEngine(dev_.get(), std::max(2, p_.search_slots), engine_stride_, threads_));
+        if (!engine_->ok()) { err = get_dev_error(); return false; }
+        graph_.reserve((int)std::min<long long>(capacity_, 1 << 26));
+        return true;
+    }
+    if (dim != dim_) {
+        err = "dimension mismatch: index holds dim=" + std::to_string(dim_) + ", got dim=" + std::to_string(dim);
+        return false;
+    }
+    return true;
+}
+
+bool HnswIndex::ensure_capacity(long long need, std::string &err)
+{
+    if (need <= capacity_) return true;
+    long long cap = capacity_;
+    while (cap < need) cap *= 2; // GraphData.cs:100
+    if (!dev_->reserve(cap)) { err = get_dev_error(); return false; }
+    capacity_ = cap;
+    return true;
+}
+
+// One snapshot batch: ids [first_id, first_id + n) are nodes without edges yet.
+bool HnswIndex::insert_batch(int first_id, int n, std::string &err)
+{
+    const int cap = (int)capacity_;
+    InsertSource src;
+    src.jobs.resize((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        InsertJob &j = src.jobs[(size_t)i];
+        j.g = &graph_;
+        j.capacity = cap;
+        j.id = first_id + i;
+        j.level = graph_.level[(size_t)j.id];
+        j.efc = p_.max_candidates;
+    }
+    if (!engine_->run(src, n)) { err = get_dev_error(); return false; }
+
+    // link, part 1 (host only): currNode.OutEdges[layer] = selected (:192) and collect the
+    // back-edge appends per (neighbour, layer), in item order.
+    LinkSource links;
+    std::unordered_map<uint64_t, size_t> where;
+    where.reserve((size_t)n * 40);
+    for (int i = 0; i < n; ++i) {
+        InsertJob &j = src.jobs[(size_t)i];
+        const int top = std::min(j.level, graph_.top_layer());
+        for (int layer = top; layer >= 0; --layer) {
+            const std::vector<int> &sel = j.selected[(size_t)layer];
+            int *l = graph_.list(j.id, layer);
+            l[0] = (int)sel.size();
+            std::memcpy(l + 1, sel.data(), sizeof(int) * sel.size());
+            for (int nb : sel) {
+                uint64_t key = ((uint64_t)(uint32_t)nb << 8) | (uint64_t)(uint32_t)layer;
+                auto it = where.find(key);
+                if (it == where.end()) {
+                    where.emplace(key, links.jobs.size());
+                    links.jobs.emplace_back();
+                    LinkJob &lj = links.jobs.back();
+                    lj.g = &graph_;
+                    lj.nb = nb;
+                    lj.layer = layer;
+                    lj.items.push_back(j.id);
+                } else {
+                    links.jobs[it->second].items.push_back(j.id);
+                }
+            }
+        }
+    }
+    if (!links.jobs.empty() && !engine_->run(links, (long long)links.jobs.size())) { err = get_dev_error(); return false; }
+    return true;
+}
+
+int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::string &err)
+{
+    if (!ensure_dim(dim, err)) return -1;
+    // GraphData.AddItem (src/HNSWIndex/GraphData.cs:79-118): one RNG draw per item, in order.
+    std::vector<int> ids((size_t)count);
+    int n_new = 0;
+    const int first_new = graph_.length;
+    for (int i = 0; i < count; ++i) {
+        int lvl = level_from_uniform(rng_.next_single(), p_.distribution_rate);
+        if (lvl < 0) { ids[(size_t)i] = -1; ++skipped_; continue; } // :82
+        if (lvl > 200) { err = "level draw out of range"; return -1; }
+        ids[(size_t)i] = graph_.add_node(lvl);
+        ++n_new;
+    }
+    if (!ensure_capacity(graph_.length, err)) return -1;
+    // rows -> HBM (id == row index)
+    if (n_new == count) {
+        if (!dev_->upload_rows(first_new, count, vectors)) { err = get_dev_error(); return -1; }
+    } else {
+        for (int i = 0; i < count; ++i)
+            if (ids[(size_t)i] >= 0 && !dev_->upload_rows(ids[(size_t)i], 1, vectors + (size_t)i * dim)) { err = get_dev_error(); return -1; }
+    }
+    // GraphConnector.ConnectNewNode (:24-47), batched
+    int pos = first_new;
+    const int end = graph_.length;
+    const int bmax = std::max(1, p_.insert_batch);
+    while (pos < end) {
+        if (graph_.entry < 0) { graph_.entry = pos++; continue; } // :28-33
+        const int top = graph_.top_layer();
+        if (graph_.level[(size_t)pos] > top) { // new entry point: alone, under the "entry point lock" (:36-41)
+            if (!insert_batch(pos, 1, err)) return -1;
+            graph_.entry = pos++;
+            continue;
+        }
+        int b = std::min(bmax, std::max(1, pos / kBatchGrowthDiv));
+        int n = 1;
+        while (n < b && pos + n < end && graph_.level[(size_t)(pos + n)] <= top) ++n;
+        if (!insert_batch(pos, n, err)) return -1;
+        pos += n;
+    }
+    if (out_ids) for (int i = 0; i < count; ++i) out_ids[i] = ids[(size_t)i];
+    return count;
+}
+
+int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *out_ids, float *out_dists, std::string &err)
+{
+    if (count <= 0) return 0;
+    if (k < 1 || graph_.entry < 0) { // HNSWIndex.cs:109: empty result lists, padded by the export
+        for (long long j = 0; j < (long long)count * std::max(k, 0); ++j) { out_ids[j] = -1; out_dists[j] = std::numeric_limits<float>::quiet_NaN(); }
+        return 0;
+    }
+    if (!ensure_dim(dim, err)) return -1;
+    if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; }
+    QuerySource src;
+    src.jobs.resize((size_t)count);
+    const int ef = std::max(p_.min_nn, k); // :115
+    for (int i = 0; i < count; ++i) {
+        QueryJob &j = src.jobs[(size_t)i];
+        j.g = &graph_;
+        j.capacity = (int)capacity_;
+        j.qi = i;
+        j.ef = ef;
+        j.k = k;
+        j.out_ids = out_ids + (size_t)i * k;
+        j.out_d = out_dists + (size_t)i * k;
+    }
+    if (!engine_->run(src, count)) { err = get_dev_error(); return -1; }
+    return 0;
+}
+
+uint64_t HnswIndex::graph_hash() const
+{
+    uint64_t x = 1469598103934665603ULL;
+    auto mix = [&](int v) {
+        uint32_t u = (uint32_t)v;
+        for (int b = 0; b < 4; ++b) { x ^= (u >> (8 * b)) & 0xff; x *= 1099511628211ULL; }
+    };
+    mix(graph_.entry);
+    for (int i = 0; i < graph_.length; ++i) {
+        mix(graph_.level[(size_t)i]);
+        for (int l = 0; l <= graph_.level[(size_t)i]; ++l) {
+            const int *e = graph_.list(i, l);
+            mix(e[0]);
+            for (int j = 1; j <= e[0]; ++j) mix(e[j]);
+        }
+    }
+    return x;
+}
+
+} // namespace hnsw

@@ -1,0 +1,69 @@
+// hnsw_index.h -- host-side mirror of HNSWIndex<float[],float> for the Add / KnnQuery path
+// (src/HNSWIndex/HNSWIndex.cs:20-29,55-78,107-137), with every distance evaluated by the
+// gfx950 backend through the lock-step engine.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device_backend.h"
+#include "host_structs.h"
+#include "search_engine.h"
+
+namespace hnsw {
+
+// src/HNSWIndex/HNSWParameters.cs:13-55 plus the backend knobs.
+struct Params {
+    int max_edges = 16;
+    double distribution_rate = 0.36067376022224085; // 1 / Math.Log(16)
+    int min_nn = 5;
+    int max_candidates = 100;
+    int remove_max_candidates = 100;
+    int collection_size = 65536;
+    int random_seed = 31337;
+    bool allow_removals = true;
+    // backend
+    int device = -1;         // -1: HNSW_MI355X_DEVICE or 0
+    int insert_batch = 4096; // 1 = strictly sequential inserts
+    int search_slots = 4096;
+    int host_threads = 0;    // 0: min(hardware threads, 16)
+};
+
+class HnswIndex {
+public:
+    static HnswIndex *create(int metric, const Params &p, std::string &err);
+    ~HnswIndex();
+
+    // hnsw_add: returns number of ids written or -1.
+    int add(const float *vectors, int count, int dim, int *out_ids, std::string &err);
+    // hnsw_knn_query: 0 or -1.
+    int knn_query(const float *queries, int count, int dim, int k, int *out_ids, float *out_dists, std::string &err);
+
+    int count() const { return graph_.length; }
+    const Graph &graph() const { return graph_; }
+    Device *device() { return dev_.get(); }
+    uint64_t graph_hash() const;
+    void set_profiling(bool on) { profiling_ = on; if (dev_) dev_->set_profiling(on); }
+
+private:
+    HnswIndex() = default;
+    bool ensure_dim(int dim, std::string &err);
+    bool ensure_capacity(long long need, std::string &err);
+    bool insert_batch(int first_id, int n, std::string &err);
+
+    int metric_ = 0;
+    int dim_ = 0; // fixed by the first add (the reference takes it from the arrays)
+    Params p_;
+    Graph graph_;
+    DotnetRandom rng_;
+    std::unique_ptr<Device> dev_;
+    std::unique_ptr<LockStepEngine> engine_;
+    int engine_stride_ = 0;
+    long long capacity_ = 0; // GraphData.Capacity (doubling, GraphData.cs:98-111)
+    int skipped_ = 0;
+    int device_ordinal_ = 0;
+    int threads_ = 1;
+    bool profiling_ = false;
+};
+
+} // namespace hnsw

@@ -1,0 +1,165 @@
+/*
+ * hnsw_mi355x.h -- C ABI of the MI355X-native distance backend for HNSWIndex.Net's
+ * Add / KnnQuery hot path.
+ *
+ * Two boundaries, one shared library (artifacts/native/linux-x64/HNSWIndex.Native.so):
+ *
+ *  (A) OUTER boundary -- the reference's own 16 cdecl exports, same names, argument order,
+ *      C types, return codes and padding, so the reference's ctypes wrapper
+ *      (bindings/bindings.py:45-119) and any C host bind unchanged.  Each prototype cites
+ *      the [UnmanagedCallersOnly] export it replaces in
+ *      /root/reference/bindings/HNSWIndex.Native/HNSWIndexExports.cs.
+ *
+ *  (B) INNER boundary -- the batched candidate-distance backend a C# (or any) host
+ *      P/Invokes in place of the scalar-pair delegate
+ *      `Func<float[],float[],float> distFnc` (src/HNSWIndex/HNSWIndex.cs:20) that
+ *      GraphData.Distance invokes one pair at a time (src/HNSWIndex/GraphData.cs:255-277).
+ *      The reference has no batched hook; this is the hook.  INTEGRATION.md shows the
+ *      C# binding.
+ *
+ * Conventions: plain pointers and sizes only; inputs are borrowed for the duration of the
+ * call; outputs are caller-allocated unless stated; no exception crosses the boundary.
+ * Every distance is computed by hand-written HIP kernels on gfx950; there is no CPU
+ * fallback -- with no HIP device the calls fail and say so.
+ */
+#ifndef HNSW_MI355X_H
+#define HNSW_MI355X_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* =====================================================================================
+ * (A) Outer boundary: the reference's 16 exports
+ * ===================================================================================== */
+
+/* HNSWIndexExports.cs:27-39  GetLastErrorUtf8.  Copies at most buf_len-1 bytes of the last
+ * error (UTF-8) and NUL-terminates; returns the byte count needed (without the NUL). */
+int hnsw_get_last_error_utf8(void *buf, int buf_len);
+
+/* :41-65  Create.  metric: "sq_euclid" | "cosine" | "ucosine".  Consumes and resets the
+ * process-global pending parameters set by hnsw_set_* (:16, :61).  Returns 0 on error. */
+void *hnsw_create(const char *distance_metric);
+
+/* :67-73  Free. handle == 0 is ignored. */
+void hnsw_free(void *handle);
+
+/* :75-100  Add.  vectors: count x dim row-major float32.  Writes the assigned ids to
+ * out_ids[count]; returns the number written, 0 for a null handle / null vectors /
+ * count <= 0 / dim <= 0, -1 on error.  The reference inserts with Parallel.For
+ * (src/HNSWIndex/HNSWIndex.cs:70-78): a scheduler-dependent interleaving.  Here the batch
+ * is inserted in id order with snapshot-batched searches (DESIGN.md "Add"); a call with
+ * count == 1 -- the reference's own recipe for deterministic builds,
+ * bindings/__tests__/parameters_test.py:65-68 -- is exactly the sequential
+ * HNSWIndex.Add(item) (HNSWIndex.cs:55-65). */
+int hnsw_add(void *handle, const float *vectors, int count, int dim, int *out_ids);
+
+/* :102-117  Remove.  Not on the hot path (out of scope this round):
+ * returns -1 and sets the last error; 0 for a null handle / null ids / count <= 0. */
+int hnsw_remove(void *handle, const int *ids, int count);
+
+/* :119-149  KnnQuery -> BatchKnnQuery (HNSWIndex.cs:129-137).  out_ids / out_dists are
+ * count x k row-major; rows with fewer than k results are padded with id -1, dist NaN
+ * (:144).  Returns 0 on success (and for a null handle), -1 on error. */
+int hnsw_knn_query(void *handle, const float *vectors, int count, int dim, int k, int *out_ids, float *out_dists);
+
+/* :151-197  RangeQuery.  SURVEY.md 8f "next": returns -1 and sets the last error. */
+int hnsw_range_query(void *handle, const float *vectors, int count, int dim, float range, void **out_ids,
+                     void **out_dists, int *counts);
+
+/* :199-217  FreeRangeResults.  Frees (with free()) whatever hnsw_range_query allocated. */
+void hnsw_free_results(void **ids_array, void **dists_array, int count);
+
+/* :219-273  pending-parameter setters (defaults: src/HNSWIndex/HNSWParameters.cs:13-55).
+ * They mutate a process-global parameter block that the NEXT hnsw_create consumes. */
+int hnsw_set_collection_size(int collection_size);       /* :219 */
+int hnsw_set_max_edges(int max_edges);                   /* :226 */
+int hnsw_set_max_candidates(int max_candidates);         /* :233 */
+int hnsw_set_remove_max_candidates(int max_candidates);  /* :240 */
+int hnsw_set_distribution_rate(float dist_rate);         /* :247 */
+int hnsw_set_random_seed(int seed);                      /* :254 */
+int hnsw_set_min_nn(int min_nn);                         /* :261 */
+int hnsw_set_allow_removals(bool allow_removals);        /* :268 */
+
+/* ---- additions next to the reference's surface (not in the reference) ---------------- */
+
+/* Pending, like hnsw_set_*: HIP device ordinal for the next hnsw_create (default: the
+ * HNSW_MI355X_DEVICE environment variable, else 0). */
+int hnsw_mi355x_set_device(int device);
+/* Pending: cap on the snapshot batch of hnsw_add (1 = strictly sequential inserts;
+ * default 4096).  See DESIGN.md "Add". */
+int hnsw_mi355x_set_insert_batch(int max_batch);
+/* Pending: number of concurrent search slots of the lock-step driver (default 4096) and
+ * host worker threads (default: min(hardware threads, 16)). */
+int hnsw_mi355x_set_search_slots(int slots);
+int hnsw_mi355x_set_host_threads(int threads);
+
+/* Graph introspection for parity checks (reads host state only). */
+int hnsw_mi355x_count(void *handle);
+int hnsw_mi355x_entry_point(void *handle);
+int hnsw_mi355x_node_max_layer(void *handle, int id);
+/* Copies up to cap out-edge ids of (id, layer); returns the edge count or -1. */
+int hnsw_mi355x_get_out_edges(void *handle, int id, int layer, int *out, int cap);
+uint64_t hnsw_mi355x_graph_hash(void *handle);
+
+/* Counters of the index's device context (see hnswdev_stats). */
+struct hnswdev_stats;
+int hnsw_mi355x_get_stats(void *handle, struct hnswdev_stats *out);
+int hnsw_mi355x_reset_stats(void *handle);
+int hnsw_mi355x_set_profiling(void *handle, int enabled);
+
+/* =====================================================================================
+ * (B) Inner boundary: batched candidate-distance backend
+ *     replaces GraphData.Distance(int, TVector) / Distance(int, int)
+ *     (src/HNSWIndex/GraphData.cs:255-277) at the 14 call sites of SURVEY.md 8a.
+ * ===================================================================================== */
+
+enum { HNSWDEV_SQ_EUCLID = 0, HNSWDEV_COSINE = 1, HNSWDEV_UCOSINE = 2 };
+
+typedef struct hnswdev_stats {
+    uint64_t launches;      /* distance-kernel launches */
+    uint64_t evals;         /* distance evaluations (one candidate row read each) */
+    uint64_t timed_launches;/* launches bracketed by HIP events (profiling on) */
+    uint64_t timed_evals;   /* evaluations inside those launches */
+    double kernel_ms;       /* sum of HIP-event durations of the timed launches */
+    uint64_t row_bytes;     /* dim * sizeof(float): algorithmic bytes per evaluation */
+} hnswdev_stats;
+
+/* All return 0 on success, < 0 on error (message via hnswdev_last_error). */
+
+/* Creates a context on HIP device `device` holding up to `capacity` rows of `dim` float32
+ * in one contiguous row-major HBM matrix (id == row index, GraphData.cs:95-115). */
+int hnswdev_create(int device, int dim, int metric, long long capacity, void **ctx);
+int hnswdev_destroy(void *ctx);
+/* Grows the matrix (contents preserved); the counterpart of the doubling resize at
+ * GraphData.cs:98-111. */
+int hnswdev_reserve(void *ctx, long long capacity);
+/* Copies rows [first_id, first_id+n) host -> HBM (and, for cosine, computes each row's
+ * f32 squared norm in the reference's lane order and its double sqrt on the device). */
+int hnswdev_upload_rows(void *ctx, int first_id, int n, const float *rows);
+/* Reads rows back (parity checks). */
+int hnswdev_download_rows(void *ctx, int first_id, int n, float *rows);
+
+/* Distance(int a, TVector b) for many (query, candidate-list) pairs at once:
+ * out[j] = metric(row[cand_ids[j]], queries[i]) for cand_offsets[i] <= j < cand_offsets[i+1].
+ * queries: nq x dim host floats; cand_offsets: nq+1 ints; synchronous. */
+int hnswdev_dist_query_batch(void *ctx, const float *queries, int nq, const int *cand_offsets, const int *cand_ids,
+                             float *out);
+/* Distance(int a, int b): out[j] = metric(row[a_ids[j]], row[b_ids[j]]); synchronous. */
+int hnswdev_dist_pair_batch(void *ctx, const int *a_ids, const int *b_ids, int n, float *out);
+
+int hnswdev_sync(void *ctx);
+int hnswdev_set_profiling(void *ctx, int enabled);
+int hnswdev_get_stats(void *ctx, hnswdev_stats *out);
+int hnswdev_reset_stats(void *ctx);
+int hnswdev_last_error(char *buf, int buf_len);
+/* Number of visible HIP devices (>= 0), or < 0 on error. */
+int hnswdev_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNSW_MI355X_H */

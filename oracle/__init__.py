@@ -43,6 +43,7 @@ def lib():
         L.orc_free.argtypes = [ct.c_void_p]
         L.orc_free.restype = None
         L.orc_add.argtypes = [ct.c_void_p, _F, ct.c_int, _I]
+        L.orc_add_batched.argtypes = [ct.c_void_p, _F, ct.c_int, _I, ct.c_int]
         L.orc_knn_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, _I, _F, ct.c_int]
         for name in ("orc_count", "orc_entry_point", "orc_capacity"):
             getattr(L, name).argtypes = [ct.c_void_p]
@@ -174,9 +175,17 @@ class OracleIndex:
             self._h = None
 
     def add(self, vecs):
+        """Sequential HNSWIndex.Add(item) per row, in order."""
         a = _f32(vecs).reshape(-1, self.dim)
         ids = np.empty(a.shape[0], dtype=np.int32)
         lib().orc_add(self._h, _pf(a), a.shape[0], _pi(ids))
+        return ids
+
+    def add_batched(self, vecs, max_batch=4096):
+        """The product's snapshot-batched schedule (see orc_add_batched)."""
+        a = _f32(vecs).reshape(-1, self.dim)
+        ids = np.empty(a.shape[0], dtype=np.int32)
+        lib().orc_add_batched(self._h, _pf(a), a.shape[0], _pi(ids), int(max_batch))
         return ids
 
     def knn_query(self, queries, k, threads=1):

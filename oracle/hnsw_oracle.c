@@ -751,6 +751,113 @@ static int add_one(sctx_t *c, const float *v)
 }
 
 /* ------------------------------------------------------------------------------------
+ * Snapshot-batched Add -- NOT a reference code path.  It is the deterministic schedule the
+ * product's hnsw_add uses for count > 1 (DESIGN.md "Add"), restated here on the CPU so that
+ * the GPU result can be checked bit for bit.  It is one legal outcome of the reference's
+ * Parallel.For Add(List) (HNSWIndex.cs:70-78) in which the B items of a batch all finish
+ * their searches before any of them links:
+ *   search half, per item, on the graph as it stands before the batch:
+ *       FindEntryPoint + for every layer SearchLayer -> RelativeNeighborPruning
+ *       (GraphConnector.cs:174-179, :189-190; next entry = selected[0], :216)
+ *   link half, items in id order: OutEdges = selected (:192), back-edges and
+ *       PruneOverflow (:196-214).
+ * A batch is at most max(1, linked/32) items (capped by max_batch); an item whose level
+ * exceeds the current top layer is inserted alone (the reference holds the entry-point lock
+ * for it, GraphConnector.cs:27-41).  max_batch == 1 is exactly orc_add.
+ * ---------------------------------------------------------------------------------- */
+static int alloc_node(index_t *ix, const float *v)
+{
+    int top_layer = level_from_uniform(rng_next_single(&ix->rng), ix->dist_rate);
+    if (top_layer < 0) return -1;
+    int id = ix->length++;
+    if (ix->length > ix->capacity) grow(ix);
+    node_init(ix, &ix->nodes[id], top_layer);
+    memcpy(ix->items + (size_t)id * (size_t)ix->dim, v, sizeof(float) * (size_t)ix->dim);
+    ix->count++;
+    return id;
+}
+
+static void batch_search(sctx_t *c, int id, edges_t *sel /* [max_layer+1] */)
+{
+    index_t *ix = c->ix;
+    node_t *cur = &ix->nodes[id];
+    int top = ix->nodes[ix->entry].max_layer;
+    int best = find_entry_point(c, cur->max_layer, item(ix, id));
+    int start = cur->max_layer < top ? cur->max_layer : top;
+    for (int l = 0; l <= cur->max_layer; l++) { sel[l].buf = NULL; sel[l].count = 0; sel[l].cap = 0; }
+    for (int layer = start; layer >= 0; --layer) {
+        nd_t *topc;
+        int n = search_layer(c, best, layer, ix->max_candidates, item(ix, id), &topc);
+        sel[layer] = relative_neighbor_pruning(c, topc, n, max_edges_at(ix, layer));
+        free(topc);
+        best = sel[layer].buf[0];
+    }
+}
+
+static void batch_link(sctx_t *c, int id, edges_t *sel)
+{
+    index_t *ix = c->ix;
+    int top = ix->nodes[ix->entry].max_layer;
+    int lvl = ix->nodes[id].max_layer;
+    int start = lvl < top ? lvl : top;
+    for (int layer = start; layer >= 0; --layer) {
+        node_t *cur = &ix->nodes[id];
+        free(cur->out[layer].buf);
+        cur->out[layer] = sel[layer];
+        if (ix->allow_removals) { free(cur->in[layer].buf); cur->in[layer] = edges_copy(&sel[layer]); }
+        int cnt = sel[layer].count;
+        for (int i = 0; i < cnt; ++i) {
+            int nb_id = ix->nodes[id].out[layer].buf[i];
+            node_t *nb = &ix->nodes[nb_id];
+            if (ix->allow_removals) edges_add(&nb->in[layer], id);
+            edges_add(&nb->out[layer], id);
+            if (nb->out[layer].count > max_edges_at(ix, layer)) prune_overflow(c, nb_id, layer);
+        }
+    }
+}
+
+ORC_API int orc_add_batched(void *h, const float *v, int n, int *out_ids, int max_batch)
+{
+    index_t *ix = (index_t *)h;
+    if (!ix || !v || n <= 0) return 0;
+    if (max_batch < 1) max_batch = 1;
+    sctx_t c = {ix, &ix->vis, 0};
+    int first = ix->length;
+    for (int i = 0; i < n; i++) {
+        int id = alloc_node(ix, v + (size_t)i * (size_t)ix->dim);
+        if (out_ids) out_ids[i] = id;
+    }
+    int pos = first, end = ix->length;
+    while (pos < end) {
+        if (ix->entry < 0) { ix->entry = pos++; continue; }
+        int top = ix->nodes[ix->entry].max_layer;
+        int nb = 1, new_ep = 0;
+        if (ix->nodes[pos].max_layer > top) {
+            new_ep = 1;
+        } else {
+            int b = pos / 32;
+            if (b < 1) b = 1;
+            if (b > max_batch) b = max_batch;
+            while (nb < b && pos + nb < end && ix->nodes[pos + nb].max_layer <= top) nb++;
+        }
+        edges_t **sels = (edges_t **)malloc(sizeof(edges_t *) * (size_t)nb);
+        for (int i = 0; i < nb; i++) {
+            sels[i] = (edges_t *)calloc((size_t)ix->nodes[pos + i].max_layer + 1, sizeof(edges_t));
+            batch_search(&c, pos + i, sels[i]);
+        }
+        for (int i = 0; i < nb; i++) {
+            batch_link(&c, pos + i, sels[i]);
+            free(sels[i]);
+        }
+        free(sels);
+        if (new_ep) ix->entry = pos;
+        pos += nb;
+    }
+    ix->n_eval += c.n_eval;
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------
  * C API (ctypes)
  * ---------------------------------------------------------------------------------- */
 ORC_API void *orc_create(int dim, int metric, int max_edges, double dist_rate, int min_nn, int max_candidates,

@@ -1,0 +1,36 @@
+"""Shared helpers for the test tiers."""
+import json
+from pathlib import Path
+
+import numpy as np
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def uniform(n, dim, seed):
+    """Reference tests use i.i.d. uniform [0,1) float32 (src/HNSWIndex.Tests/Utils.cs:35-49)."""
+    return np.random.default_rng(seed).random((n, dim), dtype=np.float32)
+
+
+def normalize_f32(x):
+    """Utils.Normalize (Utils.cs:23-30) in float32."""
+    return (x / np.sqrt((x * x).sum(axis=1, dtype=np.float32, keepdims=True))).astype(np.float32)
+
+
+def golden_cases():
+    return sorted(p.stem for p in GOLDEN.glob("*.json"))
+
+
+def load_golden(name):
+    g = json.loads((GOLDEN / f"{name}.json").read_text())
+    x = uniform(g["n"], g["dim"], g["data_seed"])
+    q = uniform(g["nq"], g["dim"], g["query_seed"])
+    if g["metric"] == "ucosine":
+        x, q = normalize_f32(x), normalize_f32(q)
+    return g, x, q
+
+
+def self_recall_at_1(index, x, ids, **kw):
+    """Utils.Recall with k=1 on the inserted vectors (Utils.cs:54-70)."""
+    res, _ = index.knn_query(x, 1, **kw)
+    return float((res[:, 0] == ids).mean())

@@ -1,0 +1,106 @@
+"""CPU tier: the C-ABI library loads, exports every symbol include/*.h declares, and keeps
+the reference's error conventions (HNSWIndexExports.cs) without touching a GPU."""
+import ctypes as ct
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def net():
+    import hnswindex
+    return hnswindex.net_amd
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "hnsw_mi355x.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hnsw(?:dev|_mi355x)?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_16_reference_exports():
+    want = {"hnsw_get_last_error_utf8", "hnsw_create", "hnsw_free", "hnsw_add", "hnsw_remove", "hnsw_knn_query",
+            "hnsw_range_query", "hnsw_free_results", "hnsw_set_collection_size", "hnsw_set_max_edges",
+            "hnsw_set_max_candidates", "hnsw_set_remove_max_candidates", "hnsw_set_distribution_rate",
+            "hnsw_set_random_seed", "hnsw_set_min_nn", "hnsw_set_allow_removals"}
+    assert want <= set(_declared_symbols())
+
+
+def test_library_exports_every_declared_symbol(net):
+    syms = _declared_symbols()
+    assert len(syms) >= 16 + 12
+    for s in syms:
+        assert hasattr(net.lib, s), s
+
+
+def test_library_is_at_the_reference_loader_path(net):
+    # /root/reference/bindings/bindings.py:27-41
+    assert net.LIB_PATH.parts[-4:] == ("artifacts", "native", "linux-x64", "HNSWIndex.Native.so")
+
+
+def _has_gpu(net):
+    return net.lib.hnswdev_device_count() > 0
+
+
+def test_null_handle_conventions(net):
+    lib = net.lib
+    v = np.zeros((2, 4), dtype=np.float32)
+    ids = np.zeros(2, dtype=np.int32)
+    F, I = ct.POINTER(ct.c_float), ct.POINTER(ct.c_int)
+    assert lib.hnsw_add(None, v.ctypes.data_as(F), 2, 4, ids.ctypes.data_as(I)) == 0      # Exports.cs:78
+    assert lib.hnsw_remove(None, ids.ctypes.data_as(I), 2) == 0                            # :105
+    d = np.zeros((2, 3), dtype=np.float32)
+    o = np.zeros((2, 3), dtype=np.int32)
+    assert lib.hnsw_knn_query(None, v.ctypes.data_as(F), 2, 4, 3, o.ctypes.data_as(I), d.ctypes.data_as(F)) == 0  # :122
+    lib.hnsw_free(None)                                                                     # :69
+    lib.hnsw_free_results(None, None, 3)                                                    # :202
+
+
+def test_setters_return_zero_and_unknown_metric_fails_with_message(net):
+    lib = net.lib
+    for name, val in (("hnsw_set_collection_size", 128), ("hnsw_set_max_edges", 8), ("hnsw_set_max_candidates", 50),
+                      ("hnsw_set_remove_max_candidates", 50), ("hnsw_set_random_seed", 7), ("hnsw_set_min_nn", 3)):
+        assert getattr(lib, name)(val) == 0
+    assert lib.hnsw_set_distribution_rate(0.5) == 0
+    assert lib.hnsw_set_allow_removals(False) == 0
+    assert not lib.hnsw_create(b"manhattan")                      # Exports.cs:58-59,64
+    msg = net.last_error()
+    assert "Unsupported distance metric" in msg and "manhattan" in msg
+    # last-error getter: returns needed byte count, truncates and NUL-terminates (:27-39)
+    need = lib.hnsw_get_last_error_utf8(None, 0)
+    assert need == len(msg.encode())
+    buf = ct.create_string_buffer(8)
+    assert lib.hnsw_get_last_error_utf8(buf, 8) == need
+    assert buf.value == msg.encode()[:7]
+    # a failed create must NOT consume the pending parameters; reset them for other tests
+    for name, val in (("hnsw_set_collection_size", 65536), ("hnsw_set_max_edges", 16), ("hnsw_set_max_candidates", 100),
+                      ("hnsw_set_remove_max_candidates", 100), ("hnsw_set_random_seed", 31337), ("hnsw_set_min_nn", 5)):
+        getattr(lib, name)(val)
+    lib.hnsw_set_distribution_rate(float(1 / np.log(16)))
+    lib.hnsw_set_allow_removals(True)
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback(net):
+    if _has_gpu(net):
+        pytest.skip("a HIP device is present")
+    assert not net.lib.hnsw_create(b"sq_euclid")
+    assert "no HIP device" in net.last_error() and "no CPU fallback" in net.last_error()
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        net.Index(8).add(np.zeros((1, 8), dtype=np.float32))
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        net.DeviceBackend(8)
+
+
+def test_product_never_references_the_oracle():
+    # the oracle is test infrastructure: nothing under the package may import, link, load
+    # or call it (comments may mention it)
+    pat = re.compile(r"import\s+oracle|from\s+oracle|oracle/|oracle\\.|libhnsw_oracle|\borc_[a-z]")
+    files = [p for p in (ROOT / "hnswindex.net_amd").rglob("*") if p.is_file() and p.suffix in (".py", ".cpp", ".hip", ".h")]
+    files.append(ROOT / "hnswindex" / "__init__.py")
+    assert len(files) > 8
+    for p in files:
+        assert not pat.search(p.read_text()), p

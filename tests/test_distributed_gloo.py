@@ -1,0 +1,70 @@
+"""CPU tier: the multi-GPU query-sharding path (hnswindex.net_amd/distributed.py) on two
+gloo ranks.  The local searcher is the oracle here (test tier only); on the GPU box the
+same function is handed `Index.knn_query`."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, nq, k, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    import hnswindex
+    from common import uniform
+    x, q = uniform(1500, 32, 1), uniform(nq, 32, 2)
+    ix = oracle.OracleIndex(32)  # every rank holds a replica, built identically
+    ix.add(x)
+    calls = []
+
+    def search(qs, kk):
+        calls.append(qs.shape[0])
+        return ix.knn_query(qs, kk)
+
+    ids, d = hnswindex.net_amd.distributed.knn_query_sharded(search, q, k)
+    full_ids, full_d = ix.knn_query(q, k)
+    ok = (ids == full_ids).all() and d.tobytes() == full_d.tobytes()
+    lo, hi = hnswindex.net_amd.distributed.shard_bounds(nq, world, rank)
+    ok = ok and calls == ([hi - lo] if hi > lo else [])
+    np.save(Path(out_dir) / f"ok_{rank}.npy", np.array([int(ok), hi - lo]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nq", [101, 2, 1])
+def test_sharded_query_equals_single_rank(tmp_path, nq):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, nq, 5, str(tmp_path)), nprocs=world, join=True)
+    sizes = []
+    for r in range(world):
+        ok, m = np.load(tmp_path / f"ok_{r}.npy")
+        assert ok == 1
+        sizes.append(int(m))
+    assert sum(sizes) == nq and max(sizes) - min(sizes) <= 1
+
+
+def test_shard_bounds_cover_without_overlap():
+    import hnswindex
+    sb = hnswindex.net_amd.distributed.shard_bounds
+    for n in (0, 1, 7, 8, 100000):
+        for w in (1, 2, 4, 8):
+            b = [sb(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))

@@ -1,0 +1,168 @@
+"""GPU tier: Add / KnnQuery through the reference-shaped C ABI and Python `Index`, against
+the oracle and the committed golden fixtures.  Integer results (ids, levels, adjacency,
+graph hash) bit-exact; distances bit-identical (north_star tolerance: 1e-5)."""
+import numpy as np
+import pytest
+
+import oracle
+from common import golden_cases, load_golden, normalize_f32, self_recall_at_1, uniform
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Index():
+    import hnswindex
+    assert hnswindex.net_amd.lib.hnswdev_device_count() > 0, "GPU tier needs a HIP device"
+    return hnswindex.Index
+
+
+def _build(Index, g, x):
+    ix = Index(g["dim"], g["metric"])
+    ix.set_collection_size(g["n"])
+    ix.set_random_seed(g["random_seed"])
+    ix.set_max_edges(g["params"]["max_edges"])
+    ix.set_max_candidates(g["params"]["max_candidates"])
+    ix.set_min_nn(g["params"]["min_nn"])
+    ix.set_insert_batch(g["batch"] if g["batch"] else 1)
+    ids = ix.add(x)
+    return ix, ids
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_fixture(Index, name):
+    g, x, q = load_golden(name)
+    ix, ids = _build(Index, g, x)
+    assert (ids == np.arange(g["n"])).all()
+    assert ix.levels()[:128].tolist() == g["levels_head"]
+    assert ix.entry_point == g["entry_point"]
+    assert f"{ix.graph_hash():016x}" == g["graph_hash"]
+    kid, kd = ix.knn_query(q, g["k"])
+    assert kid.tolist() == g["knn_ids"]
+    assert kd.view(np.uint32).tolist() == g["knn_dist_bits"]
+
+
+@pytest.mark.parametrize("metric", ["sq_euclid", "cosine", "ucosine"])
+def test_sequential_add_and_query_match_oracle(Index, metric):
+    n, dim = 1200, 128
+    x, q = uniform(n, dim, 21), uniform(200, dim, 22)
+    if metric == "ucosine":
+        x, q = normalize_f32(x), normalize_f32(q)
+    ix = Index(dim, metric)
+    ix.set_collection_size(256)                 # forces two doubling resizes
+    ix.set_insert_batch(1)
+    ids = ix.add(x)
+    ref = oracle.OracleIndex(dim, metric, collection_size=256)
+    assert (ids == ref.add(x)).all()
+    assert ix.graph_hash() == ref.graph_hash()
+    assert ix.entry_point == ref.entry_point
+    for i in (0, 1, n // 2, n - 1):
+        for layer in range(ref.max_layer(i) + 1):
+            assert ix.edges(i, layer).tolist() == ref.edges(i, layer).tolist()
+    for k in (1, 10, 50):
+        a_ids, a_d = ix.knn_query(q, k)
+        b_ids, b_d = ref.knn_query(q, k)
+        assert (a_ids == b_ids).all() and a_d.tobytes() == b_d.tobytes()
+
+
+def test_one_at_a_time_adds_equal_one_sequential_call(Index):
+    # bindings/__tests__/parameters_test.py:60-81 (the reference's determinism recipe)
+    x = uniform(400, 64, 31)
+    a = Index(64); a.set_random_seed(1337); a.set_collection_size(400)
+    for row in x:
+        a.add([row])
+    b = Index(64); b.set_random_seed(1337); b.set_collection_size(400); b.set_insert_batch(1)
+    b.add(x)
+    assert a.graph_hash() == b.graph_hash()
+    ref = oracle.OracleIndex(64, random_seed=1337, collection_size=400)
+    ref.add(x)
+    assert a.graph_hash() == ref.graph_hash()
+
+
+def test_batched_add_matches_oracle_schedule_and_recall(Index):
+    n, dim = 6000, 64
+    x = uniform(n, dim, 41)
+    ix = Index(dim)
+    ix.set_collection_size(n)
+    ix.set_insert_batch(512)
+    ids = ix.add(x)
+    ref = oracle.OracleIndex(dim, collection_size=n)
+    ref.add_batched(x, 512)
+    assert ix.graph_hash() == ref.graph_hash()
+    assert self_recall_at_1(ix, x, ids) > 0.85      # recall_test.py:15
+    # and adding in two calls continues the same deterministic schedule
+    iy = Index(dim); iy.set_collection_size(n); iy.set_insert_batch(512)
+    iy.add(x[:2500]); iy.add(x[2500:])
+    rz = oracle.OracleIndex(dim, collection_size=n)
+    rz.add_batched(x[:2500], 512); rz.add_batched(x[2500:], 512)
+    assert iy.graph_hash() == rz.graph_hash()
+
+
+def test_reference_python_thresholds_default_batched_add(Index):
+    # bindings/__tests__/recall_test.py:7-15, parameters_test.py:7-57 on seeded data
+    x = uniform(2000, 128, 51)
+    ix = Index(128)
+    ids = ix.add(x)
+    default_recall = self_recall_at_1(ix, x, ids)
+    assert default_recall > 0.85
+    iy = Index(128); iy.set_min_nn(1)
+    ids = iy.add(x)
+    assert self_recall_at_1(iy, x, ids) < default_recall
+    iz = Index(128); iz.set_max_edges(1)
+    ids = iz.add(x)
+    assert self_recall_at_1(iz, x, ids) < 0.1
+    iw = Index(128); iw.set_allow_removals(False)
+    ids = iw.add(x)
+    assert self_recall_at_1(iw, x, ids) > 0.85
+
+
+def test_metric_via_api_atol_1e5(Index):
+    # bindings/__tests__/metric_test.py:34-96
+    for metric in ("sq_euclid", "cosine", "ucosine"):
+        x = uniform(100, 128, 61)
+        if metric == "ucosine":
+            x = normalize_f32(x)
+        ix = Index(128, metric)
+        ix.add(x)
+        ids, d = ix.knn_query(x, 2)
+        a, b = x.astype(np.float64), x[ids[:, 1]].astype(np.float64)
+        want = ((a - b) ** 2).sum(1) if metric == "sq_euclid" else \
+            1 - (a * b).sum(1) / np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1)
+        assert np.allclose(d[:, 1], want, rtol=0, atol=1e-5)
+
+
+def test_edge_cases_and_errors(Index):
+    ix = Index(16)
+    ix.set_collection_size(4)
+    assert ix.add(np.empty((0, 16), np.float32)).size == 0          # count <= 0 => 0 ids (Exports.cs:81)
+    ids = ix.add(uniform(2, 16, 1))
+    assert ids.tolist() == [0, 1]
+    kid, kd = ix.knn_query(uniform(3, 16, 2), 4)                     # fewer than k results: padded (:144)
+    assert (kid[:, :2] >= 0).all() and (kid[:, 2:] == -1).all() and np.isnan(kd[:, 2:]).all()
+    ref = oracle.OracleIndex(16, collection_size=4); ref.add(uniform(2, 16, 1))
+    rid, rd = ref.knn_query(uniform(3, 16, 2), 4)
+    assert (kid == rid).all() and kd[:, :2].tobytes() == rd[:, :2].tobytes()
+    with pytest.raises(ValueError):
+        ix.add(uniform(2, 8, 1))                                      # python-side dim check (bindings.py:137)
+    import hnswindex
+    lib, F, I = hnswindex.net_amd.lib, hnswindex.net_amd.bindings._F, hnswindex.net_amd.bindings._I
+    v = uniform(1, 8, 3); out = np.zeros(1, np.int32)
+    assert lib.hnsw_add(ix._h, v.ctypes.data_as(F), 1, 8, out.ctypes.data_as(I)) == -1
+    assert "dimension mismatch" in hnswindex.net_amd.last_error()
+    with pytest.raises(RuntimeError, match="NotSupported"):
+        ix.remove([0])
+    with pytest.raises(RuntimeError, match="NotSupported"):
+        ix.range_query(uniform(1, 16, 4), 1.0)
+
+
+def test_stats_count_every_evaluation_and_profiling_times_kernels(Index):
+    x, q = uniform(3000, 64, 71), uniform(500, 64, 72)
+    ix = Index(64); ix.set_collection_size(3000)
+    ix.set_profiling(True)
+    ix.add(x)
+    ix.reset_stats()
+    ix.knn_query(q, 10)
+    s = ix.stats()
+    assert s["evals"] > 500 * 10 and s["launches"] > 0
+    assert s["timed_launches"] == s["launches"] and s["timed_evals"] == s["evals"]
+    assert s["kernel_ms"] > 0 and s["row_bytes"] == 64 * 4

@@ -1,0 +1,81 @@
+"""CPU tier: the product's host-side restatements (csrc/host_structs.h), reached through
+test hooks in the C-ABI library, against the oracle's independently written ones and the
+public .NET known answers.  No device involved."""
+import ctypes as ct
+
+import numpy as np
+import pytest
+
+import oracle
+
+F, I = ct.POINTER(ct.c_float), ct.POINTER(ct.c_int)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import hnswindex
+    L = hnswindex.net_amd.lib
+    L.hnswhost_test_random_next.argtypes = [ct.c_int, ct.c_int, I]
+    L.hnswhost_test_random_levels.argtypes = [ct.c_int, ct.c_double, ct.c_int, I]
+    L.hnswhost_test_sort.argtypes = [I, F, ct.c_int]
+    L.hnswhost_test_heap_script.argtypes = [ct.c_int, I, F, ct.c_int, I, F, I, I]
+    return L
+
+
+def test_random_known_answers_and_oracle_agreement(lib):
+    out = np.empty(3, dtype=np.int32)
+    lib.hnswhost_test_random_next(42, 3, out.ctypes.data_as(I))
+    assert out.tolist() == [1434747710, 302596119, 269548474]
+    for seed in (0, 1, 31337, 65537, -9, 2147483647, -2147483648):
+        a = np.empty(500, dtype=np.int32)
+        lib.hnswhost_test_random_next(seed, 500, a.ctypes.data_as(I))
+        assert (a == oracle.dotnet_random_next(seed, 500)).all()
+
+
+def test_levels_agree_with_oracle(lib):
+    for rate in (1 / np.log(16), float(np.float32(1 / np.log(16))), 0.5, 1 / np.log(32)):
+        a = np.empty(20000, dtype=np.int32)
+        lib.hnswhost_test_random_levels(31337, rate, a.size, a.ctypes.data_as(I))
+        assert (a == oracle.random_levels(31337, rate, a.size)).all()
+
+
+def test_sort_agrees_with_oracle_including_ties(lib):
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 2, 3, 16, 17, 33, 65, 100, 200, 400, 1000, 5000):
+        for ties in (False, True):
+            d = (rng.integers(0, 7, n) if ties else rng.permutation(n)).astype(np.float32)
+            ids = np.arange(n, dtype=np.int32)
+            a_ids, a_d = ids.copy(), d.copy()
+            lib.hnswhost_test_sort(a_ids.ctypes.data_as(I), a_d.ctypes.data_as(F), n)
+            o_ids, o_d = oracle.dotnet_sort(ids, d)
+            assert (a_ids == o_ids).all() and (a_d == o_d).all()
+
+
+def test_sort_heapsort_fallback_path(lib):
+    # a median-of-three killer-ish input: organ pipe with many equal keys drives depth down
+    n = 4096
+    d = np.concatenate([np.arange(n // 2), np.arange(n // 2)[::-1]]).astype(np.float32)
+    ids = np.arange(n, dtype=np.int32)
+    a_ids, a_d = ids.copy(), d.copy()
+    lib.hnswhost_test_sort(a_ids.ctypes.data_as(I), a_d.ctypes.data_as(F), n)
+    o_ids, o_d = oracle.dotnet_sort(ids, d)
+    assert (a_ids == o_ids).all() and (np.diff(a_d) >= 0).all()
+
+
+def test_heaps_agree_with_oracle(lib):
+    rng = np.random.default_rng(9)
+    for closer in (0, 1):
+        for _ in range(10):
+            n = 400
+            ops = np.where(rng.random(n) < 0.65, np.arange(n), -1).astype(np.int32)
+            d = rng.integers(0, 20, n).astype(np.float32)
+            out_ids = np.empty(n, dtype=np.int32)
+            out_d = np.empty(n, dtype=np.float32)
+            popped = np.empty(n, dtype=np.int32)
+            npop = ct.c_int(0)
+            c = lib.hnswhost_test_heap_script(closer, ops.ctypes.data_as(I), d.ctypes.data_as(F), n,
+                                              out_ids.ctypes.data_as(I), out_d.ctypes.data_as(F),
+                                              popped.ctypes.data_as(I), ct.byref(npop))
+            o_ids, o_d, o_pop = oracle.heap_script(closer, ops, d)
+            assert out_ids[:c].tolist() == o_ids.tolist()
+            assert popped[:npop.value].tolist() == o_pop.tolist()
