@@ -83,6 +83,10 @@ lib.hnsw_mi355x_node_max_layer.restype = ct.c_int
 lib.hnsw_mi355x_node_max_layer.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnsw_mi355x_get_out_edges.restype = ct.c_int
 lib.hnsw_mi355x_get_out_edges.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, _I, ct.c_int]
+lib.hnsw_mi355x_export_levels.restype = ct.c_int
+lib.hnsw_mi355x_export_levels.argtypes = [ct.c_void_p, _I, ct.c_int]
+lib.hnsw_mi355x_export_edges.restype = ct.c_int
+lib.hnsw_mi355x_export_edges.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int, ct.c_int]
 lib.hnsw_mi355x_graph_hash.restype = ct.c_uint64
 lib.hnsw_mi355x_graph_hash.argtypes = [ct.c_void_p]
 lib.hnsw_mi355x_get_stats.restype = ct.c_int
@@ -281,7 +285,20 @@ class Index:
         return lib.hnsw_mi355x_node_max_layer(self._h, int(i))
 
     def levels(self):
-        return np.array([self.max_layer(i) for i in range(self.count)], dtype=np.int32)
+        out = np.empty(self.count, dtype=np.int32)
+        if out.size:
+            lib.hnsw_mi355x_export_levels(self._h, out.ctypes.data_as(_I), out.size)
+        return out
+
+    def export_edges(self, layer: int, stride: int):
+        """(counts[n], edges[n, stride]) of one layer; counts == -1 where the node is absent."""
+        n = self.count
+        counts = np.empty(n, dtype=np.int32)
+        edges = np.zeros((n, stride), dtype=np.int32)
+        if n and lib.hnsw_mi355x_export_edges(self._h, int(layer), counts.ctypes.data_as(_I), edges.ctypes.data_as(_I),
+                                              int(stride), n) < 0:
+            raise RuntimeError("export_edges: stride too small")
+        return counts, edges
 
     def edges(self, i: int, layer: int):
         buf = np.empty(4096, dtype=np.int32)

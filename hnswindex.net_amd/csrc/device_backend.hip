@@ -127,6 +127,8 @@ __device__ __forceinline__ float scalar_tail(float s, const float *__restrict__ 
 __device__ double sqrt_rn(double x)
 {
     if (!(x > 0.0) || x == __builtin_inf()) return x == 0.0 ? x : sqrt(x);
+    double scale = 1.0;
+    if (x < 0x1p-900) { x *= 0x1p200; scale = 0x1p-100; } // keep the residual test clear of underflow
     double y = sqrt(x);
     for (int it = 0; it < 2; ++it) {
         double r = __builtin_fma(-y, y, x);
@@ -136,7 +138,7 @@ __device__ double sqrt_rn(double x)
         else if (r <= -(y * (y - yd))) y = yd;
         else break;
     }
-    return y;
+    return y * scale;
 }
 
 // Full metric for one (row a, vector b) pair evaluated by an 8-lane group; every lane of the

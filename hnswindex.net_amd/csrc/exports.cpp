@@ -171,6 +171,30 @@ API int hnsw_mi355x_get_out_edges(void *h, int id, int layer, int *out, int cap)
     if (out && n > 0) std::memcpy(out, l + 1, sizeof(int) * (size_t)n);
     return l[0];
 }
+API int hnsw_mi355x_export_levels(void *h, int *out, int cap)
+{
+    if (!h || !out) return -1;
+    const hnsw::Graph &g = static_cast<HnswIndex *>(h)->graph();
+    int n = std::min(g.length, cap);
+    std::memcpy(out, g.level.data(), sizeof(int) * (size_t)n);
+    return g.length;
+}
+// counts[id] = out-degree of (id, layer) or -1 if the node has no such layer;
+// edges[id*stride ...] = its ids (stride >= max degree + 1).
+API int hnsw_mi355x_export_edges(void *h, int layer, int *counts, int *edges, int stride, int cap)
+{
+    if (!h || !counts || !edges || layer < 0) return -1;
+    const hnsw::Graph &g = static_cast<HnswIndex *>(h)->graph();
+    int n = std::min(g.length, cap);
+    for (int i = 0; i < n; ++i) {
+        if (g.level[(size_t)i] < layer) { counts[i] = -1; continue; }
+        const int *l = g.list(i, layer);
+        if (l[0] > stride) return -1;
+        counts[i] = l[0];
+        std::memcpy(edges + (size_t)i * stride, l + 1, sizeof(int) * (size_t)l[0]);
+    }
+    return g.length;
+}
 API uint64_t hnsw_mi355x_graph_hash(void *h) { return h ? static_cast<HnswIndex *>(h)->graph_hash() : 0; }
 API int hnsw_mi355x_get_stats(void *h, hnswdev_stats *out)
 {

@@ -104,6 +104,11 @@ int hnsw_mi355x_node_max_layer(void *handle, int id);
 /* Copies up to cap out-edge ids of (id, layer); returns the edge count or -1. */
 int hnsw_mi355x_get_out_edges(void *handle, int id, int layer, int *out, int cap);
 uint64_t hnsw_mi355x_graph_hash(void *handle);
+/* Bulk forms: levels of nodes [0, min(count, cap)); returns count. */
+int hnsw_mi355x_export_levels(void *handle, int *out, int cap);
+/* counts[id] = out-degree of (id, layer), -1 where the node has no such layer;
+ * edges[id*stride ..] = the ids, in adjacency order.  Returns count or -1. */
+int hnsw_mi355x_export_edges(void *handle, int layer, int *counts, int *edges, int stride, int cap);
 
 /* Counters of the index's device context (see hnswdev_stats). */
 struct hnswdev_stats;

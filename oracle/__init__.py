@@ -44,6 +44,8 @@ def lib():
         L.orc_free.restype = None
         L.orc_add.argtypes = [ct.c_void_p, _F, ct.c_int, _I]
         L.orc_add_batched.argtypes = [ct.c_void_p, _F, ct.c_int, _I, ct.c_int]
+        L.orc_import_nodes.argtypes = [ct.c_void_p, _F, _I, ct.c_int, ct.c_int]
+        L.orc_import_edges.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int, ct.c_int]
         L.orc_knn_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, _I, _F, ct.c_int]
         for name in ("orc_count", "orc_entry_point", "orc_capacity"):
             getattr(L, name).argtypes = [ct.c_void_p]
@@ -187,6 +189,19 @@ class OracleIndex:
         ids = np.empty(a.shape[0], dtype=np.int32)
         lib().orc_add_batched(self._h, _pf(a), a.shape[0], _pi(ids), int(max_batch))
         return ids
+
+    def import_graph(self, items, levels, entry, layers):
+        """layers: list of (counts[n], edges[n, stride]) per layer 0.. as produced by the
+        product's Index.export_edges.  In-edge lists are not rebuilt (Add after an import
+        is only meaningful with allow_removals=False)."""
+        items, levels = _f32(items), _i32(levels)
+        n = levels.size
+        if lib().orc_import_nodes(self._h, _pf(items), _pi(levels), n, int(entry)) != n:
+            raise RuntimeError("orc_import_nodes failed")
+        for layer, (counts, edges) in enumerate(layers):
+            counts, edges = _i32(counts), _i32(edges)
+            if lib().orc_import_edges(self._h, layer, _pi(counts), _pi(edges), edges.shape[1], n) != n:
+                raise RuntimeError("orc_import_edges failed")
 
     def knn_query(self, queries, k, threads=1):
         q = _f32(queries).reshape(-1, self.dim)

@@ -992,6 +992,35 @@ ORC_API int orc_knn_query(void *h, const float *q, int n, int k, int *out_ids, f
     return 0;
 }
 
+/* --- import of a graph built elsewhere (the product's), so that the oracle can (i) check
+ * query parity on that very graph at full size and (ii) be timed on it as the CPU baseline.
+ * Levels are imposed (no RNG draw); adjacency lists are copied verbatim, order included. --- */
+ORC_API int orc_import_nodes(void *h, const float *items, const int *levels, int n, int entry)
+{
+    index_t *ix = (index_t *)h;
+    if (!ix || ix->length != 0 || n <= 0) return -1;
+    while (ix->capacity < n) grow(ix);
+    memcpy(ix->items, items, sizeof(float) * (size_t)n * (size_t)ix->dim);
+    for (int i = 0; i < n; i++) node_init(ix, &ix->nodes[i], levels[i]);
+    ix->length = n;
+    ix->count = n;
+    ix->entry = entry;
+    return n;
+}
+ORC_API int orc_import_edges(void *h, int layer, const int *counts, const int *edges, int stride, int n)
+{
+    index_t *ix = (index_t *)h;
+    if (!ix || n > ix->length) return -1;
+    for (int i = 0; i < n; i++) {
+        if (counts[i] < 0) continue;
+        if (layer > ix->nodes[i].max_layer) return -1;
+        edges_t *e = &ix->nodes[i].out[layer];
+        e->count = 0;
+        for (int j = 0; j < counts[i]; j++) edges_add(e, edges[(size_t)i * (size_t)stride + (size_t)j]);
+    }
+    return n;
+}
+
 /* --- introspection for parity checks --- */
 ORC_API int orc_count(void *h) { return ((index_t *)h)->count; }
 ORC_API int orc_entry_point(void *h) { return ((index_t *)h)->entry; }
