@@ -14,20 +14,24 @@ void set_dev_error(const std::string &msg);
 std::string get_dev_error();
 
 // One lock-step "step" worth of work for up to nslots concurrent searches.
-// All four arrays live in pinned, device-mapped host memory: the host driver writes
-// cnt/qidx/ids, the kernel reads them over PCIe and writes dist back; nothing is staged.
-//   slot s evaluates metric(row[ids[s*stride + c]], Q(s)) for c < cnt[s]
-//   Q(s) = resident query  qidx[s]            if qidx[s] >= 0
-//        = stored row      ~qidx[s]           if qidx[s] <  0   (id<->id distances)
+// The host driver fills one packed record per slot in pinned host memory,
+//     rec[s*rec_stride + 0]      = cnt   : number of candidate ids this step
+//     rec[s*rec_stride + 1]      = qidx  : >= 0 resident query index; < 0: ~row id (id<->id)
+//     rec[s*rec_stride + 2 ...]  = ids   : candidate row ids (capacity = stride)
+// launch_step() moves the used prefix to HBM with ONE async H2D copy, runs the kernel on
+// device-resident inputs, and brings the distances back with ONE async D2H copy -- all on
+// the context's stream.  (Letting the kernel read pinned host memory directly was measured
+// 2-3x slower: tools/kbench.hip, DESIGN.md "Step buffers".)
+//   slot s evaluates metric(row[ids[c]], Q(s)) for c < cnt
 struct StepBuffers {
-    int nslots = 0, stride = 0;
-    int *cnt = nullptr, *qidx = nullptr, *ids = nullptr;
-    float *dist = nullptr;
-    int *d_cnt = nullptr, *d_qidx = nullptr, *d_ids = nullptr;
+    int nslots = 0, stride = 0, rec_stride = 0;
+    int *rec = nullptr;     // pinned host, nslots * rec_stride
+    float *dist = nullptr;  // pinned host, nslots * stride
+    int *d_rec = nullptr;   // HBM mirrors
     float *d_dist = nullptr;
-    void *done = nullptr;      // hipEvent_t recorded after the kernel
-    void *t0 = nullptr, *t1 = nullptr; // hipEvent_t pair when profiling
-    bool timed = false;
+    void *done = nullptr;      // hipEvent_t recorded after the D2H copy
+    void *t0 = nullptr, *t1 = nullptr; // hipEvent_t pair around the kernel when profiling
+    bool timed = false, in_flight = false;
     uint64_t evals = 0;
 };
 

@@ -19,7 +19,9 @@
 //
 // Mapping to the wavefront: 8 lanes own the 8 partials of one candidate row, so a wave64
 // evaluates 8 candidates at a time; the collapse tree is three cross-lane adds.  One wave
-// serves one search slot (one expansion: <= 2M candidate rows against one query).
+// serves one search slot (one expansion: <= 2M candidate rows against one query).  Wider
+// per-lane loads and lane-ring variants were measured no faster (tools/kbench.hip): with the
+// step inputs resident in HBM this mapping gathers random 512-B rows at 4.2-4.9 TB/s.
 
 #include <hip/hip_runtime.h>
 
@@ -157,20 +159,21 @@ __device__ __forceinline__ float group_metric(const float *__restrict__ a, const
     return 1.0f - s / denom;               // :91
 }
 
-// One wave per search slot.
+// One wave per search slot; inputs are the packed per-slot records (device_backend.h).
 template <int METRIC>
 __global__ void __launch_bounds__(256)
 slot_distance_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn,
                      const float *__restrict__ queries, const double *__restrict__ q_sn, int dim,
-                     const int *__restrict__ slot_cnt, const int *__restrict__ slot_q, const int *__restrict__ ids,
-                     float *__restrict__ out, int stride, int nslots)
+                     const int *__restrict__ rec, float *__restrict__ out, int stride, int rec_stride, int nslots)
 {
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= nslots) return;
-    const int cnt = slot_cnt[s];
+    const int *r = rec + (size_t)s * rec_stride;
+    const int cnt = r[0];
     if (cnt <= 0) return;
-    const int qraw = slot_q[s];
+    const int qraw = r[1];
+    const int *sid = r + 2;
     const float *q;
     double sb = 0.0;
     if (qraw >= 0) {
@@ -181,7 +184,6 @@ slot_distance_kernel(const float *__restrict__ rows, const double *__restrict__ 
         if (METRIC == M_COS) sb = row_sn[~qraw];
     }
     const int grp = lane >> 3, j = lane & 7;
-    const int *sid = ids + (size_t)s * stride;
     float *so = out + (size_t)s * stride;
     for (int c0 = 0; c0 < cnt; c0 += 8) {
         const int c = c0 + grp;
@@ -189,8 +191,8 @@ slot_distance_kernel(const float *__restrict__ rows, const double *__restrict__ 
         const int id = sid[act ? c : c0]; // idle groups shadow a valid row and discard
         double sa = 0.0;
         if (METRIC == M_COS) sa = row_sn[id];
-        float r = group_metric<METRIC>(rows + (size_t)id * dim, q, dim, j, sa, sb);
-        if (act && j == 0) so[c] = r;
+        float v = group_metric<METRIC>(rows + (size_t)id * dim, q, dim, j, sa, sb);
+        if (act && j == 0) so[c] = v;
     }
 }
 
@@ -369,22 +371,20 @@ StepBuffers *Device::alloc_step(int nslots, int stride)
     StepBuffers *sb = new StepBuffers();
     sb->nslots = nslots;
     sb->stride = stride;
-    auto pin = [&](void **h, void **d, size_t bytes) -> bool {
-        if (hipHostMalloc(h, bytes, hipHostMallocMapped) != hipSuccess) return false;
-        if (hipHostGetDevicePointer(d, *h, 0) != hipSuccess) return false;
-        memset(*h, 0, bytes);
-        return true;
-    };
-    bool ok = pin((void **)&sb->cnt, (void **)&sb->d_cnt, sizeof(int) * (size_t)nslots) &&
-              pin((void **)&sb->qidx, (void **)&sb->d_qidx, sizeof(int) * (size_t)nslots) &&
-              pin((void **)&sb->ids, (void **)&sb->d_ids, sizeof(int) * (size_t)nslots * stride) &&
-              pin((void **)&sb->dist, (void **)&sb->d_dist, sizeof(float) * (size_t)nslots * stride);
+    sb->rec_stride = stride + 2;
+    const size_t rec_bytes = sizeof(int) * (size_t)nslots * sb->rec_stride;
+    const size_t dist_bytes = sizeof(float) * (size_t)nslots * stride;
+    bool ok = hipHostMalloc((void **)&sb->rec, rec_bytes, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&sb->dist, dist_bytes, hipHostMallocDefault) == hipSuccess &&
+              hipMalloc((void **)&sb->d_rec, rec_bytes) == hipSuccess &&
+              hipMalloc((void **)&sb->d_dist, dist_bytes) == hipSuccess;
+    if (ok) { memset(sb->rec, 0, rec_bytes); memset(sb->dist, 0, dist_bytes); }
     hipEvent_t ev = nullptr, t0 = nullptr, t1 = nullptr;
     ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess &&
          hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess;
     sb->done = ev; sb->t0 = t0; sb->t1 = t1;
     if (!ok) {
-        set_dev_error("alloc_step: pinned allocation failed");
+        set_dev_error("alloc_step: allocation failed");
         free_step(sb);
         return nullptr;
     }
@@ -395,10 +395,10 @@ void Device::free_step(StepBuffers *sb)
 {
     if (!sb) return;
     (void)hipSetDevice(device_);
-    if (sb->cnt) (void)hipHostFree(sb->cnt);
-    if (sb->qidx) (void)hipHostFree(sb->qidx);
-    if (sb->ids) (void)hipHostFree(sb->ids);
+    if (sb->rec) (void)hipHostFree(sb->rec);
     if (sb->dist) (void)hipHostFree(sb->dist);
+    if (sb->d_rec) (void)hipFree(sb->d_rec);
+    if (sb->d_dist) (void)hipFree(sb->d_dist);
     if (sb->done) (void)hipEventDestroy((hipEvent_t)sb->done);
     if (sb->t0) (void)hipEventDestroy((hipEvent_t)sb->t0);
     if (sb->t1) (void)hipEventDestroy((hipEvent_t)sb->t1);
@@ -407,23 +407,27 @@ void Device::free_step(StepBuffers *sb)
 
 bool Device::launch_step(StepBuffers *sb, int nslots_used, uint64_t evals)
 {
-    if (nslots_used <= 0) { sb->evals = 0; sb->timed = false; return true; }
+    sb->in_flight = false;
+    if (nslots_used <= 0 || evals == 0) { sb->evals = 0; sb->timed = false; return true; }
     if (nslots_used > sb->nslots) { set_dev_error("launch_step: too many slots"); return false; }
     hipStream_t st = S(stream_);
     sb->timed = profiling_;
     sb->evals = evals;
+    HIP_OK(hipMemcpyAsync(sb->d_rec, sb->rec, sizeof(int) * (size_t)nslots_used * sb->rec_stride, hipMemcpyHostToDevice, st));
     if (sb->timed) HIP_OK(hipEventRecord((hipEvent_t)sb->t0, st));
     dim3 grid((nslots_used + 3) / 4), block(256);
 #define LAUNCH(M)                                                                                          \
     hipLaunchKernelGGL(slot_distance_kernel<M>, grid, block, 0, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
-                       sb->d_cnt, sb->d_qidx, sb->d_ids, sb->d_dist, sb->stride, nslots_used)
+                       sb->d_rec, sb->d_dist, sb->stride, sb->rec_stride, nslots_used)
     if (metric_ == M_SQ) LAUNCH(M_SQ);
     else if (metric_ == M_COS) LAUNCH(M_COS);
     else LAUNCH(M_UCOS);
 #undef LAUNCH
     HIP_OK(hipGetLastError());
     if (sb->timed) HIP_OK(hipEventRecord((hipEvent_t)sb->t1, st));
+    HIP_OK(hipMemcpyAsync(sb->dist, sb->d_dist, sizeof(float) * (size_t)nslots_used * sb->stride, hipMemcpyDeviceToHost, st));
     HIP_OK(hipEventRecord((hipEvent_t)sb->done, st));
+    sb->in_flight = true;
     stats_.launches++;
     stats_.evals += evals;
     return true;
@@ -431,8 +435,9 @@ bool Device::launch_step(StepBuffers *sb, int nslots_used, uint64_t evals)
 
 bool Device::wait_step(StepBuffers *sb)
 {
-    if (sb->evals == 0 && !sb->timed) return true;
+    if (!sb->in_flight) return true;
     HIP_OK(hipEventSynchronize((hipEvent_t)sb->done));
+    sb->in_flight = false;
     if (sb->timed) {
         float ms = 0.f;
         HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)sb->t0, (hipEvent_t)sb->t1));
@@ -487,9 +492,10 @@ bool Device::dist_query_batch(const float *queries, int nq, const int *offsets, 
             if (m <= 0) { ++qi; pos = 0; continue; }
             int take = std::min(m, stride);
             int g = offsets[qi] + pos;
-            sb->cnt[used] = take;
-            sb->qidx[used] = qi;
-            memcpy(sb->ids + (size_t)used * stride, ids + g, sizeof(int) * (size_t)take);
+            int *r = sb->rec + (size_t)used * sb->rec_stride;
+            r[0] = take;
+            r[1] = qi;
+            memcpy(r + 2, ids + g, sizeof(int) * (size_t)take);
             where.emplace_back(g, take);
             ev += (uint64_t)take;
             ++used;

@@ -25,7 +25,7 @@ struct Params {
     // backend
     int device = -1;         // -1: HNSW_MI355X_DEVICE or 0
     int insert_batch = 4096; // 1 = strictly sequential inserts
-    int search_slots = 4096;
+    int search_slots = 16384;
     int host_threads = 0;    // 0: min(hardware threads, 16)
 };
 

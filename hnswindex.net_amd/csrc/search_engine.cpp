@@ -62,7 +62,8 @@ void LockStepEngine::half_step(int t, int g)
     int active = 0, maxslot = 0;
     for (int s = lo; s < hi; ++s) {
         Slot &sl = slots_[g][(size_t)s];
-        SlotIO io{sb->ids + (size_t)s * stride_, &sb->cnt[s], &sb->qidx[s], sb->dist + (size_t)s * stride_, stride_};
+        int *rec = sb->rec + (size_t)s * sb->rec_stride;
+        SlotIO io{rec + 2, rec, rec + 1, sb->dist + (size_t)s * stride_, stride_};
         if (sl.job && sl.awaiting) {
             sl.job->consume(io, sl.scratch);
             sl.awaiting = false;

@@ -92,7 +92,7 @@ int hnsw_mi355x_set_device(int device);
 /* Pending: cap on the snapshot batch of hnsw_add (1 = strictly sequential inserts;
  * default 4096).  See DESIGN.md "Add". */
 int hnsw_mi355x_set_insert_batch(int max_batch);
-/* Pending: number of concurrent search slots of the lock-step driver (default 4096) and
+/* Pending: number of concurrent search slots of the lock-step driver (default 16384) and
  * host worker threads (default: min(hardware threads, 16)). */
 int hnsw_mi355x_set_search_slots(int slots);
 int hnsw_mi355x_set_host_threads(int threads);
