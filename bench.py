@@ -47,6 +47,8 @@ def parse():
     p.add_argument("--cpu-queries", type=int, default=4000, help="bounded cpu_baseline sample (all-cores leg)")
     p.add_argument("--cpu-adds", type=int, default=3000, help="bounded cpu_baseline sample of sequential inserts")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--traversal", choices=["device", "host"], default="device",
+                   help="device: graph-resident search kernel (default); host: lock-step traversal on host threads")
     return p.parse_args()
 
 
@@ -104,6 +106,7 @@ def main():
     ix.set_allow_removals(False)           # build-rate runs drop in-edge upkeep
     ix.set_device(local_rank)
     ix.set_insert_batch(a.insert_batch)
+    ix.set_device_traversal(a.traversal == "device")
     if a.slots:
         ix.set_search_slots(a.slots)
     if a.threads:
@@ -152,14 +155,17 @@ def main():
     del x_t
     recall = float(np.mean([len(set(gt[i]) & set(res_ids[i])) / a.k for i in range(nrec)]))
 
-    evals_per_launch = st["timed_evals"] / max(1, st["timed_launches"])
-    kernel_s = st["kernel_ms"] / 1e3
-    achieved = st["timed_evals"] * st["row_bytes"] / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    if a.traversal == "device":
+        kname, t_evals, t_launches, k_ms = "graph_search_kernel", st["search_timed_evals"], st["search_timed_launches"], st["search_kernel_ms"]
+    else:
+        kname, t_evals, t_launches, k_ms = "slot_distance_kernel", st["timed_evals"], st["timed_launches"], st["kernel_ms"]
+    kernel_s = k_ms / 1e3
+    achieved = t_evals * st["row_bytes"] / kernel_s / 1e9 if kernel_s > 0 else 0.0
     roofline = {
-        "bound": "hbm", "kernel": "slot_distance_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-        "bytes_per_eval": st["row_bytes"], "evals_per_launch": round(evals_per_launch, 1),
-        "launches": st["timed_launches"], "avg_launch_us": round(1e3 * st["kernel_ms"] / max(1, st["timed_launches"]), 2),
+        "bytes_per_eval": st["row_bytes"], "evals_per_launch": round(t_evals / max(1, t_launches), 1),
+        "launches": t_launches, "avg_launch_us": round(1e3 * k_ms / max(1, t_launches), 2),
         "kernel_time_share_of_step": round(kernel_s / dt, 4),
     }
 
@@ -213,7 +219,8 @@ def main():
         "recall_at_10": round(recall, 4),
         "add_per_sec": round(a.n / build_s, 1), "build_seconds": round(build_s, 2),
         "build_evals": build_stats["evals"], "build_launches": build_stats["launches"],
-        "evals_per_query": round(st["evals"] / (a.nq * a.steps), 1),
+        "evals_per_query": round((st["search_evals"] + st["evals"]) / (a.nq * a.steps), 1),
+        "traversal": a.traversal, "search_overflows": st["search_overflows"],
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

@@ -40,7 +40,9 @@ _I = ct.POINTER(ct.c_int)
 class Stats(ct.Structure):
     """hnswdev_stats (include/hnsw_mi355x.h)."""
     _fields_ = [("launches", ct.c_uint64), ("evals", ct.c_uint64), ("timed_launches", ct.c_uint64),
-                ("timed_evals", ct.c_uint64), ("kernel_ms", ct.c_double), ("row_bytes", ct.c_uint64)]
+                ("timed_evals", ct.c_uint64), ("kernel_ms", ct.c_double), ("row_bytes", ct.c_uint64),
+                ("search_launches", ct.c_uint64), ("search_evals", ct.c_uint64), ("search_timed_launches", ct.c_uint64),
+                ("search_timed_evals", ct.c_uint64), ("search_kernel_ms", ct.c_double), ("search_overflows", ct.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -65,7 +67,7 @@ lib.hnsw_free_results.argtypes = [ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_
 for _name in ("hnsw_set_collection_size", "hnsw_set_max_edges", "hnsw_set_max_candidates",
               "hnsw_set_remove_max_candidates", "hnsw_set_random_seed", "hnsw_set_min_nn",
               "hnsw_mi355x_set_device", "hnsw_mi355x_set_insert_batch", "hnsw_mi355x_set_search_slots",
-              "hnsw_mi355x_set_host_threads"):
+              "hnsw_mi355x_set_host_threads", "hnsw_mi355x_set_device_traversal"):
     getattr(lib, _name).restype = ct.c_int
     getattr(lib, _name).argtypes = [ct.c_int]
 lib.hnsw_set_distribution_rate.restype = ct.c_int
@@ -213,6 +215,10 @@ class Index:
 
     def set_host_threads(self, threads: int):
         self._check(lib.hnsw_mi355x_set_host_threads(threads))
+
+    def set_device_traversal(self, enabled: bool):
+        """True (default): knn_query traverses on the device; False: host lock-step traversal."""
+        self._check(lib.hnsw_mi355x_set_device_traversal(int(enabled)))
 
     # ---- data path ----
     def add(self, vecs: npt.ArrayLike) -> npt.NDArray[np.int32]:

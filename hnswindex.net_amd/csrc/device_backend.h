@@ -35,6 +35,19 @@ struct StepBuffers {
     uint64_t evals = 0;
 };
 
+// One traversal for the graph-resident search kernel: greedy descent from `entry` at
+// `entry_layer` down to (exclusive) `search_layer`, then the beam search at `search_layer`.
+struct SearchJob {
+    int qref;         // >= 0 resident query index; < 0: ~row id
+    int entry;        // entry node id
+    int entry_layer;  // layer the descent starts at (== search_layer: no descent)
+    int search_layer; // layer of the beam search
+};
+struct SearchHit {
+    int id;
+    float dist;
+};
+
 class Device {
 public:
     static Device *create(int device, int dim, int metric, long long capacity);
@@ -59,6 +72,16 @@ public:
     // Makes this context's HIP device current on the calling thread.
     bool bind_thread() { return bind(); }
 
+    // --- graph-resident traversal (DESIGN.md "Graph-resident search") ---
+    // Mirrors the host adjacency in HBM (layer 0: n x stride0 ints [count, e...]; upper layers:
+    // per-node offset into a pool of strideU-int blocks).  Full replace.
+    bool set_graph(const int *adj0, long long n, int stride0, const int *level, const int64_t *upper, const int *pool,
+                   long long pool_len, int strideU);
+    // Runs njobs traversals with beam width k.  out_hits: njobs x k (heap order, as
+    // BinaryHeap.ToArray()), out_cnt: hits per job, out_flag: 1 where the candidate heap
+    // outgrew its LDS capacity (caller re-runs that job on the lock-step path).  Synchronous.
+    bool search_batch(const SearchJob *jobs, int njobs, int k, SearchHit *out_hits, int *out_cnt, int *out_flag);
+
     // C-ABI conveniences (synchronous; validate ids on the host before launching).
     bool dist_query_batch(const float *queries, int nq, const int *offsets, const int *ids, float *out);
     bool dist_pair_batch(const int *a, const int *b, int n, float *out);
@@ -78,6 +101,20 @@ private:
     float *d_queries_ = nullptr;
     double *d_q_sn_ = nullptr;
     long long q_capacity_ = 0, n_queries_ = 0;
+    // graph mirror
+    int *g_adj0_ = nullptr, *g_level_ = nullptr, *g_pool_ = nullptr;
+    int64_t *g_upper_ = nullptr;
+    long long g_n_ = 0, g_cap_n_ = 0, g_pool_cap_ = 0;
+    int g_stride0_ = 0, g_strideU_ = 0;
+    // search scratch
+    unsigned *s_visited_ = nullptr;
+    size_t s_visited_bytes_ = 0;
+    SearchJob *s_jobs_ = nullptr;
+    SearchHit *s_hits_ = nullptr;
+    int *s_cnt_ = nullptr, *s_flag_ = nullptr;
+    unsigned long long *s_evals_ = nullptr;
+    size_t s_jobs_cap_ = 0, s_hits_cap_ = 0;
+    void *ev0_ = nullptr, *ev1_ = nullptr;
     void *stream_ = nullptr;
     bool profiling_ = false;
     hnswdev_stats stats_{};

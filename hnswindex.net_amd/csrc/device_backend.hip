@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -196,6 +197,273 @@ slot_distance_kernel(const float *__restrict__ rows, const double *__restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Graph-resident search: the whole traversal of one query on one wavefront.
+//
+// SearchLayer / SearchLayerQuery (GraphNavigator.cs:123-256) and FindEntryAtLayer (:51-82)
+// restated for a wave64: the two BinaryHeaps (BinaryHeap.cs:30-107) live in LDS and are
+// manipulated by wave-uniform scalar code with the reference's exact sift rules (so the heap
+// ARRAY, not just the heap SET, matches -- tie order decides ids); the visited set
+// (VisitedListPool.cs:10-67) is a private bitset in HBM; the out-edge lists come from the HBM
+// mirror of the host graph; candidate rows are measured 8 lanes per row exactly as in
+// slot_distance_kernel.  Unvisited neighbours keep their adjacency order (ballot + prefix
+// count), so pushes happen in the reference's order.
+// ------------------------------------------------------------------------------------
+struct ND {
+    int id;
+    float dist;
+};
+
+__device__ __forceinline__ int dev_float_compare_to(float x, float y)
+{
+    if (x < y) return -1;
+    if (x > y) return 1;
+    if (x == y) return 0;
+    if (x != x) return (y != y) ? 0 : -1;
+    return 1;
+}
+// DistanceComparer (farther first) / ReverseDistanceComparer (closer first), DistanceComparer.cs:9-25
+template <bool CLOSER>
+__device__ __forceinline__ int nd_cmp(ND x, ND y)
+{
+    if (CLOSER) {
+        if (x.dist > y.dist) return -1;
+        if (x.dist < y.dist) return 1;
+        return dev_float_compare_to(y.dist, x.dist);
+    }
+    if (x.dist < y.dist) return -1;
+    if (x.dist > y.dist) return 1;
+    return dev_float_compare_to(x.dist, y.dist);
+}
+template <bool CLOSER>
+__device__ __forceinline__ void heap_push(ND *b, int &count, ND item) // BinaryHeap.cs:30-34, :89-107
+{
+    int i = count++;
+    while (i > 0) {
+        int p = (i - 1) >> 1;
+        ND parent = b[p];
+        if (nd_cmp<CLOSER>(item, parent) <= 0) break;
+        b[i] = parent;
+        i = p;
+    }
+    b[i] = item;
+}
+template <bool CLOSER>
+__device__ __forceinline__ ND heap_pop(ND *b, int &count) // BinaryHeap.cs:53-87
+{
+    ND result = b[0];
+    int n = --count;
+    ND item = b[n];
+    if (n != 0) {
+        int i = 0, half = n >> 1;
+        while (i < half) {
+            int left = (i << 1) + 1, right = left + 1;
+            ND lv = b[left];
+            int mc = left;
+            ND mv = lv;
+            if (right < n) {
+                ND rv = b[right];
+                if (nd_cmp<CLOSER>(lv, rv) < 0) { mc = right; mv = rv; }
+            }
+            if (nd_cmp<CLOSER>(mv, item) <= 0) break;
+            b[i] = mv;
+            i = mc;
+        }
+        b[i] = item;
+    }
+    return result;
+}
+
+// Distances of nbuf[0..m) to the query staged in LDS (qs), written to dbuf[0..m).
+// 8 lanes per candidate, NP candidates per lane group in flight (row loads of all NP passes
+// are independent, so one HBM round trip serves up to 8*NP rows).
+template <int METRIC, int NP>
+__device__ __forceinline__ void measure_pass(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                                             const float *qs, double sb, const int *nbuf, float *dbuf, int p0, int m, int lane)
+{
+    const int grp = lane >> 3, j = lane & 7;
+    const float *a[NP];
+    int cidx[NP];
+    float acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int c = p0 + grp + 8 * p;
+        cidx[p] = c;
+        int id = nbuf[c < m ? c : p0]; // idle groups shadow a valid row
+        a[p] = rows + (size_t)id * dim;
+        acc[p] = 0.0f;
+    }
+    const int nblk = dim >> 3;
+#pragma unroll 4
+    for (int k = 0; k < nblk; ++k) {
+        float y = qs[8 * k + j];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float x = a[p][8 * k + j];
+            if (METRIC == M_SQ) {
+                float d = x - y;
+                acc[p] = __builtin_fmaf(d, d, acc[p]);
+            } else {
+                float pr = x * y;
+                acc[p] = acc[p] + pr;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float s = (METRIC == M_SQ) ? collapse_l2(acc[p]) : collapse_cos(acc[p]);
+        if (dim & 7) s = scalar_tail<METRIC>(s, a[p], qs, dim);
+        float r;
+        if (METRIC == M_SQ) r = s;
+        else if (METRIC == M_UCOS) r = 1.0f - s;
+        else {
+            int id = nbuf[cidx[p] < m ? cidx[p] : p0];
+            float denom = (float)(row_sn[id] * sb);
+            r = (denom < 1e-30f) ? 1.0f : 1.0f - s / denom;
+        }
+        if (j == 0 && cidx[p] < m) dbuf[cidx[p]] = r;
+    }
+}
+
+template <int METRIC>
+__device__ __forceinline__ void measure_all(const float *rows, const double *row_sn, int dim, const float *qs, double sb,
+                                            const int *nbuf, float *dbuf, int m, int lane)
+{
+    for (int p0 = 0; p0 < m; p0 += 32) {
+        int left = m - p0;
+        if (left > 24) measure_pass<METRIC, 4>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
+        else if (left > 16) measure_pass<METRIC, 3>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
+        else if (left > 8) measure_pass<METRIC, 2>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
+        else measure_pass<METRIC, 1>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
+    }
+}
+
+constexpr int kNbufCap = 136; // >= 2*M + 2 for M <= 64 ... (checked on the host)
+
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
+                    const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
+                    const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
+                    const SearchJob *__restrict__ jobs, int k, int cand_cap, unsigned *__restrict__ visited,
+                    long long vis_words, ND *__restrict__ out_hits, int *__restrict__ out_cnt, int *__restrict__ out_flag,
+                    unsigned long long *__restrict__ eval_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ND *top = reinterpret_cast<ND *>(smem);                 // k + 1
+    ND *cand = top + (k + 1);                               // cand_cap
+    float *qs = reinterpret_cast<float *>(cand + cand_cap); // dim (+pad)
+    int *nbuf = reinterpret_cast<int *>(qs + ((dim + 3) & ~3));
+    float *dbuf = reinterpret_cast<float *>(nbuf + kNbufCap);
+
+    const int lane = threadIdx.x;
+    const int job = blockIdx.x;
+    const SearchJob jb = jobs[job];
+    unsigned *vis = visited + (size_t)job * (size_t)vis_words;
+
+    const float *q;
+    double sb = 0.0;
+    if (jb.qref >= 0) {
+        q = queries + (size_t)jb.qref * dim;
+        if (METRIC == M_COS) sb = q_sn[jb.qref];
+    } else {
+        q = rows + (size_t)(~jb.qref) * dim;
+        if (METRIC == M_COS) sb = row_sn[~jb.qref];
+    }
+    for (int i = lane; i < dim; i += 64) qs[i] = q[i];
+    __syncthreads();
+
+    unsigned long long evals = 0;
+
+    // ---- FindEntryPoint / FindEntryAtLayer (GraphNavigator.cs:27-82) ----
+    int best = jb.entry;
+    if (lane == 0) nbuf[0] = best;
+    __syncthreads();
+    measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, 1, lane);
+    __syncthreads();
+    float cur = dbuf[0]; // :57
+    evals += 1;
+    for (int layer = jb.entry_layer; layer > jb.search_layer; --layer) {
+        bool changed = true;
+        while (changed) { // :60
+            changed = false;
+            const int *l = pool + upper[best] + (size_t)(layer - 1) * strideU;
+            const int n = l[0];
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) nbuf[i] = l[1 + i]; // :65 span taken once per pass
+            __syncthreads();
+            if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane);
+            __syncthreads();
+            evals += (unsigned long long)n;
+            for (int i = 0; i < n; ++i) { // :67-78
+                float d = dbuf[i];
+                if (d < cur) { cur = d; best = nbuf[i]; changed = true; }
+            }
+        }
+    }
+
+    // ---- SearchLayer (GraphNavigator.cs:123-189) ----
+    const int layer = jb.search_layer;
+    int top_n = 0, cand_n = 0;
+    bool overflow = false;
+    {
+        ND e{best, cur};
+        heap_push<false>(top, top_n, e); // :134
+        heap_push<true>(cand, cand_n, e); // :138
+        if (lane == 0) atomicOr(&vis[best >> 5], 1u << (best & 31)); // :140
+    }
+    float farthest = cur; // :135
+    while (cand_n > 0) {
+        ND c = heap_pop<true>(cand, cand_n);           // :146
+        if (c.dist > farthest && top_n >= k) break;    // :147-150
+        const int *l = (layer == 0) ? adj0 + (size_t)c.id * stride0 : pool + upper[c.id] + (size_t)(layer - 1) * strideU;
+        const int n = l[0];
+        int m = 0;
+        __syncthreads();
+        for (int base = 0; base < n; base += 64) { // :158-161 keep only unvisited, in list order
+            const int i = base + lane;
+            bool fresh = false;
+            int nb = 0;
+            if (i < n) {
+                nb = l[1 + i];
+                const unsigned bit = 1u << (nb & 31);
+                const unsigned old = atomicOr(&vis[nb >> 5], bit); // :181 (lists hold no duplicates)
+                fresh = (old & bit) == 0;
+            }
+            const unsigned long long mask = __ballot(fresh);
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (fresh) nbuf[m + pos] = nb;
+            m += __popcll(mask);
+        }
+        __syncthreads();
+        if (m == 0) continue;
+        measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
+        __syncthreads();
+        evals += (unsigned long long)m;
+        for (int i = 0; i < m; ++i) {
+            const float d = dbuf[i];
+            if (top_n < k || d < farthest) { // :165
+                ND sel{nbuf[i], d};
+                if (cand_n >= cand_cap) { overflow = true; break; }
+                heap_push<true>(cand, cand_n, sel);               // :168
+                heap_push<false>(top, top_n, sel);                // :171
+                if (top_n > k) (void)heap_pop<false>(top, top_n); // :173-174
+                farthest = top[0].dist;                           // :176-177
+            }
+        }
+        if (overflow) break;
+    }
+    __syncthreads();
+    // ToArray(): the heap's buffer prefix, heap order (BinaryHeap.cs:41-44)
+    for (int i = lane; i < top_n; i += 64) out_hits[(size_t)job * k + i] = top[i];
+    if (lane == 0) {
+        out_cnt[job] = overflow ? 0 : top_n;
+        out_flag[job] = overflow ? 1 : 0;
+        atomicAdd(eval_counter, evals);
+    }
+}
+
 // Flat id<->id pairs: 8 lanes per pair (hnswdev_dist_pair_batch).
 template <int METRIC>
 __global__ void __launch_bounds__(256)
@@ -284,6 +552,11 @@ Device::~Device()
     if (d_row_sn_) (void)hipFree(d_row_sn_);
     if (d_queries_) (void)hipFree(d_queries_);
     if (d_q_sn_) (void)hipFree(d_q_sn_);
+    for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_})
+        if (p) (void)hipFree(p);
+    if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
+    if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
 }
 
 bool Device::reserve(long long capacity)
@@ -463,6 +736,127 @@ void Device::reset_stats()
     uint64_t rb = stats_.row_bytes;
     stats_ = hnswdev_stats{};
     stats_.row_bytes = rb;
+}
+
+
+// ---- graph mirror + graph-resident search -------------------------------------------------
+bool Device::set_graph(const int *adj0, long long n, int stride0, const int *level, const int64_t *upper, const int *pool,
+                       long long pool_len, int strideU)
+{
+    if (n < 0 || (n > 0 && (!adj0 || !level || !upper))) { set_dev_error("set_graph: bad argument"); return false; }
+    if (stride0 - 1 > kNbufCap || strideU - 1 > kNbufCap) { set_dev_error("set_graph: MaxEdges too large for the search kernel"); return false; }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    if (n > g_cap_n_ || stride0 != g_stride0_) {
+        if (g_adj0_) HIP_OK(hipFree(g_adj0_));
+        if (g_level_) HIP_OK(hipFree(g_level_));
+        if (g_upper_) HIP_OK(hipFree(g_upper_));
+        g_adj0_ = nullptr; g_level_ = nullptr; g_upper_ = nullptr;
+        long long cap = std::max<long long>(n, std::max<long long>(capacity_, 1024));
+        HIP_OK(hipMalloc(&g_adj0_, sizeof(int) * (size_t)cap * stride0));
+        HIP_OK(hipMalloc(&g_level_, sizeof(int) * (size_t)cap));
+        HIP_OK(hipMalloc(&g_upper_, sizeof(int64_t) * (size_t)cap));
+        g_cap_n_ = cap;
+    }
+    if (pool_len > g_pool_cap_) {
+        if (g_pool_) HIP_OK(hipFree(g_pool_));
+        g_pool_ = nullptr;
+        long long cap = std::max<long long>(pool_len * 2, 4096);
+        HIP_OK(hipMalloc(&g_pool_, sizeof(int) * (size_t)cap));
+        g_pool_cap_ = cap;
+    }
+    g_n_ = n; g_stride0_ = stride0; g_strideU_ = strideU;
+    if (n > 0) {
+        HIP_OK(hipMemcpyAsync(g_adj0_, adj0, sizeof(int) * (size_t)n * stride0, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(g_level_, level, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(g_upper_, upper, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    }
+    if (pool_len > 0) HIP_OK(hipMemcpyAsync(g_pool_, pool, sizeof(int) * (size_t)pool_len, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st)); // host arrays are borrowed only for this call
+    return true;
+}
+
+bool Device::search_batch(const SearchJob *jobs, int njobs, int k, SearchHit *out_hits, int *out_cnt, int *out_flag)
+{
+    if (njobs <= 0) return true;
+    if (!jobs || !out_hits || !out_cnt || !out_flag || k < 1) { set_dev_error("search_batch: bad argument"); return false; }
+    if (g_n_ <= 0) { set_dev_error("search_batch: no graph uploaded"); return false; }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    // LDS: top (k+1) + cand heap + query + neighbour/distance scratch
+    int cand_cap = std::min(std::max(8 * k, 1024), 6144);
+    if (const char *e = std::getenv("HNSW_MI355X_CAND_CAP")) cand_cap = std::max(1, std::atoi(e)); // tests: force the overflow hand-back
+    auto lds_bytes = [&](int cc) { return sizeof(ND) * (size_t)(k + 1 + cc) + sizeof(float) * (size_t)((dim_ + 3) & ~3) + 8u * kNbufCap; };
+    while (cand_cap > 256 && lds_bytes(cand_cap) > 64 * 1024) cand_cap /= 2;
+    if (lds_bytes(cand_cap) > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
+    const long long vis_words = (g_n_ + 31) / 32;
+    const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
+    // jobs per launch bounded by an 8 GiB visited arena
+    long long chunk = std::min<long long>(njobs, std::max<long long>(256, (8LL << 30) / (long long)std::max<size_t>(vis_bytes_per_job, 1)));
+    if (vis_bytes_per_job * (size_t)chunk > s_visited_bytes_) {
+        if (s_visited_) HIP_OK(hipFree(s_visited_));
+        s_visited_ = nullptr;
+        s_visited_bytes_ = vis_bytes_per_job * (size_t)chunk;
+        HIP_OK(hipMalloc(&s_visited_, s_visited_bytes_));
+    }
+    if ((size_t)chunk > s_jobs_cap_) {
+        if (s_jobs_) HIP_OK(hipFree(s_jobs_));
+        if (s_cnt_) HIP_OK(hipFree(s_cnt_));
+        if (s_flag_) HIP_OK(hipFree(s_flag_));
+        s_jobs_cap_ = (size_t)chunk;
+        HIP_OK(hipMalloc(&s_jobs_, sizeof(SearchJob) * s_jobs_cap_));
+        HIP_OK(hipMalloc(&s_cnt_, sizeof(int) * s_jobs_cap_));
+        HIP_OK(hipMalloc(&s_flag_, sizeof(int) * s_jobs_cap_));
+    }
+    if ((size_t)chunk * k > s_hits_cap_) {
+        if (s_hits_) HIP_OK(hipFree(s_hits_));
+        s_hits_cap_ = (size_t)chunk * k;
+        HIP_OK(hipMalloc(&s_hits_, sizeof(SearchHit) * s_hits_cap_));
+    }
+    if (!s_evals_) HIP_OK(hipMalloc(&s_evals_, sizeof(unsigned long long)));
+    if (!ev0_) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); ev0_ = a; ev1_ = b; }
+    for (int i = 0; i < njobs; ++i) {
+        const SearchJob &j = jobs[i];
+        bool ok = j.entry >= 0 && j.entry < g_n_ && j.search_layer >= 0 && j.entry_layer >= j.search_layer &&
+                  (j.qref >= 0 ? j.qref < n_queries_ : (~j.qref) < n_rows_hw_);
+        if (!ok) { set_dev_error("search_batch: job outside the uploaded graph / rows / queries"); return false; }
+    }
+    for (long long off = 0; off < njobs; off += chunk) {
+        const int nj = (int)std::min<long long>(chunk, njobs - off);
+        HIP_OK(hipMemcpyAsync(s_jobs_, jobs + off, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(s_visited_, 0, vis_bytes_per_job * (size_t)nj, st));
+        HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
+        const bool timed = profiling_;
+        if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
+        const size_t lds = lds_bytes(cand_cap);
+#define LAUNCH(M)                                                                                                     \
+    hipLaunchKernelGGL(graph_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
+                       g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, s_visited_, vis_words,   \
+                       reinterpret_cast<ND *>(s_hits_), s_cnt_, s_flag_, s_evals_)
+        if (metric_ == M_SQ) LAUNCH(M_SQ);
+        else if (metric_ == M_COS) LAUNCH(M_COS);
+        else LAUNCH(M_UCOS);
+#undef LAUNCH
+        HIP_OK(hipGetLastError());
+        if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
+        unsigned long long ev = 0;
+        HIP_OK(hipMemcpyAsync(out_hits + (size_t)off * k, s_hits_, sizeof(SearchHit) * (size_t)nj * k, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(out_cnt + off, s_cnt_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(out_flag + off, s_flag_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(&ev, s_evals_, sizeof(ev), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        stats_.search_launches++;
+        stats_.search_evals += ev;
+        if (timed) {
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
+            stats_.search_kernel_ms += ms;
+            stats_.search_timed_launches++;
+            stats_.search_timed_evals += ev;
+        }
+        for (int i = 0; i < nj; ++i) stats_.search_overflows += (uint64_t)(out_flag[off + i] != 0);
+    }
+    return true;
 }
 
 // ---- synchronous conveniences behind the C ABI ---------------------------------------

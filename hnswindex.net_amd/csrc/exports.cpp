@@ -144,6 +144,7 @@ SETTER(hnsw_mi355x_set_device, device, int)
 SETTER(hnsw_mi355x_set_insert_batch, insert_batch, int)
 SETTER(hnsw_mi355x_set_search_slots, search_slots, int)
 SETTER(hnsw_mi355x_set_host_threads, host_threads, int)
+SETTER(hnsw_mi355x_set_device_traversal, device_traversal, int)
 
 API int hnsw_set_distribution_rate(float dist_rate) // :247 -- crosses the ABI as float, widened to double
 {

@@ -496,6 +496,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
         ++n_new;
     }
     if (!ensure_capacity(graph_.length, err)) return -1;
+    graph_dirty_ = true;
     // rows -> HBM (id == row index)
     if (n_new == count) {
         if (!dev_->upload_rows(first_new, count, vectors)) { err = get_dev_error(); return -1; }
@@ -525,6 +526,90 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
     return count;
 }
 
+namespace {
+template <class F>
+void parallel_for(int n, int threads, F fn)
+{
+    threads = std::max(1, std::min(threads, n / 64));
+    if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::vector<std::thread> th;
+    std::atomic<int> next{0};
+    for (int t = 0; t < threads; ++t)
+        th.emplace_back([&] {
+            for (;;) {
+                int i0 = next.fetch_add(64, std::memory_order_relaxed);
+                if (i0 >= n) break;
+                for (int i = i0, e = std::min(n, i0 + 64); i < e; ++i) fn(i);
+            }
+        });
+    for (auto &t : th) t.join();
+}
+} // namespace
+
+bool HnswIndex::sync_graph(std::string &err)
+{
+    if (!graph_dirty_) return true;
+    if (!dev_->set_graph(graph_.adj0.data(), graph_.length, graph_.stride0, graph_.level.data(), graph_.upper.data(),
+                         graph_.pool.data(), (long long)graph_.pool.size(), graph_.strideU)) {
+        err = get_dev_error();
+        return false;
+    }
+    graph_dirty_ = false;
+    return true;
+}
+
+// Host lock-step traversal for the queries listed in `which` (nullptr: all `count` queries).
+int HnswIndex::knn_query_lockstep(const int *which, int count, int k, int *out_ids, float *out_dists, std::string &err)
+{
+    QuerySource src;
+    src.jobs.resize((size_t)count);
+    const int ef = std::max(p_.min_nn, k); // HNSWIndex.cs:115
+    for (int i = 0; i < count; ++i) {
+        const int qi = which ? which[i] : i;
+        QueryJob &j = src.jobs[(size_t)i];
+        j.g = &graph_;
+        j.capacity = (int)capacity_;
+        j.qi = qi;
+        j.ef = ef;
+        j.k = k;
+        j.out_ids = out_ids + (size_t)qi * k;
+        j.out_d = out_dists + (size_t)qi * k;
+    }
+    if (!engine_->run(src, count)) { err = get_dev_error(); return -1; }
+    return 0;
+}
+
+// Graph-resident traversal: one kernel launch runs every query's FindEntryPointQuery +
+// SearchLayerQuery (HNSWIndex.cs:116-117); the host only orders the returned heap arrays.
+int HnswIndex::knn_query_device(const float *, int count, int k, int *out_ids, float *out_dists, std::string &err)
+{
+    if (!sync_graph(err)) return -1;
+    const int ef = std::max(p_.min_nn, k);
+    std::vector<SearchJob> jobs((size_t)count);
+    const int ep = graph_.entry, top = graph_.top_layer();
+    for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0};
+    std::vector<SearchHit> hits((size_t)count * ef);
+    std::vector<int> cnt((size_t)count), flag((size_t)count);
+    if (!dev_->search_batch(jobs.data(), count, ef, hits.data(), cnt.data(), flag.data())) { err = get_dev_error(); return -1; }
+    std::vector<int> redo;
+    for (int i = 0; i < count; ++i) if (flag[(size_t)i]) redo.push_back(i);
+    parallel_for(count, threads_, [&](int i) {
+        if (flag[(size_t)i]) return;
+        NodeDist *h = reinterpret_cast<NodeDist *>(hits.data() + (size_t)i * ef);
+        const int n = cnt[(size_t)i];
+        // OrderBy(c => c.Dist) (:121) is stable over the heap-order array
+        std::stable_sort(h, h + n, [](const NodeDist &a, const NodeDist &b) { return float_compare_to(a.dist, b.dist) < 0; });
+        const int m = std::min(n, k);
+        int *oi = out_ids + (size_t)i * k;
+        float *od = out_dists + (size_t)i * k;
+        for (int j = 0; j < m; ++j) { oi[j] = h[j].id; od[j] = h[j].dist; }
+        for (int j = m; j < k; ++j) { oi[j] = -1; od[j] = std::numeric_limits<float>::quiet_NaN(); } // Exports.cs:144
+    });
+    if (!redo.empty()) // candidate heap outgrew LDS: exact re-run on the lock-step path
+        return knn_query_lockstep(redo.data(), (int)redo.size(), k, out_ids, out_dists, err);
+    return 0;
+}
+
 int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *out_ids, float *out_dists, std::string &err)
 {
     if (count <= 0) return 0;
@@ -534,21 +619,8 @@ int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *o
     }
     if (!ensure_dim(dim, err)) return -1;
     if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; }
-    QuerySource src;
-    src.jobs.resize((size_t)count);
-    const int ef = std::max(p_.min_nn, k); // :115
-    for (int i = 0; i < count; ++i) {
-        QueryJob &j = src.jobs[(size_t)i];
-        j.g = &graph_;
-        j.capacity = (int)capacity_;
-        j.qi = i;
-        j.ef = ef;
-        j.k = k;
-        j.out_ids = out_ids + (size_t)i * k;
-        j.out_d = out_dists + (size_t)i * k;
-    }
-    if (!engine_->run(src, count)) { err = get_dev_error(); return -1; }
-    return 0;
+    if (p_.device_traversal) return knn_query_device(queries, count, k, out_ids, out_dists, err);
+    return knn_query_lockstep(nullptr, count, k, out_ids, out_dists, err);
 }
 
 uint64_t HnswIndex::graph_hash() const

@@ -27,6 +27,7 @@ struct Params {
     int insert_batch = 4096; // 1 = strictly sequential inserts
     int search_slots = 16384;
     int host_threads = 0;    // 0: min(hardware threads, 16)
+    int device_traversal = 1; // 1: graph-resident search kernel; 0: host lock-step traversal
 };
 
 class HnswIndex {
@@ -50,6 +51,9 @@ private:
     bool ensure_dim(int dim, std::string &err);
     bool ensure_capacity(long long need, std::string &err);
     bool insert_batch(int first_id, int n, std::string &err);
+    bool sync_graph(std::string &err);
+    int knn_query_device(const float *queries, int count, int k, int *out_ids, float *out_dists, std::string &err);
+    int knn_query_lockstep(const int *which, int count, int k, int *out_ids, float *out_dists, std::string &err);
 
     int metric_ = 0;
     int dim_ = 0; // fixed by the first add (the reference takes it from the arrays)
@@ -64,6 +68,7 @@ private:
     int device_ordinal_ = 0;
     int threads_ = 1;
     bool profiling_ = false;
+    bool graph_dirty_ = true;
 };
 
 } // namespace hnsw

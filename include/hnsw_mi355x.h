@@ -96,6 +96,9 @@ int hnsw_mi355x_set_insert_batch(int max_batch);
  * host worker threads (default: min(hardware threads, 16)). */
 int hnsw_mi355x_set_search_slots(int slots);
 int hnsw_mi355x_set_host_threads(int threads);
+/* Pending: 1 (default) = KnnQuery traverses on the device (graph mirrored in HBM, heaps in LDS);
+ * 0 = traversal on the host, distances batched to the device step by step.  Same results. */
+int hnsw_mi355x_set_device_traversal(int enabled);
 
 /* Graph introspection for parity checks (reads host state only). */
 int hnsw_mi355x_count(void *handle);
@@ -131,6 +134,13 @@ typedef struct hnswdev_stats {
     uint64_t timed_evals;   /* evaluations inside those launches */
     double kernel_ms;       /* sum of HIP-event durations of the timed launches */
     uint64_t row_bytes;     /* dim * sizeof(float): algorithmic bytes per evaluation */
+    /* graph-resident search kernel (traversal on the device) */
+    uint64_t search_launches;
+    uint64_t search_evals;        /* distance evaluations inside those launches (device-counted) */
+    uint64_t search_timed_launches;
+    uint64_t search_timed_evals;
+    double search_kernel_ms;      /* HIP-event durations of the timed search launches */
+    uint64_t search_overflows;    /* traversals handed back to the lock-step path */
 } hnswdev_stats;
 
 /* All return 0 on success, < 0 on error (message via hnswdev_last_error). */

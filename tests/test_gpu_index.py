@@ -17,8 +17,12 @@ def Index():
     return hnswindex.Index
 
 
-def _build(Index, g, x):
+TRAVERSALS = ["device", "host"]
+
+
+def _build(Index, g, x, traversal="device"):
     ix = Index(g["dim"], g["metric"])
+    ix.set_device_traversal(traversal == "device")
     ix.set_collection_size(g["n"])
     ix.set_random_seed(g["random_seed"])
     ix.set_max_edges(g["params"]["max_edges"])
@@ -29,10 +33,11 @@ def _build(Index, g, x):
     return ix, ids
 
 
+@pytest.mark.parametrize("traversal", TRAVERSALS)
 @pytest.mark.parametrize("name", golden_cases())
-def test_golden_fixture(Index, name):
+def test_golden_fixture(Index, name, traversal):
     g, x, q = load_golden(name)
-    ix, ids = _build(Index, g, x)
+    ix, ids = _build(Index, g, x, traversal)
     assert (ids == np.arange(g["n"])).all()
     assert ix.levels()[:128].tolist() == g["levels_head"]
     assert ix.entry_point == g["entry_point"]
@@ -42,13 +47,15 @@ def test_golden_fixture(Index, name):
     assert kd.view(np.uint32).tolist() == g["knn_dist_bits"]
 
 
+@pytest.mark.parametrize("traversal", TRAVERSALS)
 @pytest.mark.parametrize("metric", ["sq_euclid", "cosine", "ucosine"])
-def test_sequential_add_and_query_match_oracle(Index, metric):
+def test_sequential_add_and_query_match_oracle(Index, metric, traversal):
     n, dim = 1200, 128
     x, q = uniform(n, dim, 21), uniform(200, dim, 22)
     if metric == "ucosine":
         x, q = normalize_f32(x), normalize_f32(q)
     ix = Index(dim, metric)
+    ix.set_device_traversal(traversal == "device")
     ix.set_collection_size(256)                 # forces two doubling resizes
     ix.set_insert_batch(1)
     ids = ix.add(x)
@@ -157,7 +164,7 @@ def test_edge_cases_and_errors(Index):
 
 def test_stats_count_every_evaluation_and_profiling_times_kernels(Index):
     x, q = uniform(3000, 64, 71), uniform(500, 64, 72)
-    ix = Index(64); ix.set_collection_size(3000)
+    ix = Index(64); ix.set_collection_size(3000); ix.set_device_traversal(False)
     ix.set_profiling(True)
     ix.add(x)
     ix.reset_stats()
@@ -166,3 +173,52 @@ def test_stats_count_every_evaluation_and_profiling_times_kernels(Index):
     assert s["evals"] > 500 * 10 and s["launches"] > 0
     assert s["timed_launches"] == s["launches"] and s["timed_evals"] == s["evals"]
     assert s["kernel_ms"] > 0 and s["row_bytes"] == 64 * 4
+
+
+@pytest.mark.parametrize("dim,metric,M", [(127, "sq_euclid", 12), (768, "ucosine", 32), (96, "cosine", 5), (8, "sq_euclid", 40)])
+def test_device_and_host_traversal_agree_with_oracle_odd_shapes(Index, dim, metric, M):
+    n = 3000
+    x, q = uniform(n, dim, 81), uniform(300, dim, 82)
+    if metric == "ucosine":
+        x, q = normalize_f32(x), normalize_f32(q)
+    ref = oracle.OracleIndex(dim, metric, max_edges=M, max_candidates=60, min_nn=40, collection_size=n)
+    ref.add_batched(x, 256)
+    want_ids, want_d = ref.knn_query(q, 7)
+    for traversal in TRAVERSALS:
+        ix = Index(dim, metric)
+        ix.set_collection_size(n); ix.set_max_edges(M); ix.set_max_candidates(60); ix.set_min_nn(40)
+        ix.set_insert_batch(256); ix.set_device_traversal(traversal == "device")
+        ix.add(x)
+        assert ix.graph_hash() == ref.graph_hash()
+        ids, d = ix.knn_query(q, 7)
+        assert (ids == want_ids).all() and d.tobytes() == want_d.tobytes(), traversal
+
+
+def test_candidate_heap_overflow_hands_back_to_lockstep_exactly(Index, monkeypatch):
+    # a tiny LDS candidate heap forces the hand-back path; results must not change
+    x, q = uniform(4000, 64, 91), uniform(256, 64, 92)
+    ref = oracle.OracleIndex(64, collection_size=4000, min_nn=64)
+    ref.add_batched(x, 512)
+    want_ids, want_d = ref.knn_query(q, 10)
+    monkeypatch.setenv("HNSW_MI355X_CAND_CAP", "24")
+    ix = Index(64); ix.set_collection_size(4000); ix.set_min_nn(64); ix.set_insert_batch(512)
+    ix.add(x)
+    ids, d = ix.knn_query(q, 10)
+    assert (ids == want_ids).all() and d.tobytes() == want_d.tobytes()
+    assert ix.stats()["search_overflows"] > 0
+
+
+def test_search_stats_count_device_evaluations(Index):
+    x, q = uniform(3000, 64, 71), uniform(500, 64, 72)
+    ix = Index(64); ix.set_collection_size(3000)
+    ix.add(x)
+    ix.set_profiling(True)
+    ix.reset_stats()
+    ix.knn_query(q, 10)
+    s = ix.stats()
+    assert s["search_launches"] == 1 and s["search_timed_launches"] == 1
+    assert s["search_evals"] > 500 * 10 and s["search_kernel_ms"] > 0
+    ref = oracle.OracleIndex(64, collection_size=3000); ref.add_batched(x, 4096); ref.reset_n_eval(); ref.knn_query(q, 10)
+    # same traversal => same evaluations, except that the oracle re-measures the layer-0 entry
+    # point once per query (GraphNavigator.cs:200) and re-measures the start node on each upper layer
+    assert abs(s["search_evals"] - ref.n_eval) <= 500 * (1 + ref.levels().max())
