@@ -81,6 +81,15 @@ public:
     // BinaryHeap.ToArray()), out_cnt: hits per job, out_flag: 1 where the candidate heap
     // outgrew its LDS capacity (caller re-runs that job on the lock-step path).  Synchronous.
     bool search_batch(const SearchJob *jobs, int njobs, int k, SearchHit *out_hits, int *out_cnt, int *out_flag);
+    // Insert, search half, fused on the device: traversal with beam k (= MaxCandidates) followed
+    // by RelativeNeighborPruning.  jobs[].qref must be ~item_id.  max_edges0 = MaxEdges(0) = 2M.
+    // out_sel: njobs x sel_stride selected ids; out_first: search distance of selected[0].
+    bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int *out_sel, int sel_stride,
+                             int *out_cnt, float *out_first, int *out_flag);
+    // PruneOverflow for njobs adjacency lists.  recs: njobs x in_stride ints [node, cnt, ids...];
+    // job_max_edges[j] = MaxEdges(layer of job j).  out_sel / out_cnt: the new lists.
+    bool prune_batch(const int *recs, int njobs, int in_stride, const int *job_max_edges, int *out_sel, int sel_stride,
+                     int *out_cnt);
 
     // C-ABI conveniences (synchronous; validate ids on the host before launching).
     bool dist_query_batch(const float *queries, int nq, const int *offsets, const int *ids, float *out);
@@ -114,6 +123,10 @@ private:
     int *s_cnt_ = nullptr, *s_flag_ = nullptr;
     unsigned long long *s_evals_ = nullptr;
     size_t s_jobs_cap_ = 0, s_hits_cap_ = 0;
+    int *s_sel_ = nullptr, *s_in_ = nullptr, *s_jme_ = nullptr;
+    float *s_first_ = nullptr;
+    size_t s_sel_cap_ = 0, s_in_cap_ = 0, s_jme_cap_ = 0, s_first_cap_ = 0;
+    bool ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_job);
     void *ev0_ = nullptr, *ev1_ = nullptr;
     void *stream_ = nullptr;
     bool profiling_ = false;

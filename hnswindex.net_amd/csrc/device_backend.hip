@@ -339,45 +339,63 @@ __device__ __forceinline__ void measure_all(const float *rows, const double *row
     }
 }
 
-constexpr int kNbufCap = 136; // >= 2*M + 2 for M <= 64 ... (checked on the host)
+constexpr int kNbufCap = 136; // >= 2*M + 1 (checked on the host in set_graph)
 
-template <int METRIC>
-__global__ void __launch_bounds__(64)
-graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
-                    const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
-                    const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
-                    const SearchJob *__restrict__ jobs, int k, int cand_cap, unsigned *__restrict__ visited,
-                    long long vis_words, ND *__restrict__ out_hits, int *__restrict__ out_cnt, int *__restrict__ out_flag,
-                    unsigned long long *__restrict__ eval_counter)
+// LDS carve-up shared by the traversal kernels
+struct SearchLds {
+    ND *top;    // k + 1
+    ND *cand;   // cand_cap
+    float *qs;  // dim (padded to 4)
+    float *qs2; // dim (padded to 4): second vector (heuristic / prune)
+    int *nbuf;  // kNbufCap
+    float *dbuf; // kNbufCap
+    int *acc;   // kNbufCap: accepted ids of the heuristic
+    int *stk;   // 3 * 40: introsort work stack
+};
+__host__ __device__ inline size_t search_lds_bytes(int k, int cand_cap, int dim)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    ND *top = reinterpret_cast<ND *>(smem);                 // k + 1
-    ND *cand = top + (k + 1);                               // cand_cap
-    float *qs = reinterpret_cast<float *>(cand + cand_cap); // dim (+pad)
-    int *nbuf = reinterpret_cast<int *>(qs + ((dim + 3) & ~3));
-    float *dbuf = reinterpret_cast<float *>(nbuf + kNbufCap);
+    return sizeof(ND) * (size_t)(k + 1 + cand_cap) + 2 * sizeof(float) * (size_t)((dim + 3) & ~3) + 3u * 4u * kNbufCap + 4u * 3u * 40u;
+}
+__device__ __forceinline__ SearchLds carve_lds(unsigned char *smem, int k, int cand_cap, int dim)
+{
+    SearchLds L;
+    L.top = reinterpret_cast<ND *>(smem);
+    L.cand = L.top + (k + 1);
+    L.qs = reinterpret_cast<float *>(L.cand + cand_cap);
+    L.qs2 = L.qs + ((dim + 3) & ~3);
+    L.nbuf = reinterpret_cast<int *>(L.qs2 + ((dim + 3) & ~3));
+    L.dbuf = reinterpret_cast<float *>(L.nbuf + kNbufCap);
+    L.acc = reinterpret_cast<int *>(L.dbuf + kNbufCap);
+    L.stk = L.acc + kNbufCap;
+    return L;
+}
 
-    const int lane = threadIdx.x;
-    const int job = blockIdx.x;
-    const SearchJob jb = jobs[job];
-    unsigned *vis = visited + (size_t)job * (size_t)vis_words;
-
-    const float *q;
-    double sb = 0.0;
-    if (jb.qref >= 0) {
-        q = queries + (size_t)jb.qref * dim;
-        if (METRIC == M_COS) sb = q_sn[jb.qref];
-    } else {
-        q = rows + (size_t)(~jb.qref) * dim;
-        if (METRIC == M_COS) sb = row_sn[~jb.qref];
+struct GraphView {
+    const int *adj0;
+    int stride0;
+    const int64_t *upper;
+    const int *pool;
+    int strideU;
+    __device__ __forceinline__ const int *list(int id, int layer) const
+    {
+        return layer == 0 ? adj0 + (size_t)id * stride0 : pool + upper[id] + (size_t)(layer - 1) * strideU;
     }
-    for (int i = lane; i < dim; i += 64) qs[i] = q[i];
-    __syncthreads();
+};
 
-    unsigned long long evals = 0;
-
+// Descent + beam search of one job; result = L.top[0..top_n) in heap order.  Returns false on
+// candidate-heap overflow.  The query must already be staged in L.qs.
+template <int METRIC>
+__device__ __forceinline__ bool traverse(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
+                                         const GraphView &G, const SearchJob jb, int k, int cand_cap, unsigned *vis,
+                                         const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals)
+{
+    ND *top = L.top, *cand = L.cand;
+    int *nbuf = L.nbuf;
+    float *dbuf = L.dbuf;
+    const float *qs = L.qs;
     // ---- FindEntryPoint / FindEntryAtLayer (GraphNavigator.cs:27-82) ----
     int best = jb.entry;
+    __syncthreads();
     if (lane == 0) nbuf[0] = best;
     __syncthreads();
     measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, 1, lane);
@@ -388,7 +406,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
         bool changed = true;
         while (changed) { // :60
             changed = false;
-            const int *l = pool + upper[best] + (size_t)(layer - 1) * strideU;
+            const int *l = G.list(best, layer);
             const int n = l[0];
             __syncthreads();
             for (int i = lane; i < n; i += 64) nbuf[i] = l[1 + i]; // :65 span taken once per pass
@@ -402,7 +420,6 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
             }
         }
     }
-
     // ---- SearchLayer (GraphNavigator.cs:123-189) ----
     const int layer = jb.search_layer;
     int top_n = 0, cand_n = 0;
@@ -417,7 +434,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     while (cand_n > 0) {
         ND c = heap_pop<true>(cand, cand_n);           // :146
         if (c.dist > farthest && top_n >= k) break;    // :147-150
-        const int *l = (layer == 0) ? adj0 + (size_t)c.id * stride0 : pool + upper[c.id] + (size_t)(layer - 1) * strideU;
+        const int *l = G.list(c.id, layer);
         const int n = l[0];
         int m = 0;
         __syncthreads();
@@ -455,11 +472,242 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
         if (overflow) break;
     }
     __syncthreads();
+    top_n_out = top_n;
+    return !overflow;
+}
+
+// ---- MemoryExtensions.Sort(Span<NodeDistance>, DistanceComparer) on an LDS array: the BCL
+// introsort restated (insertion sort <= 16, median of three, heapsort at depth limit
+// 2*(log2 n + 1)); wave-uniform scalar code, recursion replaced by a work stack in LDS.
+// Same algorithm as csrc/host_structs.h::dotnet_sort, so tie order is identical. ----
+__device__ __forceinline__ void sw_swap(ND *k, int i, int j) { ND t = k[i]; k[i] = k[j]; k[j] = t; }
+__device__ __forceinline__ void sw_swap_if_greater(ND *k, int i, int j) { if (nd_cmp<false>(k[i], k[j]) > 0) sw_swap(k, i, j); }
+__device__ inline void sw_insertion(ND *k, int n)
+{
+    for (int i = 0; i < n - 1; i++) {
+        ND t = k[i + 1];
+        int j = i;
+        while (j >= 0 && nd_cmp<false>(t, k[j]) < 0) { k[j + 1] = k[j]; j--; }
+        k[j + 1] = t;
+    }
+}
+__device__ inline void sw_down_heap(ND *k, int i, int n)
+{
+    ND d = k[i - 1];
+    while (i <= (n >> 1)) {
+        int child = 2 * i;
+        if (child < n && nd_cmp<false>(k[child - 1], k[child]) < 0) child++;
+        if (!(nd_cmp<false>(d, k[child - 1]) < 0)) break;
+        k[i - 1] = k[child - 1];
+        i = child;
+    }
+    k[i - 1] = d;
+}
+__device__ inline void sw_heap_sort(ND *k, int n)
+{
+    for (int i = n >> 1; i >= 1; i--) sw_down_heap(k, i, n);
+    for (int i = n; i > 1; i--) { sw_swap(k, 0, i - 1); sw_down_heap(k, 1, i - 1); }
+}
+__device__ inline int sw_partition(ND *k, int n)
+{
+    int hi = n - 1, mid = hi >> 1;
+    sw_swap_if_greater(k, 0, mid);
+    sw_swap_if_greater(k, 0, hi);
+    sw_swap_if_greater(k, mid, hi);
+    ND pivot = k[mid];
+    sw_swap(k, mid, hi - 1);
+    int left = 0, right = hi - 1;
+    while (left < right) {
+        while (nd_cmp<false>(k[++left], pivot) < 0) {}
+        while (nd_cmp<false>(pivot, k[--right]) < 0) {}
+        if (left >= right) break;
+        sw_swap(k, left, right);
+    }
+    if (left != hi - 1) sw_swap(k, left, hi - 1);
+    return left;
+}
+__device__ inline void dev_dotnet_sort(ND *arr, int n, int *stk)
+{
+    if (n <= 1) return;
+    int sp = 0;
+    stk[0] = 0; stk[1] = n; stk[2] = 2 * ((31 - __clz(n)) + 1);
+    sp = 1;
+    while (sp > 0) {
+        --sp;
+        ND *k = arr + stk[3 * sp];
+        int ps = stk[3 * sp + 1];
+        int depth = stk[3 * sp + 2];
+        while (ps > 1) {
+            if (ps <= 16) {
+                if (ps == 2) { sw_swap_if_greater(k, 0, 1); break; }
+                if (ps == 3) { sw_swap_if_greater(k, 0, 1); sw_swap_if_greater(k, 0, 2); sw_swap_if_greater(k, 1, 2); break; }
+                sw_insertion(k, ps);
+                break;
+            }
+            if (depth == 0) { sw_heap_sort(k, ps); break; }
+            depth--;
+            int p = sw_partition(k, ps);
+            // right part [p+1, ps) is an independent sub-problem: queue it (the BCL recurses into it)
+            if (sp < 39) {
+                stk[3 * sp] = (int)(k - arr) + p + 1; stk[3 * sp + 1] = ps - (p + 1); stk[3 * sp + 2] = depth;
+                ++sp;
+            }
+            ps = p;
+        }
+    }
+}
+
+// Heuristic.RelativeNeighborPruning (Heuristic.cs:11-46) on cands[0..n) (LDS): writes the
+// selected ids to L.acc, returns their count.  The candidate under test is staged in L.qs2
+// and measured against ALL accepted rows at once (the reference's early break only skips
+// evaluations).
+template <int METRIC>
+__device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                                                         ND *cands, int n, int max_edges, const SearchLds &L, int lane,
+                                                         unsigned long long &evals)
+{
+    int *acc = L.acc;
+    __syncthreads();
+    if (n < max_edges) { // :13-18 input (heap) order, unsorted
+        for (int i = lane; i < n; i += 64) acc[i] = cands[i].id;
+        __syncthreads();
+        return n;
+    }
+    dev_dotnet_sort(cands, n, L.stk); // :22
+    __syncthreads();
+    int rc = 0;
+    for (int i = 0; i < n && rc < max_edges; ++i) { // :23
+        const ND c = cands[i];
+        if (rc == 0) { if (lane == 0) acc[0] = c.id; rc = 1; __syncthreads(); continue; }
+        const float *crow = rows + (size_t)c.id * dim;
+        for (int t = lane; t < dim; t += 64) L.qs2[t] = crow[t];
+        double sbc = 0.0;
+        if (METRIC == M_COS) sbc = row_sn[c.id];
+        __syncthreads();
+        measure_all<METRIC>(rows, row_sn, dim, L.qs2, sbc, acc, L.dbuf, rc, lane); // distanceFnc(s.Id, candidateId) :34
+        __syncthreads();
+        evals += (unsigned long long)rc;
+        bool ok = true;
+        for (int j = 0; j < rc; ++j)
+            if (L.dbuf[j] < c.dist) { ok = false; break; }
+        if (ok) { if (lane == 0) acc[rc] = c.id; rc++; }
+        __syncthreads();
+    }
+    return rc;
+}
+
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
+                    const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
+                    const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
+                    const SearchJob *__restrict__ jobs, int k, int cand_cap, unsigned *__restrict__ visited,
+                    long long vis_words, ND *__restrict__ out_hits, int *__restrict__ out_cnt, int *__restrict__ out_flag,
+                    unsigned long long *__restrict__ eval_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SearchLds L = carve_lds(smem, k, cand_cap, dim);
+    const int lane = threadIdx.x;
+    const int job = blockIdx.x;
+    const SearchJob jb = jobs[job];
+    unsigned *vis = visited + (size_t)job * (size_t)vis_words;
+    const GraphView G{adj0, stride0, upper, pool, strideU};
+
+    const float *q;
+    double sb = 0.0;
+    if (jb.qref >= 0) {
+        q = queries + (size_t)jb.qref * dim;
+        if (METRIC == M_COS) sb = q_sn[jb.qref];
+    } else {
+        q = rows + (size_t)(~jb.qref) * dim;
+        if (METRIC == M_COS) sb = row_sn[~jb.qref];
+    }
+    for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+    unsigned long long evals = 0;
+    int top_n = 0;
+    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, vis, L, lane, top_n, evals);
     // ToArray(): the heap's buffer prefix, heap order (BinaryHeap.cs:41-44)
-    for (int i = lane; i < top_n; i += 64) out_hits[(size_t)job * k + i] = top[i];
+    for (int i = lane; i < top_n; i += 64) out_hits[(size_t)job * k + i] = L.top[i];
     if (lane == 0) {
-        out_cnt[job] = overflow ? 0 : top_n;
-        out_flag[job] = overflow ? 1 : 0;
+        out_cnt[job] = ok ? top_n : 0;
+        out_flag[job] = ok ? 0 : 1;
+        atomicAdd(eval_counter, evals);
+    }
+}
+
+// Insert, search half, fused: ConnectAtLayer's SearchLayer + RelativeNeighborPruning
+// (GraphConnector.cs:189-190) for one (item, layer).  Output: the selected neighbour ids (in
+// selection order) and the search distance of selected[0] (the next layer's entry, :216).
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                           const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
+                           const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
+                           int cand_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
+                           int *__restrict__ out_sel, int sel_stride, int *__restrict__ out_cnt, float *__restrict__ out_first_dist,
+                           int *__restrict__ out_flag, unsigned long long *__restrict__ eval_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SearchLds L = carve_lds(smem, k, cand_cap, dim);
+    const int lane = threadIdx.x;
+    const int job = blockIdx.x;
+    const SearchJob jb = jobs[job];
+    unsigned *vis = visited + (size_t)job * (size_t)vis_words;
+    const GraphView G{adj0, stride0, upper, pool, strideU};
+    const int item = ~jb.qref;
+    const float *q = rows + (size_t)item * dim;
+    double sb = 0.0;
+    if (METRIC == M_COS) sb = row_sn[item];
+    for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+    unsigned long long evals = 0;
+    int top_n = 0;
+    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, vis, L, lane, top_n, evals);
+    int rc = 0;
+    float first = 0.f;
+    if (ok) {
+        const int max_edges = jb.search_layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
+        rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals);
+        first = L.top[0].dist; // selected[0] is cands[0] in both Heuristic paths
+        for (int i = lane; i < rc; i += 64) out_sel[(size_t)job * sel_stride + i] = L.acc[i];
+    }
+    if (lane == 0) {
+        out_cnt[job] = rc;
+        out_first_dist[job] = first;
+        out_flag[job] = ok ? 0 : 1;
+        atomicAdd(eval_counter, evals);
+    }
+}
+
+// Insert, link half: GraphConnector.PruneOverflow (GraphConnector.cs:222-262) for one
+// overflowing adjacency list: distances node<->edges (:230-234), sort + heuristic (:235).
+// in: per job [node, cnt, ids[cnt]] (stride in_stride); out: new list.
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+graph_prune_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, const int *__restrict__ in,
+                   int in_stride, int k_cap, int *__restrict__ out_sel, int sel_stride, int *__restrict__ out_cnt,
+                   const int *__restrict__ job_max_edges, unsigned long long *__restrict__ eval_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SearchLds L = carve_lds(smem, k_cap, 0, dim);
+    const int lane = threadIdx.x;
+    const int job = blockIdx.x;
+    const int *rec = in + (size_t)job * in_stride;
+    const int node = rec[0], n = rec[1];
+    const float *q = rows + (size_t)node * dim;
+    double sb = 0.0;
+    if (METRIC == M_COS) sb = row_sn[node];
+    for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+    for (int i = lane; i < n; i += 64) L.nbuf[i] = rec[2 + i];
+    __syncthreads();
+    unsigned long long evals = (unsigned long long)n;
+    measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, L.nbuf, L.dbuf, n, lane); // Distance(cand, node.Id) :233
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) L.top[i] = ND{L.nbuf[i], L.dbuf[i]};
+    __syncthreads();
+    const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, n, job_max_edges[job], L, lane, evals);
+    for (int i = lane; i < rc; i += 64) out_sel[(size_t)job * sel_stride + i] = L.acc[i];
+    if (lane == 0) {
+        out_cnt[job] = rc;
         atomicAdd(eval_counter, evals);
     }
 }
@@ -553,7 +801,7 @@ Device::~Device()
     if (d_queries_) (void)hipFree(d_queries_);
     if (d_q_sn_) (void)hipFree(d_q_sn_);
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_in_, (void *)s_jme_, (void *)s_first_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -776,23 +1024,19 @@ bool Device::set_graph(const int *adj0, long long n, int stride0, const int *lev
     return true;
 }
 
-bool Device::search_batch(const SearchJob *jobs, int njobs, int k, SearchHit *out_hits, int *out_cnt, int *out_flag)
+template <class T>
+static bool grow_dev(T **p, size_t *cap, size_t need)
 {
-    if (njobs <= 0) return true;
-    if (!jobs || !out_hits || !out_cnt || !out_flag || k < 1) { set_dev_error("search_batch: bad argument"); return false; }
-    if (g_n_ <= 0) { set_dev_error("search_batch: no graph uploaded"); return false; }
-    if (!bind()) return false;
-    hipStream_t st = S(stream_);
-    // LDS: top (k+1) + cand heap + query + neighbour/distance scratch
-    int cand_cap = std::min(std::max(8 * k, 1024), 6144);
-    if (const char *e = std::getenv("HNSW_MI355X_CAND_CAP")) cand_cap = std::max(1, std::atoi(e)); // tests: force the overflow hand-back
-    auto lds_bytes = [&](int cc) { return sizeof(ND) * (size_t)(k + 1 + cc) + sizeof(float) * (size_t)((dim_ + 3) & ~3) + 8u * kNbufCap; };
-    while (cand_cap > 256 && lds_bytes(cand_cap) > 64 * 1024) cand_cap /= 2;
-    if (lds_bytes(cand_cap) > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
-    const long long vis_words = (g_n_ + 31) / 32;
-    const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
-    // jobs per launch bounded by an 8 GiB visited arena
-    long long chunk = std::min<long long>(njobs, std::max<long long>(256, (8LL << 30) / (long long)std::max<size_t>(vis_bytes_per_job, 1)));
+    if (need <= *cap) return true;
+    if (*p) HIP_OK(hipFree(*p));
+    *p = nullptr;
+    HIP_OK(hipMalloc(p, sizeof(T) * need));
+    *cap = need;
+    return true;
+}
+
+bool Device::ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_job)
+{
     if (vis_bytes_per_job * (size_t)chunk > s_visited_bytes_) {
         if (s_visited_) HIP_OK(hipFree(s_visited_));
         s_visited_ = nullptr;
@@ -808,19 +1052,144 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, SearchHit *ou
         HIP_OK(hipMalloc(&s_cnt_, sizeof(int) * s_jobs_cap_));
         HIP_OK(hipMalloc(&s_flag_, sizeof(int) * s_jobs_cap_));
     }
-    if ((size_t)chunk * k > s_hits_cap_) {
-        if (s_hits_) HIP_OK(hipFree(s_hits_));
-        s_hits_cap_ = (size_t)chunk * k;
-        HIP_OK(hipMalloc(&s_hits_, sizeof(SearchHit) * s_hits_cap_));
-    }
+    if (k > 0 && !grow_dev(&s_hits_, &s_hits_cap_, (size_t)chunk * k)) return false;
     if (!s_evals_) HIP_OK(hipMalloc(&s_evals_, sizeof(unsigned long long)));
     if (!ev0_) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); ev0_ = a; ev1_ = b; }
+    return true;
+}
+
+static bool jobs_valid(const SearchJob *jobs, int njobs, long long g_n, long long n_queries, long long n_rows)
+{
     for (int i = 0; i < njobs; ++i) {
         const SearchJob &j = jobs[i];
-        bool ok = j.entry >= 0 && j.entry < g_n_ && j.search_layer >= 0 && j.entry_layer >= j.search_layer &&
-                  (j.qref >= 0 ? j.qref < n_queries_ : (~j.qref) < n_rows_hw_);
-        if (!ok) { set_dev_error("search_batch: job outside the uploaded graph / rows / queries"); return false; }
+        bool ok = j.entry >= 0 && j.entry < g_n && j.search_layer >= 0 && j.entry_layer >= j.search_layer &&
+                  (j.qref >= 0 ? j.qref < n_queries : (~j.qref) < n_rows);
+        if (!ok) return false;
     }
+    return true;
+}
+
+bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int *out_sel, int sel_stride,
+                                 int *out_cnt, float *out_first, int *out_flag)
+{
+    if (njobs <= 0) return true;
+    if (!jobs || !out_sel || !out_cnt || !out_first || !out_flag || k < 1 || sel_stride < max_edges0) { set_dev_error("insert_search_batch: bad argument"); return false; }
+    if (g_n_ <= 0) { set_dev_error("insert_search_batch: no graph uploaded"); return false; }
+    for (int i = 0; i < njobs; ++i) if (jobs[i].qref >= 0) { set_dev_error("insert_search_batch: qref must name a stored row"); return false; }
+    if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("insert_search_batch: job outside the uploaded graph / rows"); return false; }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    int cand_cap = std::min(std::max(8 * k, 1024), 6144);
+    if (const char *e = std::getenv("HNSW_MI355X_CAND_CAP")) cand_cap = std::max(1, std::atoi(e));
+    while (cand_cap > 256 && search_lds_bytes(k, cand_cap, dim_) > 64 * 1024) cand_cap /= 2;
+    if (search_lds_bytes(k, cand_cap, dim_) > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
+    const long long vis_words = (g_n_ + 31) / 32;
+    const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
+    long long chunk = std::min<long long>(njobs, std::max<long long>(256, (8LL << 30) / (long long)std::max<size_t>(vis_bytes_per_job, 1)));
+    if (!ensure_search_scratch(chunk, 0, vis_bytes_per_job)) return false;
+    if (!grow_dev(&s_sel_, &s_sel_cap_, (size_t)chunk * sel_stride) || !grow_dev(&s_first_, &s_first_cap_, (size_t)chunk)) return false;
+    for (long long off = 0; off < njobs; off += chunk) {
+        const int nj = (int)std::min<long long>(chunk, njobs - off);
+        HIP_OK(hipMemcpyAsync(s_jobs_, jobs + off, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(s_visited_, 0, vis_bytes_per_job * (size_t)nj, st));
+        HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
+        const bool timed = profiling_;
+        if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
+        const size_t lds = search_lds_bytes(k, cand_cap, dim_);
+#define LAUNCH(M)                                                                                                          \
+    hipLaunchKernelGGL(graph_insert_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
+                       g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, max_edges0, s_visited_, vis_words, s_sel_, sel_stride, \
+                       s_cnt_, s_first_, s_flag_, s_evals_)
+        if (metric_ == M_SQ) LAUNCH(M_SQ);
+        else if (metric_ == M_COS) LAUNCH(M_COS);
+        else LAUNCH(M_UCOS);
+#undef LAUNCH
+        HIP_OK(hipGetLastError());
+        if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
+        unsigned long long ev = 0;
+        HIP_OK(hipMemcpyAsync(out_sel + (size_t)off * sel_stride, s_sel_, sizeof(int) * (size_t)nj * sel_stride, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(out_cnt + off, s_cnt_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(out_first + off, s_first_, sizeof(float) * (size_t)nj, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(out_flag + off, s_flag_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(&ev, s_evals_, sizeof(ev), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        stats_.search_launches++;
+        stats_.search_evals += ev;
+        if (timed) {
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
+            stats_.search_kernel_ms += ms;
+            stats_.search_timed_launches++;
+            stats_.search_timed_evals += ev;
+        }
+        for (int i = 0; i < nj; ++i) stats_.search_overflows += (uint64_t)(out_flag[off + i] != 0);
+    }
+    return true;
+}
+
+bool Device::prune_batch(const int *recs, int njobs, int in_stride, const int *job_max_edges, int *out_sel, int sel_stride, int *out_cnt)
+{
+    if (njobs <= 0) return true;
+    if (!recs || !job_max_edges || !out_sel || !out_cnt || in_stride < 3) { set_dev_error("prune_batch: bad argument"); return false; }
+    for (int j = 0; j < njobs; ++j) {
+        const int *r = recs + (size_t)j * in_stride;
+        bool ok = r[0] >= 0 && r[0] < n_rows_hw_ && r[1] >= 1 && r[1] <= in_stride - 2 && r[1] <= kNbufCap &&
+                  job_max_edges[j] >= 1 && job_max_edges[j] <= sel_stride;
+        for (int i = 0; ok && i < r[1]; ++i) ok = r[2 + i] >= 0 && r[2 + i] < n_rows_hw_;
+        if (!ok) { set_dev_error("prune_batch: record outside the uploaded rows / limits"); return false; }
+    }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    if (!ensure_search_scratch(1, 0, 4)) return false;
+    if (!grow_dev(&s_in_, &s_in_cap_, (size_t)njobs * in_stride) || !grow_dev(&s_jme_, &s_jme_cap_, (size_t)njobs) ||
+        !grow_dev(&s_sel_, &s_sel_cap_, (size_t)njobs * sel_stride))
+        return false;
+    if ((size_t)njobs > s_jobs_cap_) { // s_cnt_ is sized with s_jobs_
+        if (!ensure_search_scratch(njobs, 0, 4)) return false;
+    }
+    HIP_OK(hipMemcpyAsync(s_in_, recs, sizeof(int) * (size_t)njobs * in_stride, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(s_jme_, job_max_edges, sizeof(int) * (size_t)njobs, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
+    const int k_cap = kNbufCap;
+    const size_t lds = search_lds_bytes(k_cap, 0, dim_);
+#define LAUNCH(M)                                                                                                        \
+    hipLaunchKernelGGL(graph_prune_kernel<M>, dim3(njobs), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, s_in_, in_stride, k_cap, \
+                       s_sel_, sel_stride, s_cnt_, s_jme_, s_evals_)
+    if (metric_ == M_SQ) LAUNCH(M_SQ);
+    else if (metric_ == M_COS) LAUNCH(M_COS);
+    else LAUNCH(M_UCOS);
+#undef LAUNCH
+    HIP_OK(hipGetLastError());
+    unsigned long long ev = 0;
+    HIP_OK(hipMemcpyAsync(out_sel, s_sel_, sizeof(int) * (size_t)njobs * sel_stride, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(out_cnt, s_cnt_, sizeof(int) * (size_t)njobs, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(&ev, s_evals_, sizeof(ev), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    stats_.search_launches++;
+    stats_.search_evals += ev;
+    return true;
+}
+
+
+bool Device::search_batch(const SearchJob *jobs, int njobs, int k, SearchHit *out_hits, int *out_cnt, int *out_flag)
+{
+    if (njobs <= 0) return true;
+    if (!jobs || !out_hits || !out_cnt || !out_flag || k < 1) { set_dev_error("search_batch: bad argument"); return false; }
+    if (g_n_ <= 0) { set_dev_error("search_batch: no graph uploaded"); return false; }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    // LDS: top (k+1) + cand heap + query + neighbour/distance scratch
+    int cand_cap = std::min(std::max(8 * k, 1024), 6144);
+    if (const char *e = std::getenv("HNSW_MI355X_CAND_CAP")) cand_cap = std::max(1, std::atoi(e)); // tests: force the overflow hand-back
+    auto lds_bytes = [&](int cc) { return search_lds_bytes(k, cc, dim_); };
+    while (cand_cap > 256 && lds_bytes(cand_cap) > 64 * 1024) cand_cap /= 2;
+    if (lds_bytes(cand_cap) > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
+    const long long vis_words = (g_n_ + 31) / 32;
+    const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
+    // jobs per launch bounded by an 8 GiB visited arena
+    long long chunk = std::min<long long>(njobs, std::max<long long>(256, (8LL << 30) / (long long)std::max<size_t>(vis_bytes_per_job, 1)));
+    if (!ensure_search_scratch(chunk, k, vis_bytes_per_job)) return false;
+    if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("search_batch: job outside the uploaded graph / rows / queries"); return false; }
     for (long long off = 0; off < njobs; off += chunk) {
         const int nj = (int)std::min<long long>(chunk, njobs - off);
         HIP_OK(hipMemcpyAsync(s_jobs_, jobs + off, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));

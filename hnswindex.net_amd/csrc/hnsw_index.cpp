@@ -352,6 +352,24 @@ struct LinkSource : JobSource {
     void release(Job *, SlotScratch &) override {}
 };
 
+template <class F>
+void parallel_for(int n, int threads, F fn)
+{
+    threads = std::max(1, std::min(threads, n / 64));
+    if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::vector<std::thread> th;
+    std::atomic<int> next{0};
+    for (int t = 0; t < threads; ++t)
+        th.emplace_back([&] {
+            for (;;) {
+                int i0 = next.fetch_add(64, std::memory_order_relaxed);
+                if (i0 >= n) break;
+                for (int i = i0, e = std::min(n, i0 + 64); i < e; ++i) fn(i);
+            }
+        });
+    for (auto &t : th) t.join();
+}
+
 constexpr int kBatchGrowthDiv = 32; // a snapshot batch never exceeds 1/32 of the linked graph
 
 } // namespace
@@ -431,54 +449,192 @@ bool HnswIndex::ensure_capacity(long long need, std::string &err)
     return true;
 }
 
-// One snapshot batch: ids [first_id, first_id + n) are nodes without edges yet.
-bool HnswIndex::insert_batch(int first_id, int n, std::string &err)
+// ---- search half --------------------------------------------------------------------------
+// Host traversal on the lock-step engine for the listed items (indices into the batch).
+bool HnswIndex::search_half_lockstep(int first_id, const std::vector<int> &items, Selection &sel, std::string &err)
 {
-    const int cap = (int)capacity_;
+    if (items.empty()) return true;
     InsertSource src;
-    src.jobs.resize((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        InsertJob &j = src.jobs[(size_t)i];
+    src.jobs.resize(items.size());
+    for (size_t t = 0; t < items.size(); ++t) {
+        InsertJob &j = src.jobs[t];
         j.g = &graph_;
-        j.capacity = cap;
-        j.id = first_id + i;
+        j.capacity = (int)capacity_;
+        j.id = first_id + items[t];
         j.level = graph_.level[(size_t)j.id];
         j.efc = p_.max_candidates;
     }
-    if (!engine_->run(src, n)) { err = get_dev_error(); return false; }
+    if (!engine_->run(src, (long long)items.size())) { err = get_dev_error(); return false; }
+    for (size_t t = 0; t < items.size(); ++t) sel[(size_t)items[t]] = std::move(src.jobs[t].selected);
+    return true;
+}
 
-    // link, part 1 (host only): currNode.OutEdges[layer] = selected (:192) and collect the
-    // back-edge appends per (neighbour, layer), in item order.
-    LinkSource links;
+// Graph-resident traversal: one fused kernel launch per layer (search + heuristic) for the whole
+// batch; items whose candidate heap outgrew LDS are redone on the lock-step path.
+bool HnswIndex::search_half_device(int first_id, int n, Selection &sel, std::string &err)
+{
+    if (!sync_graph(err)) return false;
+    const int top = graph_.top_layer(), ep = graph_.entry;
+    const int sel_stride = 2 * p_.max_edges;
+    std::vector<int> l0((size_t)n), next_entry((size_t)n, ep);
+    std::vector<char> redo((size_t)n, 0);
+    int maxl = 0;
+    for (int i = 0; i < n; ++i) {
+        const int lvl = graph_.level[(size_t)(first_id + i)];
+        sel[(size_t)i].assign((size_t)lvl + 1, {});
+        l0[(size_t)i] = std::min(lvl, top); // GraphConnector.cs:176
+        maxl = std::max(maxl, l0[(size_t)i]);
+    }
+    std::vector<SearchJob> jobs;
+    std::vector<int> who, out_sel, out_cnt, out_flag;
+    std::vector<float> out_first;
+    for (int L = maxl; L >= 0; --L) {
+        jobs.clear(); who.clear();
+        for (int i = 0; i < n; ++i) {
+            if (redo[(size_t)i] || l0[(size_t)i] < L) continue;
+            const int id = first_id + i;
+            // first layer of the item: FindEntryPoint from the top (:174); below: entry = selected[0] (:216,:179)
+            jobs.push_back(L == l0[(size_t)i] ? SearchJob{~id, ep, top, L} : SearchJob{~id, next_entry[(size_t)i], L, L});
+            who.push_back(i);
+        }
+        if (jobs.empty()) continue;
+        const int nj = (int)jobs.size();
+        out_sel.resize((size_t)nj * sel_stride); out_cnt.resize((size_t)nj); out_flag.resize((size_t)nj); out_first.resize((size_t)nj);
+        if (!dev_->insert_search_batch(jobs.data(), nj, p_.max_candidates, 2 * p_.max_edges, out_sel.data(), sel_stride,
+                                       out_cnt.data(), out_first.data(), out_flag.data())) { err = get_dev_error(); return false; }
+        for (int t = 0; t < nj; ++t) {
+            const int i = who[(size_t)t];
+            if (out_flag[(size_t)t]) { redo[(size_t)i] = 1; continue; }
+            const int *ids = out_sel.data() + (size_t)t * sel_stride;
+            sel[(size_t)i][(size_t)L].assign(ids, ids + out_cnt[(size_t)t]);
+            next_entry[(size_t)i] = ids[0];
+        }
+    }
+    std::vector<int> again;
+    for (int i = 0; i < n; ++i) if (redo[(size_t)i]) again.push_back(i);
+    return search_half_lockstep(first_id, again, sel, err);
+}
+
+// ---- link half ----------------------------------------------------------------------------
+namespace {
+struct LinkGroup {
+    int nb, layer;
+    std::vector<int> items;
+    size_t idx = 0;
+};
+// currNode.OutEdges[layer] = selected (:192) and the back-edge appends grouped per
+// (neighbour, layer), in item order.
+void collect_groups(Graph &g, int first_id, int n, const std::vector<std::vector<std::vector<int>>> &sel, std::vector<LinkGroup> &groups)
+{
     std::unordered_map<uint64_t, size_t> where;
     where.reserve((size_t)n * 40);
+    const int top = g.top_layer();
     for (int i = 0; i < n; ++i) {
-        InsertJob &j = src.jobs[(size_t)i];
-        const int top = std::min(j.level, graph_.top_layer());
-        for (int layer = top; layer >= 0; --layer) {
-            const std::vector<int> &sel = j.selected[(size_t)layer];
-            int *l = graph_.list(j.id, layer);
-            l[0] = (int)sel.size();
-            std::memcpy(l + 1, sel.data(), sizeof(int) * sel.size());
-            for (int nb : sel) {
-                uint64_t key = ((uint64_t)(uint32_t)nb << 8) | (uint64_t)(uint32_t)layer;
+        const int id = first_id + i;
+        for (int layer = std::min(g.level[(size_t)id], top); layer >= 0; --layer) {
+            const std::vector<int> &s = sel[(size_t)i][(size_t)layer];
+            int *l = g.list(id, layer);
+            l[0] = (int)s.size();
+            std::memcpy(l + 1, s.data(), sizeof(int) * s.size());
+            for (int nb : s) {
+                const uint64_t key = ((uint64_t)(uint32_t)nb << 8) | (uint64_t)(uint32_t)layer;
                 auto it = where.find(key);
                 if (it == where.end()) {
-                    where.emplace(key, links.jobs.size());
-                    links.jobs.emplace_back();
-                    LinkJob &lj = links.jobs.back();
-                    lj.g = &graph_;
-                    lj.nb = nb;
-                    lj.layer = layer;
-                    lj.items.push_back(j.id);
+                    where.emplace(key, groups.size());
+                    groups.push_back(LinkGroup{nb, layer, {id}, 0});
                 } else {
-                    links.jobs[it->second].items.push_back(j.id);
+                    groups[it->second].items.push_back(id);
                 }
             }
         }
     }
+}
+} // namespace
+
+bool HnswIndex::link_half_lockstep(int first_id, int n, const Selection &sel, std::string &err)
+{
+    std::vector<LinkGroup> groups;
+    collect_groups(graph_, first_id, n, sel, groups);
+    LinkSource links;
+    links.jobs.resize(groups.size());
+    for (size_t t = 0; t < groups.size(); ++t) {
+        LinkJob &lj = links.jobs[t];
+        lj.g = &graph_;
+        lj.nb = groups[t].nb;
+        lj.layer = groups[t].layer;
+        lj.items = std::move(groups[t].items);
+    }
     if (!links.jobs.empty() && !engine_->run(links, (long long)links.jobs.size())) { err = get_dev_error(); return false; }
     return true;
+}
+
+// Rounds: every group appends until its list overflows (:207-209); all overflowing lists of a
+// round are pruned by ONE kernel launch (PruneOverflow :222-262 incl. sort + heuristic on the
+// device); repeat until every append is done.  Groups are independent lists, so this is the
+// sequential loop's outcome.
+bool HnswIndex::link_half_device(int first_id, int n, const Selection &sel, std::string &err)
+{
+    std::vector<LinkGroup> groups;
+    collect_groups(graph_, first_id, n, sel, groups);
+    const int in_stride = graph_.stride0 + 1, sel_stride = 2 * p_.max_edges;
+    std::vector<int> active((size_t)groups.size()), pending, recs, jme, out_sel, out_cnt;
+    for (size_t t = 0; t < groups.size(); ++t) active[t] = (int)t;
+    std::vector<char> over(groups.size(), 0);
+    while (!active.empty()) {
+        parallel_for((int)active.size(), threads_, [&](int a) {
+            LinkGroup &g = groups[(size_t)active[(size_t)a]];
+            const int maxE = graph_.max_edges_at(g.layer);
+            int *l = graph_.list(g.nb, g.layer);
+            over[(size_t)active[(size_t)a]] = 0;
+            while (g.idx < g.items.size()) {
+                l[1 + l[0]] = g.items[g.idx++]; // :207
+                l[0]++;
+                if (l[0] > maxE) { over[(size_t)active[(size_t)a]] = 1; break; } // :209
+            }
+        });
+        pending.clear();
+        for (int gi : active) if (over[(size_t)gi]) pending.push_back(gi);
+        if (pending.empty()) break;
+        const int np = (int)pending.size();
+        recs.assign((size_t)np * in_stride, 0); jme.resize((size_t)np);
+        out_sel.resize((size_t)np * sel_stride); out_cnt.resize((size_t)np);
+        for (int t = 0; t < np; ++t) {
+            const LinkGroup &g = groups[(size_t)pending[(size_t)t]];
+            const int *l = graph_.list(g.nb, g.layer);
+            int *r = recs.data() + (size_t)t * in_stride;
+            r[0] = g.nb;
+            r[1] = l[0];
+            std::memcpy(r + 2, l + 1, sizeof(int) * (size_t)l[0]);
+            jme[(size_t)t] = graph_.max_edges_at(g.layer);
+        }
+        if (!dev_->prune_batch(recs.data(), np, in_stride, jme.data(), out_sel.data(), sel_stride, out_cnt.data())) { err = get_dev_error(); return false; }
+        for (int t = 0; t < np; ++t) {
+            const LinkGroup &g = groups[(size_t)pending[(size_t)t]];
+            int *l = graph_.list(g.nb, g.layer); // node.OutEdges[layer] = newOut :236
+            l[0] = out_cnt[(size_t)t];
+            std::memcpy(l + 1, out_sel.data() + (size_t)t * sel_stride, sizeof(int) * (size_t)l[0]);
+        }
+        active.swap(pending);
+    }
+    return true;
+}
+
+// One snapshot batch: ids [first_id, first_id + n) are nodes without edges yet.
+bool HnswIndex::insert_batch(int first_id, int n, std::string &err)
+{
+    Selection sel((size_t)n);
+    // tiny batches (the strictly sequential schedule) stay on the lock-step path: a kernel
+    // launch per layer plus a graph upload per item costs more than it saves
+    const bool on_device = p_.device_traversal && n >= 32;
+    if (on_device) {
+        if (!search_half_device(first_id, n, sel, err)) return false;
+    } else {
+        std::vector<int> all((size_t)n);
+        for (int i = 0; i < n; ++i) all[(size_t)i] = i;
+        if (!search_half_lockstep(first_id, all, sel, err)) return false;
+    }
+    graph_dirty_ = true;
+    return on_device ? link_half_device(first_id, n, sel, err) : link_half_lockstep(first_id, n, sel, err);
 }
 
 int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::string &err)
@@ -525,26 +681,6 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
     if (out_ids) for (int i = 0; i < count; ++i) out_ids[i] = ids[(size_t)i];
     return count;
 }
-
-namespace {
-template <class F>
-void parallel_for(int n, int threads, F fn)
-{
-    threads = std::max(1, std::min(threads, n / 64));
-    if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-    std::vector<std::thread> th;
-    std::atomic<int> next{0};
-    for (int t = 0; t < threads; ++t)
-        th.emplace_back([&] {
-            for (;;) {
-                int i0 = next.fetch_add(64, std::memory_order_relaxed);
-                if (i0 >= n) break;
-                for (int i = i0, e = std::min(n, i0 + 64); i < e; ++i) fn(i);
-            }
-        });
-    for (auto &t : th) t.join();
-}
-} // namespace
 
 bool HnswIndex::sync_graph(std::string &err)
 {

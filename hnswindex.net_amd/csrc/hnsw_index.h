@@ -51,6 +51,11 @@ private:
     bool ensure_dim(int dim, std::string &err);
     bool ensure_capacity(long long need, std::string &err);
     bool insert_batch(int first_id, int n, std::string &err);
+    using Selection = std::vector<std::vector<std::vector<int>>>; // [item][layer] -> selected neighbour ids
+    bool search_half_lockstep(int first_id, const std::vector<int> &items, Selection &sel, std::string &err);
+    bool search_half_device(int first_id, int n, Selection &sel, std::string &err);
+    bool link_half_lockstep(int first_id, int n, const Selection &sel, std::string &err);
+    bool link_half_device(int first_id, int n, const Selection &sel, std::string &err);
     bool sync_graph(std::string &err);
     int knn_query_device(const float *queries, int count, int k, int *out_ids, float *out_dists, std::string &err);
     int knn_query_lockstep(const int *which, int count, int k, int *out_ids, float *out_dists, std::string &err);
