@@ -161,9 +161,20 @@ def main():
         kname, t_evals, t_launches, k_ms = "slot_distance_kernel", st["timed_evals"], st["timed_launches"], st["kernel_ms"]
     kernel_s = k_ms / 1e3
     achieved = t_evals * st["row_bytes"] / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    traffic = None
+    try:  # PMC traffic is collected in separate rocprofv3 passes (tools/run_profiles.sh); quote it only
+        # for the very workload it was measured on
+        pm = json.loads((ROOT / "profiles" / "r1_pmc_traffic.json").read_text())
+        w = pm["workload"]
+        if a.traversal == "device" and (w["n"], w["dim"], w["nq"], w["ef_search"], w["k"], w["max_edges"]) == \
+                (a.n, a.dim, a.nq, a.ef_search, a.k, a.max_edges) and a.metric == "sq_euclid":
+            traffic = round(pm["traffic_bytes_per_launch"])
+    except Exception:
+        pass
     roofline = {
         "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+        "algorithmic_bytes_per_launch": round(t_evals / max(1, t_launches) * st["row_bytes"]),
         "bytes_per_eval": st["row_bytes"], "evals_per_launch": round(t_evals / max(1, t_launches), 1),
         "launches": t_launches, "avg_launch_us": round(1e3 * k_ms / max(1, t_launches), 2),
         "kernel_time_share_of_step": round(kernel_s / dt, 4),
@@ -218,7 +229,8 @@ def main():
         },
         "recall_at_10": round(recall, 4),
         "add_per_sec": round(a.n / build_s, 1), "build_seconds": round(build_s, 2),
-        "build_evals": build_stats["evals"], "build_launches": build_stats["launches"],
+        "build_evals": build_stats["evals"] + build_stats["search_evals"],
+        "build_launches": build_stats["launches"] + build_stats["search_launches"],
         "evals_per_query": round((st["search_evals"] + st["evals"]) / (a.nq * a.steps), 1),
         "traversal": a.traversal, "search_overflows": st["search_overflows"],
         "roofline": roofline, "cpu_baseline": cpu,
