@@ -75,6 +75,7 @@ public:
     // --- graph-resident traversal (DESIGN.md "Graph-resident search") ---
     // Mirrors the host adjacency in HBM (layer 0: n x stride0 ints [count, e...]; upper layers:
     // per-node offset into a pool of strideU-int blocks).  Full replace.
+    long long graph_nodes() const { return g_n_; }
     bool set_graph(const int *adj0, long long n, int stride0, const int *level, const int64_t *upper, const int *pool,
                    long long pool_len, int strideU);
     // Runs njobs traversals with beam width k.  out_hits: njobs x k (heap order, as
@@ -86,6 +87,18 @@ public:
     // out_sel: njobs x sel_stride selected ids; out_first: search distance of selected[0].
     bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int *out_sel, int sel_stride,
                              int *out_cnt, float *out_first, int *out_flag);
+    // Keeps the HBM graph mirror in step with nodes appended on the host since the last call:
+    // levels / upper offsets of nodes [first, first+n) and the pool tail [pool_from, pool_len).
+    // Returns false (with no error set) when capacity is exceeded: caller falls back to set_graph.
+    bool graph_append_nodes(long long first, long long n, const int *level, const int64_t *upper, const int *pool,
+                            long long pool_from, long long pool_len, bool *need_full_sync);
+    // Insert, link half, on the HBM graph mirror (one launch):
+    //  rows:   nrows records [node, layer, cnt, ids...] (row_stride ints): OutEdges[layer] = selected
+    //  groups: for group g, node g_node[g] / layer g_layer[g] receives the back-edge appends
+    //          g_items[g_off[g] .. g_off[g+1]) in order, pruning on overflow (PruneOverflow).
+    //  out_lists: ngroups x list_stride ints [cnt, ids...]: the final adjacency list of every group.
+    bool link_batch(const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
+                    const int *g_items, int ngroups, int max_edges0, int *out_lists, int list_stride);
     // PruneOverflow for njobs adjacency lists.  recs: njobs x in_stride ints [node, cnt, ids...];
     // job_max_edges[j] = MaxEdges(layer of job j).  out_sel / out_cnt: the new lists.
     bool prune_batch(const int *recs, int njobs, int in_stride, const int *job_max_edges, int *out_sel, int sel_stride,
@@ -126,6 +139,8 @@ private:
     int *s_sel_ = nullptr, *s_in_ = nullptr, *s_jme_ = nullptr;
     float *s_first_ = nullptr;
     size_t s_sel_cap_ = 0, s_in_cap_ = 0, s_jme_cap_ = 0, s_first_cap_ = 0;
+    int *s_lk_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t s_lk_cap_[5] = {0, 0, 0, 0, 0};
     bool ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_job);
     void *ev0_ = nullptr, *ev1_ = nullptr;
     void *stream_ = nullptr;

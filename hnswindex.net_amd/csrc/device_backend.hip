@@ -712,6 +712,66 @@ graph_prune_kernel(const float *__restrict__ rows, const double *__restrict__ ro
     }
 }
 
+// Insert, link half, on the HBM mirror.  (a) new nodes' own lists.
+__global__ void __launch_bounds__(64)
+graph_write_rows_kernel(int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool,
+                        int strideU, const int *__restrict__ recs, int row_stride)
+{
+    const int *r = recs + (size_t)blockIdx.x * row_stride;
+    const int node = r[0], layer = r[1], cnt = r[2];
+    int *l = layer == 0 ? adj0 + (size_t)node * stride0 : pool + upper[node] + (size_t)(layer - 1) * strideU;
+    if (threadIdx.x == 0) l[0] = cnt;
+    for (int i = threadIdx.x; i < cnt; i += 64) l[1 + i] = r[3 + i];
+}
+
+// (b) one wave per (neighbour, layer) list: every back-edge append of the batch, in item order
+// (neighbor.OutEdges[layer].Add(currNode.Id), GraphConnector.cs:207), each overflow pruned in
+// place (PruneOverflow :222-262: distances :230-234, sort + heuristic :235).  Lists are
+// independent, so the outcome equals the reference's sequential loop.
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, int *__restrict__ adj0,
+                  int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
+                  const int *__restrict__ g_node, const int *__restrict__ g_layer, const int *__restrict__ g_off,
+                  const int *__restrict__ g_items, int max_edges0, int k_cap, int *__restrict__ out_lists, int list_stride,
+                  unsigned long long *__restrict__ eval_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const SearchLds L = carve_lds(smem, k_cap, 0, dim);
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
+    const int node = g_node[g], layer = g_layer[g];
+    const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1);
+    int *l = layer == 0 ? adj0 + (size_t)node * stride0 : pool + upper[node] + (size_t)(layer - 1) * strideU;
+    const float *q = rows + (size_t)node * dim;
+    double sb = 0.0;
+    if (METRIC == M_COS) sb = row_sn[node];
+    for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+    int cnt = l[0];
+    for (int i = lane; i < cnt; i += 64) L.nbuf[i] = l[1 + i];
+    __syncthreads();
+    unsigned long long evals = 0;
+    for (int t = g_off[g]; t < g_off[g + 1]; ++t) {
+        if (lane == 0) L.nbuf[cnt] = g_items[t]; // :207
+        cnt++;
+        __syncthreads();
+        if (cnt > max_edges) { // :209
+            measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, L.nbuf, L.dbuf, cnt, lane); // Distance(cand, node.Id) :233
+            __syncthreads();
+            evals += (unsigned long long)cnt;
+            for (int i = lane; i < cnt; i += 64) L.top[i] = ND{L.nbuf[i], L.dbuf[i]};
+            const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, cnt, max_edges, L, lane, evals);
+            for (int i = lane; i < rc; i += 64) L.nbuf[i] = L.acc[i]; // node.OutEdges[layer] = newOut :236
+            cnt = rc;
+            __syncthreads();
+        }
+    }
+    if (lane == 0) { l[0] = cnt; out_lists[(size_t)g * list_stride] = cnt; }
+    for (int i = lane; i < cnt; i += 64) { l[1 + i] = L.nbuf[i]; out_lists[(size_t)g * list_stride + 1 + i] = L.nbuf[i]; }
+    if (lane == 0) atomicAdd(eval_counter, evals);
+}
+
+
 // Flat id<->id pairs: 8 lanes per pair (hnswdev_dist_pair_batch).
 template <int METRIC>
 __global__ void __launch_bounds__(256)
@@ -801,7 +861,7 @@ Device::~Device()
     if (d_queries_) (void)hipFree(d_queries_);
     if (d_q_sn_) (void)hipFree(d_q_sn_);
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_in_, (void *)s_jme_, (void *)s_first_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_in_, (void *)s_jme_, (void *)s_first_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4]})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -1126,6 +1186,96 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     }
     return true;
 }
+
+bool Device::graph_append_nodes(long long first, long long n, const int *level, const int64_t *upper, const int *pool,
+                                long long pool_from, long long pool_len, bool *need_full_sync)
+{
+    *need_full_sync = false;
+    if (n <= 0) return true;
+    if (!g_adj0_ || first != g_n_ || first + n > g_cap_n_ || pool_len > g_pool_cap_) { *need_full_sync = true; return true; }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    HIP_OK(hipMemcpyAsync(g_level_ + first, level + first, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(g_upper_ + first, upper + first, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    // new nodes start with empty lists (GraphData.NewNode :224-242)
+    HIP_OK(hipMemsetAsync(g_adj0_ + (size_t)first * g_stride0_, 0, sizeof(int) * (size_t)n * g_stride0_, st));
+    if (pool_len > pool_from) HIP_OK(hipMemcpyAsync(g_pool_ + pool_from, pool + pool_from, sizeof(int) * (size_t)(pool_len - pool_from), hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st));
+    g_n_ = first + n;
+    return true;
+}
+
+bool Device::link_batch(const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
+                        const int *g_items, int ngroups, int max_edges0, int *out_lists, int list_stride)
+{
+    if (nrows < 0 || ngroups < 0 || (nrows > 0 && !rows) || (ngroups > 0 && (!g_node || !g_layer || !g_off || !g_items || !out_lists))) {
+        set_dev_error("link_batch: bad argument");
+        return false;
+    }
+    if (g_n_ <= 0) { set_dev_error("link_batch: no graph uploaded"); return false; }
+    // host-side validation: a bad id must be an error return, never a GPU fault
+    for (int r = 0; r < nrows; ++r) {
+        const int *x = rows + (size_t)r * row_stride;
+        bool ok = x[0] >= 0 && x[0] < g_n_ && x[1] >= 0 && x[2] >= 0 && x[2] <= row_stride - 3 &&
+                  x[2] <= (x[1] == 0 ? max_edges0 : max_edges0 / 2);
+        for (int i = 0; ok && i < x[2]; ++i) ok = x[3 + i] >= 0 && x[3 + i] < g_n_;
+        if (!ok) { set_dev_error("link_batch: row record outside the graph"); return false; }
+    }
+    const int total = ngroups > 0 ? g_off[ngroups] : 0;
+    for (int g = 0; g < ngroups; ++g)
+        if (g_node[g] < 0 || g_node[g] >= g_n_ || g_layer[g] < 0 || g_off[g + 1] < g_off[g]) { set_dev_error("link_batch: group outside the graph"); return false; }
+    for (int t = 0; t < total; ++t)
+        if (g_items[t] < 0 || g_items[t] >= g_n_) { set_dev_error("link_batch: item outside the graph"); return false; }
+    if (list_stride < max_edges0 + 1 || max_edges0 + 1 > kNbufCap) { set_dev_error("link_batch: list stride too small"); return false; }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    if (!ensure_search_scratch(1, 0, 4)) return false;
+    const size_t need[5] = {(size_t)nrows * row_stride, (size_t)ngroups * 2, (size_t)ngroups + 1, (size_t)std::max(total, 1), (size_t)ngroups * list_stride};
+    for (int i = 0; i < 5; ++i) if (!grow_dev(&s_lk_[i], &s_lk_cap_[i], std::max<size_t>(need[i], 1))) return false;
+    if (nrows > 0) {
+        HIP_OK(hipMemcpyAsync(s_lk_[0], rows, sizeof(int) * need[0], hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(graph_write_rows_kernel, dim3(nrows), dim3(64), 0, st, g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_lk_[0], row_stride);
+        HIP_OK(hipGetLastError());
+    }
+    if (ngroups > 0) {
+        HIP_OK(hipMemcpyAsync(s_lk_[1], g_node, sizeof(int) * (size_t)ngroups, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(s_lk_[1] + ngroups, g_layer, sizeof(int) * (size_t)ngroups, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(s_lk_[2], g_off, sizeof(int) * ((size_t)ngroups + 1), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(s_lk_[3], g_items, sizeof(int) * (size_t)total, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
+        const bool timed = profiling_;
+        if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
+        const int k_cap = kNbufCap;
+        const size_t lds = search_lds_bytes(k_cap, 0, dim_);
+#define LAUNCH(M)                                                                                                          \
+    hipLaunchKernelGGL(graph_link_kernel<M>, dim3(ngroups), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_,  \
+                       g_upper_, g_pool_, g_strideU_, s_lk_[1], s_lk_[1] + ngroups, s_lk_[2], s_lk_[3], max_edges0, k_cap,    \
+                       s_lk_[4], list_stride, s_evals_)
+        if (metric_ == M_SQ) LAUNCH(M_SQ);
+        else if (metric_ == M_COS) LAUNCH(M_COS);
+        else LAUNCH(M_UCOS);
+#undef LAUNCH
+        HIP_OK(hipGetLastError());
+        if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
+        unsigned long long ev = 0;
+        HIP_OK(hipMemcpyAsync(out_lists, s_lk_[4], sizeof(int) * (size_t)ngroups * list_stride, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(&ev, s_evals_, sizeof(ev), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        stats_.search_launches++;
+        stats_.search_evals += ev;
+        if (timed) {
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
+            stats_.search_kernel_ms += ms;
+            stats_.search_timed_launches++;
+            stats_.search_timed_evals += ev;
+        }
+    } else {
+        HIP_OK(hipStreamSynchronize(st));
+    }
+    return true;
+}
+
 
 bool Device::prune_batch(const int *recs, int njobs, int in_stride, const int *job_max_edges, int *out_sel, int sel_stride, int *out_cnt)
 {

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <limits>
 #include <thread>
@@ -370,7 +371,21 @@ void parallel_for(int n, int threads, F fn)
     for (auto &t : th) t.join();
 }
 
-constexpr int kBatchGrowthDiv = 32; // a snapshot batch never exceeds 1/32 of the linked graph
+constexpr int kBatchGrowthDiv = 32;
+
+// Optional phase timing (HNSW_MI355X_TRACE=1): printed when the index is destroyed.
+struct PhaseTimers {
+    double sync_graph = 0, search_half = 0, collect = 0, link_host = 0, link_dev = 0, post = 0, query_dev = 0, set_queries = 0;
+    long rounds = 0, batches = 0, prune_jobs = 0;
+    bool on = std::getenv("HNSW_MI355X_TRACE") != nullptr;
+};
+PhaseTimers g_pt;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct Tick {
+    double &acc; double t0;
+    explicit Tick(double &a) : acc(a), t0(g_pt.on ? now_s() : 0) {}
+    ~Tick() { if (g_pt.on) acc += now_s() - t0; }
+}; // a snapshot batch never exceeds 1/32 of the linked graph
 
 } // namespace
 
@@ -414,6 +429,9 @@ HnswIndex *HnswIndex::create(int metric, const Params &p, std::string &err)
 
 HnswIndex::~HnswIndex()
 {
+    if (g_pt.on)
+        fprintf(stderr, "[hnsw trace] batches=%ld sync_graph=%.3fs search_half=%.3fs collect=%.3fs link_host=%.3fs link_dev=%.3fs (rounds=%ld prune_jobs=%ld) | query: set_queries=%.3fs dev=%.3fs post=%.3fs\n",
+                g_pt.batches, g_pt.sync_graph, g_pt.search_half, g_pt.collect, g_pt.link_host, g_pt.link_dev, g_pt.rounds, g_pt.prune_jobs, g_pt.set_queries, g_pt.query_dev, g_pt.post);
     engine_.reset(); // before the device it allocates from
     dev_.reset();
 }
@@ -473,7 +491,9 @@ bool HnswIndex::search_half_lockstep(int first_id, const std::vector<int> &items
 // batch; items whose candidate heap outgrew LDS are redone on the lock-step path.
 bool HnswIndex::search_half_device(int first_id, int n, Selection &sel, std::string &err)
 {
-    if (!sync_graph(err)) return false;
+    { Tick t(g_pt.sync_graph); if (!sync_graph(err)) return false; }
+    Tick t_all(g_pt.search_half);
+    g_pt.batches++;
     const int top = graph_.top_layer(), ep = graph_.entry;
     const int sel_stride = 2 * p_.max_edges;
     std::vector<int> l0((size_t)n), next_entry((size_t)n, ep);
@@ -568,54 +588,67 @@ bool HnswIndex::link_half_lockstep(int first_id, int n, const Selection &sel, st
     return true;
 }
 
-// Rounds: every group appends until its list overflows (:207-209); all overflowing lists of a
-// round are pruned by ONE kernel launch (PruneOverflow :222-262 incl. sort + heuristic on the
-// device); repeat until every append is done.  Groups are independent lists, so this is the
-// sequential loop's outcome.
+// The whole link half as ONE launch on the HBM mirror (graph_link_kernel): the host only groups
+// the back-edge appends per (neighbour, layer) list -- array-indexed for layer 0 -- and copies the
+// final lists back into its own graph.  The mirror stays in step, so no re-upload follows.
 bool HnswIndex::link_half_device(int first_id, int n, const Selection &sel, std::string &err)
 {
-    std::vector<LinkGroup> groups;
-    collect_groups(graph_, first_id, n, sel, groups);
-    const int in_stride = graph_.stride0 + 1, sel_stride = 2 * p_.max_edges;
-    std::vector<int> active((size_t)groups.size()), pending, recs, jme, out_sel, out_cnt;
-    for (size_t t = 0; t < groups.size(); ++t) active[t] = (int)t;
-    std::vector<char> over(groups.size(), 0);
-    while (!active.empty()) {
-        parallel_for((int)active.size(), threads_, [&](int a) {
-            LinkGroup &g = groups[(size_t)active[(size_t)a]];
-            const int maxE = graph_.max_edges_at(g.layer);
-            int *l = graph_.list(g.nb, g.layer);
-            over[(size_t)active[(size_t)a]] = 0;
-            while (g.idx < g.items.size()) {
-                l[1 + l[0]] = g.items[g.idx++]; // :207
-                l[0]++;
-                if (l[0] > maxE) { over[(size_t)active[(size_t)a]] = 1; break; } // :209
+    const int M2 = 2 * p_.max_edges, row_stride = 3 + M2, list_stride = graph_.stride0;
+    const int top = graph_.top_layer();
+    std::vector<int> rows, g_node, g_layer, g_cnt;
+    std::vector<std::pair<int, int>> seq; // (group, item id) in append order
+    std::unordered_map<uint64_t, int> upper_groups;
+    {
+        Tick t(g_pt.collect);
+        if ((int)grp_of_node0_.size() < graph_.length) grp_of_node0_.resize((size_t)graph_.length, -1);
+        rows.reserve((size_t)n * row_stride);
+        seq.reserve((size_t)n * M2);
+        for (int i = 0; i < n; ++i) {
+            const int id = first_id + i;
+            for (int layer = std::min(graph_.level[(size_t)id], top); layer >= 0; --layer) {
+                const std::vector<int> &s = sel[(size_t)i][(size_t)layer];
+                int *l = graph_.list(id, layer); // currNode.OutEdges[layer] = selected (:192), host copy
+                l[0] = (int)s.size();
+                std::memcpy(l + 1, s.data(), sizeof(int) * s.size());
+                size_t r0 = rows.size();
+                rows.resize(r0 + (size_t)row_stride, 0);
+                rows[r0] = id; rows[r0 + 1] = layer; rows[r0 + 2] = (int)s.size();
+                std::memcpy(rows.data() + r0 + 3, s.data(), sizeof(int) * s.size());
+                for (int nb : s) {
+                    int gi;
+                    if (layer == 0) {
+                        gi = grp_of_node0_[(size_t)nb];
+                        if (gi < 0) { gi = (int)g_node.size(); grp_of_node0_[(size_t)nb] = gi; g_node.push_back(nb); g_layer.push_back(0); g_cnt.push_back(0); }
+                    } else {
+                        const uint64_t key = ((uint64_t)(uint32_t)nb << 8) | (uint64_t)(uint32_t)layer;
+                        auto it = upper_groups.find(key);
+                        if (it == upper_groups.end()) { gi = (int)g_node.size(); upper_groups.emplace(key, gi); g_node.push_back(nb); g_layer.push_back(layer); g_cnt.push_back(0); }
+                        else gi = it->second;
+                    }
+                    g_cnt[(size_t)gi]++;
+                    seq.emplace_back(gi, id);
+                }
             }
-        });
-        pending.clear();
-        for (int gi : active) if (over[(size_t)gi]) pending.push_back(gi);
-        if (pending.empty()) break;
-        const int np = (int)pending.size();
-        recs.assign((size_t)np * in_stride, 0); jme.resize((size_t)np);
-        out_sel.resize((size_t)np * sel_stride); out_cnt.resize((size_t)np);
-        for (int t = 0; t < np; ++t) {
-            const LinkGroup &g = groups[(size_t)pending[(size_t)t]];
-            const int *l = graph_.list(g.nb, g.layer);
-            int *r = recs.data() + (size_t)t * in_stride;
-            r[0] = g.nb;
-            r[1] = l[0];
-            std::memcpy(r + 2, l + 1, sizeof(int) * (size_t)l[0]);
-            jme[(size_t)t] = graph_.max_edges_at(g.layer);
         }
-        if (!dev_->prune_batch(recs.data(), np, in_stride, jme.data(), out_sel.data(), sel_stride, out_cnt.data())) { err = get_dev_error(); return false; }
-        for (int t = 0; t < np; ++t) {
-            const LinkGroup &g = groups[(size_t)pending[(size_t)t]];
-            int *l = graph_.list(g.nb, g.layer); // node.OutEdges[layer] = newOut :236
-            l[0] = out_cnt[(size_t)t];
-            std::memcpy(l + 1, out_sel.data() + (size_t)t * sel_stride, sizeof(int) * (size_t)l[0]);
-        }
-        active.swap(pending);
+        for (size_t g = 0; g < g_node.size(); ++g) if (g_layer[g] == 0) grp_of_node0_[(size_t)g_node[g]] = -1;
     }
+    const int G = (int)g_node.size();
+    std::vector<int> g_off((size_t)G + 1, 0), g_items(seq.size()), fill((size_t)G, 0);
+    for (int g = 0; g < G; ++g) g_off[(size_t)g + 1] = g_off[(size_t)g] + g_cnt[(size_t)g];
+    for (const auto &pr : seq) g_items[(size_t)(g_off[(size_t)pr.first] + fill[(size_t)pr.first]++)] = pr.second;
+    std::vector<int> out_lists((size_t)G * list_stride);
+    {
+        Tick t(g_pt.link_dev);
+        g_pt.rounds++;
+        if (!dev_->link_batch(rows.data(), (int)(rows.size() / (size_t)row_stride), row_stride, g_node.data(), g_layer.data(), g_off.data(),
+                              g_items.data(), G, M2, out_lists.data(), list_stride)) { err = get_dev_error(); return false; }
+    }
+    Tick t(g_pt.link_host);
+    parallel_for(G, threads_, [&](int g) { // node.OutEdges[layer] as left by the appends / prunes
+        const int *o = out_lists.data() + (size_t)g * list_stride;
+        int *l = graph_.list(g_node[(size_t)g], g_layer[(size_t)g]);
+        std::memcpy(l, o, sizeof(int) * (size_t)(o[0] + 1));
+    });
     return true;
 }
 
@@ -623,18 +656,15 @@ bool HnswIndex::link_half_device(int first_id, int n, const Selection &sel, std:
 bool HnswIndex::insert_batch(int first_id, int n, std::string &err)
 {
     Selection sel((size_t)n);
-    // tiny batches (the strictly sequential schedule) stay on the lock-step path: a kernel
-    // launch per layer plus a graph upload per item costs more than it saves
-    const bool on_device = p_.device_traversal && n >= 32;
-    if (on_device) {
+    if (p_.device_traversal) {
         if (!search_half_device(first_id, n, sel, err)) return false;
-    } else {
-        std::vector<int> all((size_t)n);
-        for (int i = 0; i < n; ++i) all[(size_t)i] = i;
-        if (!search_half_lockstep(first_id, all, sel, err)) return false;
+        return link_half_device(first_id, n, sel, err); // keeps the HBM mirror in step
     }
+    std::vector<int> all((size_t)n);
+    for (int i = 0; i < n; ++i) all[(size_t)i] = i;
+    if (!search_half_lockstep(first_id, all, sel, err)) return false;
     graph_dirty_ = true;
-    return on_device ? link_half_device(first_id, n, sel, err) : link_half_lockstep(first_id, n, sel, err);
+    return link_half_lockstep(first_id, n, sel, err);
 }
 
 int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::string &err)
@@ -652,7 +682,6 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
         ++n_new;
     }
     if (!ensure_capacity(graph_.length, err)) return -1;
-    graph_dirty_ = true;
     // rows -> HBM (id == row index)
     if (n_new == count) {
         if (!dev_->upload_rows(first_new, count, vectors)) { err = get_dev_error(); return -1; }
@@ -684,12 +713,22 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
 
 bool HnswIndex::sync_graph(std::string &err)
 {
-    if (!graph_dirty_) return true;
+    if (!graph_dirty_) { // incremental: nodes appended on the host since the last sync (their lists are empty)
+        bool full = false;
+        // Device tracks how many nodes it mirrors; anything beyond is new
+        if (!dev_->graph_append_nodes(dev_->graph_nodes(), graph_.length - dev_->graph_nodes(), graph_.level.data(), graph_.upper.data(),
+                                      graph_.pool.data(), dev_pool_len_, (long long)graph_.pool.size(), &full)) {
+            err = get_dev_error();
+            return false;
+        }
+        if (!full) { dev_pool_len_ = (long long)graph_.pool.size(); return true; }
+    }
     if (!dev_->set_graph(graph_.adj0.data(), graph_.length, graph_.stride0, graph_.level.data(), graph_.upper.data(),
                          graph_.pool.data(), (long long)graph_.pool.size(), graph_.strideU)) {
         err = get_dev_error();
         return false;
     }
+    dev_pool_len_ = (long long)graph_.pool.size();
     graph_dirty_ = false;
     return true;
 }
@@ -726,7 +765,9 @@ int HnswIndex::knn_query_device(const float *, int count, int k, int *out_ids, f
     for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0};
     std::vector<SearchHit> hits((size_t)count * ef);
     std::vector<int> cnt((size_t)count), flag((size_t)count);
-    if (!dev_->search_batch(jobs.data(), count, ef, hits.data(), cnt.data(), flag.data())) { err = get_dev_error(); return -1; }
+    { Tick t(g_pt.query_dev);
+    if (!dev_->search_batch(jobs.data(), count, ef, hits.data(), cnt.data(), flag.data())) { err = get_dev_error(); return -1; } }
+    Tick t_post(g_pt.post);
     std::vector<int> redo;
     for (int i = 0; i < count; ++i) if (flag[(size_t)i]) redo.push_back(i);
     parallel_for(count, threads_, [&](int i) {
@@ -754,7 +795,7 @@ int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *o
         return 0;
     }
     if (!ensure_dim(dim, err)) return -1;
-    if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; }
+    { Tick t(g_pt.set_queries); if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; } }
     if (p_.device_traversal) return knn_query_device(queries, count, k, out_ids, out_dists, err);
     return knn_query_lockstep(nullptr, count, k, out_ids, out_dists, err);
 }

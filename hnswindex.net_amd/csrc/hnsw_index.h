@@ -73,7 +73,9 @@ private:
     int device_ordinal_ = 0;
     int threads_ = 1;
     bool profiling_ = false;
-    bool graph_dirty_ = true;
+    bool graph_dirty_ = true;       // HBM mirror needs a full re-upload
+    long long dev_pool_len_ = 0;    // pool ints already mirrored
+    std::vector<int> grp_of_node0_; // link half: group index per layer-0 neighbour (-1 = none)
 };
 
 } // namespace hnsw
