@@ -78,10 +78,10 @@ public:
     long long graph_nodes() const { return g_n_; }
     bool set_graph(const int *adj0, long long n, int stride0, const int *level, const int64_t *upper, const int *pool,
                    long long pool_len, int strideU);
-    // Runs njobs traversals with beam width k.  out_hits: njobs x k (heap order, as
-    // BinaryHeap.ToArray()), out_cnt: hits per job, out_flag: 1 where the candidate heap
-    // outgrew its LDS capacity (caller re-runs that job on the lock-step path).  Synchronous.
-    bool search_batch(const SearchJob *jobs, int njobs, int k, SearchHit *out_hits, int *out_cnt, int *out_flag);
+    // Runs njobs KnnQuery traversals with beam width k and returns the first k_out results of
+    // the stable distance order (padded with -1 / NaN); out_flag: 1 where the candidate heap
+    // outgrew LDS + spill capacity (caller re-runs that job on the lock-step path).  Synchronous.
+    bool search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag);
     // Insert, search half, fused on the device: traversal with beam k (= MaxCandidates) followed
     // by RelativeNeighborPruning.  jobs[].qref must be ~item_id.  max_edges0 = MaxEdges(0) = 2M.
     // out_sel: njobs x sel_stride selected ids; out_first: search distance of selected[0].
@@ -139,9 +139,16 @@ private:
     int *s_sel_ = nullptr, *s_in_ = nullptr, *s_jme_ = nullptr;
     float *s_first_ = nullptr;
     size_t s_sel_cap_ = 0, s_in_cap_ = 0, s_jme_cap_ = 0, s_first_cap_ = 0;
+    SearchHit *s_spill_ = nullptr;
+    size_t s_spill_cap_ = 0;
     int *s_lk_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t s_lk_cap_[5] = {0, 0, 0, 0, 0};
     bool ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_job);
+    void *pinned_stage(size_t bytes);
+    void *h_stage_ = nullptr;
+    size_t h_stage_cap_ = 0;
+    bool insert_search_pass(const SearchJob *jobs, int njobs, int k, int cand_cap, int max_edges0, int *out_sel, int sel_stride,
+                            int *out_cnt, float *out_first, int *out_flag);
     void *ev0_ = nullptr, *ev1_ = nullptr;
     void *stream_ = nullptr;
     bool profiling_ = false;

@@ -236,41 +236,56 @@ __device__ __forceinline__ int nd_cmp(ND x, ND y)
     if (x.dist > y.dist) return 1;
     return dev_float_compare_to(x.dist, y.dist);
 }
-template <bool CLOSER>
-__device__ __forceinline__ void heap_push(ND *b, int &count, ND item) // BinaryHeap.cs:30-34, :89-107
+// Heap storage: `top` lives entirely in LDS; `cand` keeps its first `cap` entries in LDS and
+// spills the (rarely reached) deep leaves to a private HBM area, so the LDS footprint -- and
+// with it the number of resident waves -- is set by the common case, not the worst one.
+struct LdsHeap {
+    ND *b;
+    __device__ __forceinline__ ND get(int i) const { return b[i]; }
+    __device__ __forceinline__ void set(int i, ND v) const { b[i] = v; }
+};
+struct SpillHeap {
+    ND *b;
+    int cap;
+    ND *g;
+    __device__ __forceinline__ ND get(int i) const { return i < cap ? b[i] : g[i - cap]; }
+    __device__ __forceinline__ void set(int i, ND v) const { if (i < cap) b[i] = v; else g[i - cap] = v; }
+};
+template <bool CLOSER, class H>
+__device__ __forceinline__ void heap_push(const H &h, int &count, ND item) // BinaryHeap.cs:30-34, :89-107
 {
     int i = count++;
     while (i > 0) {
         int p = (i - 1) >> 1;
-        ND parent = b[p];
+        ND parent = h.get(p);
         if (nd_cmp<CLOSER>(item, parent) <= 0) break;
-        b[i] = parent;
+        h.set(i, parent);
         i = p;
     }
-    b[i] = item;
+    h.set(i, item);
 }
-template <bool CLOSER>
-__device__ __forceinline__ ND heap_pop(ND *b, int &count) // BinaryHeap.cs:53-87
+template <bool CLOSER, class H>
+__device__ __forceinline__ ND heap_pop(const H &h, int &count) // BinaryHeap.cs:53-87
 {
-    ND result = b[0];
+    ND result = h.get(0);
     int n = --count;
-    ND item = b[n];
+    ND item = h.get(n);
     if (n != 0) {
         int i = 0, half = n >> 1;
         while (i < half) {
             int left = (i << 1) + 1, right = left + 1;
-            ND lv = b[left];
+            ND lv = h.get(left);
             int mc = left;
             ND mv = lv;
             if (right < n) {
-                ND rv = b[right];
+                ND rv = h.get(right);
                 if (nd_cmp<CLOSER>(lv, rv) < 0) { mc = right; mv = rv; }
             }
             if (nd_cmp<CLOSER>(mv, item) <= 0) break;
-            b[i] = mv;
+            h.set(i, mv);
             i = mc;
         }
-        b[i] = item;
+        h.set(i, item);
     }
     return result;
 }
@@ -339,6 +354,7 @@ __device__ __forceinline__ void measure_all(const float *rows, const double *row
     }
 }
 
+constexpr int kSpillCap = 8192; // candidate-heap entries per traversal that may spill to HBM
 constexpr int kNbufCap = 136; // >= 2*M + 1 (checked on the host in set_graph)
 
 // LDS carve-up shared by the traversal kernels
@@ -352,9 +368,12 @@ struct SearchLds {
     int *acc;   // kNbufCap: accepted ids of the heuristic
     int *stk;   // 3 * 40: introsort work stack
 };
-__host__ __device__ inline size_t search_lds_bytes(int k, int cand_cap, int dim)
+// heur: also room for the heuristic (second vector, accepted ids, introsort stack)
+__host__ __device__ inline size_t search_lds_bytes(int k, int cand_cap, int dim, bool heur = true)
 {
-    return sizeof(ND) * (size_t)(k + 1 + cand_cap) + 2 * sizeof(float) * (size_t)((dim + 3) & ~3) + 3u * 4u * kNbufCap + 4u * 3u * 40u;
+    size_t b = sizeof(ND) * (size_t)(k + 1 + cand_cap) + sizeof(float) * (size_t)((dim + 3) & ~3) + 2u * 4u * kNbufCap;
+    if (heur) b += sizeof(float) * (size_t)((dim + 3) & ~3) + 4u * kNbufCap + 4u * 3u * 40u;
+    return b;
 }
 __device__ __forceinline__ SearchLds carve_lds(unsigned char *smem, int k, int cand_cap, int dim)
 {
@@ -362,10 +381,11 @@ __device__ __forceinline__ SearchLds carve_lds(unsigned char *smem, int k, int c
     L.top = reinterpret_cast<ND *>(smem);
     L.cand = L.top + (k + 1);
     L.qs = reinterpret_cast<float *>(L.cand + cand_cap);
-    L.qs2 = L.qs + ((dim + 3) & ~3);
-    L.nbuf = reinterpret_cast<int *>(L.qs2 + ((dim + 3) & ~3));
+    L.nbuf = reinterpret_cast<int *>(L.qs + ((dim + 3) & ~3));
     L.dbuf = reinterpret_cast<float *>(L.nbuf + kNbufCap);
-    L.acc = reinterpret_cast<int *>(L.dbuf + kNbufCap);
+    // heuristic-only regions (present when the launch sized LDS with heur = true)
+    L.qs2 = L.dbuf + kNbufCap;
+    L.acc = reinterpret_cast<int *>(L.qs2 + ((dim + 3) & ~3));
     L.stk = L.acc + kNbufCap;
     return L;
 }
@@ -386,10 +406,12 @@ struct GraphView {
 // candidate-heap overflow.  The query must already be staged in L.qs.
 template <int METRIC>
 __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
-                                         const GraphView &G, const SearchJob jb, int k, int cand_cap, unsigned *vis,
-                                         const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals)
+                                         const GraphView &G, const SearchJob jb, int k, int cand_cap, ND *spill, int spill_cap,
+                                         unsigned *vis, const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals)
 {
-    ND *top = L.top, *cand = L.cand;
+    const LdsHeap top{L.top};
+    const SpillHeap cand{L.cand, cand_cap, spill};
+    const int cand_limit = cand_cap + spill_cap;
     int *nbuf = L.nbuf;
     float *dbuf = L.dbuf;
     const float *qs = L.qs;
@@ -458,15 +480,26 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
         measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
         __syncthreads();
         evals += (unsigned long long)m;
-        for (int i = 0; i < m; ++i) {
-            const float d = dbuf[i];
-            if (top_n < k || d < farthest) { // :165
-                ND sel{nbuf[i], d};
-                if (cand_n >= cand_cap) { overflow = true; break; }
-                heap_push<true>(cand, cand_n, sel);               // :168
-                heap_push<false>(top, top_n, sel);                // :171
-                if (top_n > k) (void)heap_pop<false>(top, top_n); // :173-174
-                farthest = top[0].dist;                           // :176-177
+        // Replay of the push loop (:165-178) in adjacency order.  farthest never grows once the
+        // result heap is full, so a candidate that fails `d < farthest` now can never pass later:
+        // only the lanes of the ballot are visited, and the exact test is repeated on each.
+        for (int base = 0; base < m && !overflow; base += 64) {
+            const int i = base + lane;
+            const float my_d = (i < m) ? dbuf[i] : 0.0f;
+            const int my_id = (i < m) ? nbuf[i] : 0;
+            unsigned long long maybe = __ballot(i < m && (top_n < k || my_d < farthest));
+            while (maybe) {
+                const int src = __builtin_ctzll(maybe);
+                maybe &= maybe - 1;
+                const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_d), src));
+                if (top_n < k || d < farthest) { // :165
+                    ND sel{__builtin_amdgcn_readlane(my_id, src), d};
+                    if (cand_n >= cand_limit) { overflow = true; break; }
+                    heap_push<true>(cand, cand_n, sel);               // :168
+                    heap_push<false>(top, top_n, sel);                // :171
+                    if (top_n > k) (void)heap_pop<false>(top, top_n); // :173-174
+                    farthest = top.get(0).dist;                       // :176-177
+                }
             }
         }
         if (overflow) break;
@@ -601,8 +634,9 @@ __global__ void __launch_bounds__(64)
 graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
-                    const SearchJob *__restrict__ jobs, int k, int cand_cap, unsigned *__restrict__ visited,
-                    long long vis_words, ND *__restrict__ out_hits, int *__restrict__ out_cnt, int *__restrict__ out_flag,
+                    const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill, int spill_cap,
+                    unsigned *__restrict__ visited, long long vis_words, int k_out, int *__restrict__ out_ids,
+                    float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
                     unsigned long long *__restrict__ eval_counter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -625,9 +659,42 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
     unsigned long long evals = 0;
     int top_n = 0;
-    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, vis, L, lane, top_n, evals);
-    // ToArray(): the heap's buffer prefix, heap order (BinaryHeap.cs:41-44)
-    for (int i = lane; i < top_n; i += 64) out_hits[(size_t)job * k + i] = L.top[i];
+    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)job * spill_cap, spill_cap, vis, L, lane, top_n, evals);
+    // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(c => c.Dist) is a STABLE sort over the heap
+    // array (ToArray(), BinaryHeap.cs:41-44) and only the first k_out survive -- so select the
+    // k_out smallest (float.CompareTo order: NaN first, -0 == +0) with ties broken by array index:
+    // exactly the stable sort's prefix.  Key = (order-preserving bits << 32) | index, wave min.
+    __syncthreads();
+    unsigned long long used = 0; // bit t: entry lane + 64*t already emitted
+    for (int r = 0; r < k_out; ++r) {
+        unsigned long long best = ~0ull;
+        for (int t = 0, i = lane; i < top_n; ++t, i += 64) {
+            if ((used >> t) & 1ull) continue;
+            float d = L.top[i].dist;
+            unsigned u;
+            if (d != d) u = 0u;                      // NaN sorts first
+            else {
+                if (d == 0.0f) d = 0.0f;             // -0 and +0 compare equal
+                u = __float_as_uint(d);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                if (u == 0u) u = 1u;                 // keep NaN's key unique (only -NaN-like bit patterns reach 0)
+            }
+            unsigned long long key = ((unsigned long long)u << 32) | (unsigned)i;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned long long o = __shfl_xor(best, off, 64);
+            best = o < best ? o : best;
+        }
+        if (best == ~0ull) { // fewer than k_out results: pad (HNSWIndexExports.cs:144)
+            if (lane == 0) { out_ids[(size_t)job * k_out + r] = -1; out_d[(size_t)job * k_out + r] = __uint_as_float(0x7fc00000u); }
+            continue;
+        }
+        const int wi = (int)(best & 0xffffffffu);
+        if ((wi & 63) == lane) used |= 1ull << (wi >> 6);
+        if (lane == 0) { ND w = L.top[wi]; out_ids[(size_t)job * k_out + r] = w.id; out_d[(size_t)job * k_out + r] = w.dist; }
+    }
     if (lane == 0) {
         out_cnt[job] = ok ? top_n : 0;
         out_flag[job] = ok ? 0 : 1;
@@ -643,7 +710,7 @@ __global__ void __launch_bounds__(64)
 graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
-                           int cand_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
+                           int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
                            int *__restrict__ out_sel, int sel_stride, int *__restrict__ out_cnt, float *__restrict__ out_first_dist,
                            int *__restrict__ out_flag, unsigned long long *__restrict__ eval_counter)
 {
@@ -661,7 +728,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
     unsigned long long evals = 0;
     int top_n = 0;
-    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, vis, L, lane, top_n, evals);
+    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)job * spill_cap, spill_cap, vis, L, lane, top_n, evals);
     int rc = 0;
     float first = 0.f;
     if (ok) {
@@ -861,10 +928,11 @@ Device::~Device()
     if (d_queries_) (void)hipFree(d_queries_);
     if (d_q_sn_) (void)hipFree(d_q_sn_);
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_in_, (void *)s_jme_, (void *)s_first_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4]})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_in_, (void *)s_jme_, (void *)s_first_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
+    if (h_stage_) (void)hipHostFree(h_stage_);
 }
 
 bool Device::reserve(long long capacity)
@@ -935,7 +1003,12 @@ bool Device::set_queries(const float *queries, int nq)
     }
     n_queries_ = nq;
     if (nq == 0) return true;
-    HIP_OK(hipMemcpyAsync(d_queries_, queries, (size_t)nq * dim_ * sizeof(float), hipMemcpyHostToDevice, S(stream_)));
+    {
+        const size_t bytes = (size_t)nq * dim_ * sizeof(float);
+        void *hs = bytes <= (256u << 20) ? pinned_stage(bytes) : nullptr;
+        if (hs) { memcpy(hs, queries, bytes); HIP_OK(hipMemcpyAsync(d_queries_, hs, bytes, hipMemcpyHostToDevice, S(stream_))); }
+        else HIP_OK(hipMemcpyAsync(d_queries_, queries, bytes, hipMemcpyHostToDevice, S(stream_)));
+    }
     if (metric_ == M_COS) {
         int blocks = (int)(((long long)nq * 8 + 255) / 256);
         hipLaunchKernelGGL(row_sqrtnorm_kernel, dim3(blocks), dim3(256), 0, S(stream_), d_queries_, dim_, 0LL, nq, d_q_sn_);
@@ -1084,6 +1157,23 @@ bool Device::set_graph(const int *adj0, long long n, int stride0, const int *lev
     return true;
 }
 
+// LDS part of the candidate heap: sized for the common case (4 x beam width; C2 queries peak
+// near 500 entries at ef = 128), the rest spills to HBM (SpillHeap).  A smaller LDS footprint means
+// more resident waves to hide memory latency: 7.6 -> 6.1 ms per 10k-query launch going from 1024
+// to 512 entries.  Beyond LDS + spill capacity the traversal is flagged for the lock-step path.
+static int cand_lds_cap(int k, int dim, bool heur)
+{
+    int cap = std::min(std::max((heur ? 6 : 4) * k, 256), 4096);
+    if (const char *e = std::getenv("HNSW_MI355X_CAND_CAP")) cap = std::max(1, std::atoi(e)); // tests: force spill / hand-back
+    while (cap > 64 && search_lds_bytes(k, cap, dim, heur) > 64 * 1024) cap /= 2;
+    return cap;
+}
+static int spill_cap_for_tests()
+{
+    if (const char *e = std::getenv("HNSW_MI355X_SPILL_CAP")) return std::max(0, std::min(kSpillCap, std::atoi(e)));
+    return kSpillCap;
+}
+
 template <class T>
 static bool grow_dev(T **p, size_t *cap, size_t need)
 {
@@ -1113,6 +1203,7 @@ bool Device::ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_
         HIP_OK(hipMalloc(&s_flag_, sizeof(int) * s_jobs_cap_));
     }
     if (k > 0 && !grow_dev(&s_hits_, &s_hits_cap_, (size_t)chunk * k)) return false;
+    if (!grow_dev(&s_spill_, &s_spill_cap_, (size_t)chunk * kSpillCap)) return false;
     if (!s_evals_) HIP_OK(hipMalloc(&s_evals_, sizeof(unsigned long long)));
     if (!ev0_) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); ev0_ = a; ev1_ = b; }
     return true;
@@ -1129,20 +1220,12 @@ static bool jobs_valid(const SearchJob *jobs, int njobs, long long g_n, long lon
     return true;
 }
 
-bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int *out_sel, int sel_stride,
-                                 int *out_cnt, float *out_first, int *out_flag)
+bool Device::insert_search_pass(const SearchJob *jobs, int njobs, int k, int cand_cap, int max_edges0, int *out_sel, int sel_stride,
+                                int *out_cnt, float *out_first, int *out_flag)
 {
     if (njobs <= 0) return true;
-    if (!jobs || !out_sel || !out_cnt || !out_first || !out_flag || k < 1 || sel_stride < max_edges0) { set_dev_error("insert_search_batch: bad argument"); return false; }
-    if (g_n_ <= 0) { set_dev_error("insert_search_batch: no graph uploaded"); return false; }
-    for (int i = 0; i < njobs; ++i) if (jobs[i].qref >= 0) { set_dev_error("insert_search_batch: qref must name a stored row"); return false; }
-    if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("insert_search_batch: job outside the uploaded graph / rows"); return false; }
     if (!bind()) return false;
     hipStream_t st = S(stream_);
-    int cand_cap = std::min(std::max(8 * k, 1024), 6144);
-    if (const char *e = std::getenv("HNSW_MI355X_CAND_CAP")) cand_cap = std::max(1, std::atoi(e));
-    while (cand_cap > 256 && search_lds_bytes(k, cand_cap, dim_) > 64 * 1024) cand_cap /= 2;
-    if (search_lds_bytes(k, cand_cap, dim_) > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
     const long long vis_words = (g_n_ + 31) / 32;
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
     long long chunk = std::min<long long>(njobs, std::max<long long>(256, (8LL << 30) / (long long)std::max<size_t>(vis_bytes_per_job, 1)));
@@ -1158,7 +1241,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         const size_t lds = search_lds_bytes(k, cand_cap, dim_);
 #define LAUNCH(M)                                                                                                          \
     hipLaunchKernelGGL(graph_insert_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
-                       g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, max_edges0, s_visited_, vis_words, s_sel_, sel_stride, \
+                       g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(), max_edges0, s_visited_, vis_words, s_sel_, sel_stride, \
                        s_cnt_, s_first_, s_flag_, s_evals_)
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
@@ -1182,8 +1265,22 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
             stats_.search_timed_launches++;
             stats_.search_timed_evals += ev;
         }
-        for (int i = 0; i < nj; ++i) stats_.search_overflows += (uint64_t)(out_flag[off + i] != 0);
     }
+    return true;
+}
+
+bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int *out_sel, int sel_stride,
+                                 int *out_cnt, float *out_first, int *out_flag)
+{
+    if (njobs <= 0) return true;
+    if (!jobs || !out_sel || !out_cnt || !out_first || !out_flag || k < 1 || sel_stride < max_edges0) { set_dev_error("insert_search_batch: bad argument"); return false; }
+    if (g_n_ <= 0) { set_dev_error("insert_search_batch: no graph uploaded"); return false; }
+    for (int i = 0; i < njobs; ++i) if (jobs[i].qref >= 0) { set_dev_error("insert_search_batch: qref must name a stored row"); return false; }
+    if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("insert_search_batch: job outside the uploaded graph / rows"); return false; }
+    const int cap = cand_lds_cap(k, dim_, true);
+    if (search_lds_bytes(k, cap, dim_, true) > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
+    if (!insert_search_pass(jobs, njobs, k, cap, max_edges0, out_sel, sel_stride, out_cnt, out_first, out_flag)) return false;
+    for (int i = 0; i < njobs; ++i) stats_.search_overflows += (uint64_t)(out_flag[i] != 0);
     return true;
 }
 
@@ -1321,49 +1418,77 @@ bool Device::prune_batch(const int *recs, int njobs, int in_stride, const int *j
 }
 
 
-bool Device::search_batch(const SearchJob *jobs, int njobs, int k, SearchHit *out_hits, int *out_cnt, int *out_flag)
+// Pinned host staging (grown on demand): DMA to/from pageable user memory runs at ~2 GB/s,
+// through a pinned bounce buffer at PCIe rate.
+void *Device::pinned_stage(size_t bytes)
+{
+    if (bytes <= h_stage_cap_) return h_stage_;
+    if (h_stage_) (void)hipHostFree(h_stage_);
+    h_stage_ = nullptr;
+    h_stage_cap_ = 0;
+    size_t cap = std::max<size_t>(bytes, 1u << 20);
+    if (hipHostMalloc(&h_stage_, cap, hipHostMallocDefault) != hipSuccess) { set_dev_error("pinned staging allocation failed"); return nullptr; }
+    h_stage_cap_ = cap;
+    return h_stage_;
+}
+
+// KnnQuery on the device: descent + layer-0 beam search (width k) + the stable top-k_out tail.
+// out_ids / out_d: njobs x k_out, final (padded with -1 / NaN); out_flag: 1 = not run to
+// completion (candidate heap beyond LDS + spill), caller re-runs that job on the lock-step path.
+bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag)
 {
     if (njobs <= 0) return true;
-    if (!jobs || !out_hits || !out_cnt || !out_flag || k < 1) { set_dev_error("search_batch: bad argument"); return false; }
+    if (!jobs || !out_ids || !out_d || !out_flag || k < 1 || k_out < 1) { set_dev_error("search_batch: bad argument"); return false; }
     if (g_n_ <= 0) { set_dev_error("search_batch: no graph uploaded"); return false; }
+    if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("search_batch: job outside the uploaded graph / rows / queries"); return false; }
+    const int cand_cap = cand_lds_cap(k, dim_, false);
+    const size_t lds = search_lds_bytes(k, cand_cap, dim_, false);
+    if (lds > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
     if (!bind()) return false;
     hipStream_t st = S(stream_);
-    // LDS: top (k+1) + cand heap + query + neighbour/distance scratch
-    int cand_cap = std::min(std::max(8 * k, 1024), 6144);
-    if (const char *e = std::getenv("HNSW_MI355X_CAND_CAP")) cand_cap = std::max(1, std::atoi(e)); // tests: force the overflow hand-back
-    auto lds_bytes = [&](int cc) { return search_lds_bytes(k, cc, dim_); };
-    while (cand_cap > 256 && lds_bytes(cand_cap) > 64 * 1024) cand_cap /= 2;
-    if (lds_bytes(cand_cap) > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
     const long long vis_words = (g_n_ + 31) / 32;
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
     // jobs per launch bounded by an 8 GiB visited arena
     long long chunk = std::min<long long>(njobs, std::max<long long>(256, (8LL << 30) / (long long)std::max<size_t>(vis_bytes_per_job, 1)));
-    if (!ensure_search_scratch(chunk, k, vis_bytes_per_job)) return false;
-    if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("search_batch: job outside the uploaded graph / rows / queries"); return false; }
+    if (!ensure_search_scratch(chunk, k_out, vis_bytes_per_job)) return false;
+    // pinned layout: [evals (16 B) | jobs | ids | dists | flags]
+    const size_t b_jobs = sizeof(SearchJob) * (size_t)chunk, b_res = 4u * (size_t)chunk * k_out;
+    char *hs = static_cast<char *>(pinned_stage(16 + b_jobs + 2 * b_res + 4u * (size_t)chunk));
+    if (!hs) return false;
+    unsigned long long *h_ev = reinterpret_cast<unsigned long long *>(hs);
+    SearchJob *h_jobs = reinterpret_cast<SearchJob *>(hs + 16);
+    int *h_ids = reinterpret_cast<int *>(hs + 16 + b_jobs);
+    float *h_d = reinterpret_cast<float *>(hs + 16 + b_jobs + b_res);
+    int *h_flag = reinterpret_cast<int *>(hs + 16 + b_jobs + 2 * b_res);
+    int *d_ids = reinterpret_cast<int *>(s_hits_);
+    float *d_d = reinterpret_cast<float *>(s_hits_) + (size_t)chunk * k_out;
     for (long long off = 0; off < njobs; off += chunk) {
         const int nj = (int)std::min<long long>(chunk, njobs - off);
-        HIP_OK(hipMemcpyAsync(s_jobs_, jobs + off, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
+        memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
+        HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemsetAsync(s_visited_, 0, vis_bytes_per_job * (size_t)nj, st));
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-        const size_t lds = lds_bytes(cand_cap);
-#define LAUNCH(M)                                                                                                     \
-    hipLaunchKernelGGL(graph_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
-                       g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, s_visited_, vis_words,   \
-                       reinterpret_cast<ND *>(s_hits_), s_cnt_, s_flag_, s_evals_)
+#define LAUNCH(M)                                                                                                          \
+    hipLaunchKernelGGL(graph_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_,     \
+                       g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, reinterpret_cast<ND *>(s_spill_), \
+                       spill_cap_for_tests(), s_visited_, vis_words, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_)
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
         else LAUNCH(M_UCOS);
 #undef LAUNCH
         HIP_OK(hipGetLastError());
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
-        unsigned long long ev = 0;
-        HIP_OK(hipMemcpyAsync(out_hits + (size_t)off * k, s_hits_, sizeof(SearchHit) * (size_t)nj * k, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(out_cnt + off, s_cnt_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(out_flag + off, s_flag_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(&ev, s_evals_, sizeof(ev), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(h_ids, d_ids, 4u * (size_t)nj * k_out, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(h_d, d_d, 4u * (size_t)nj * k_out, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(h_flag, s_flag_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
+        memcpy(out_ids + (size_t)off * k_out, h_ids, 4u * (size_t)nj * k_out);
+        memcpy(out_d + (size_t)off * k_out, h_d, 4u * (size_t)nj * k_out);
+        memcpy(out_flag + off, h_flag, sizeof(int) * (size_t)nj);
+        const unsigned long long ev = *h_ev;
         stats_.search_launches++;
         stats_.search_evals += ev;
         if (timed) {
@@ -1373,8 +1498,8 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, SearchHit *ou
             stats_.search_timed_launches++;
             stats_.search_timed_evals += ev;
         }
-        for (int i = 0; i < nj; ++i) stats_.search_overflows += (uint64_t)(out_flag[off + i] != 0);
     }
+    for (int i = 0; i < njobs; ++i) stats_.search_overflows += (uint64_t)(out_flag[i] != 0);
     return true;
 }
 

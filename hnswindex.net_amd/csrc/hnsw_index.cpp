@@ -755,7 +755,7 @@ int HnswIndex::knn_query_lockstep(const int *which, int count, int k, int *out_i
 }
 
 // Graph-resident traversal: one kernel launch runs every query's FindEntryPointQuery +
-// SearchLayerQuery (HNSWIndex.cs:116-117); the host only orders the returned heap arrays.
+// SearchLayerQuery + stable OrderBy/Take(k) (HNSWIndex.cs:116-123).
 int HnswIndex::knn_query_device(const float *, int count, int k, int *out_ids, float *out_dists, std::string &err)
 {
     if (!sync_graph(err)) return -1;
@@ -763,25 +763,12 @@ int HnswIndex::knn_query_device(const float *, int count, int k, int *out_ids, f
     std::vector<SearchJob> jobs((size_t)count);
     const int ep = graph_.entry, top = graph_.top_layer();
     for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0};
-    std::vector<SearchHit> hits((size_t)count * ef);
-    std::vector<int> cnt((size_t)count), flag((size_t)count);
+    std::vector<int> flag((size_t)count);
     { Tick t(g_pt.query_dev);
-    if (!dev_->search_batch(jobs.data(), count, ef, hits.data(), cnt.data(), flag.data())) { err = get_dev_error(); return -1; } }
+    if (!dev_->search_batch(jobs.data(), count, ef, k, out_ids, out_dists, flag.data())) { err = get_dev_error(); return -1; } }
     Tick t_post(g_pt.post);
     std::vector<int> redo;
     for (int i = 0; i < count; ++i) if (flag[(size_t)i]) redo.push_back(i);
-    parallel_for(count, threads_, [&](int i) {
-        if (flag[(size_t)i]) return;
-        NodeDist *h = reinterpret_cast<NodeDist *>(hits.data() + (size_t)i * ef);
-        const int n = cnt[(size_t)i];
-        // OrderBy(c => c.Dist) (:121) is stable over the heap-order array
-        std::stable_sort(h, h + n, [](const NodeDist &a, const NodeDist &b) { return float_compare_to(a.dist, b.dist) < 0; });
-        const int m = std::min(n, k);
-        int *oi = out_ids + (size_t)i * k;
-        float *od = out_dists + (size_t)i * k;
-        for (int j = 0; j < m; ++j) { oi[j] = h[j].id; od[j] = h[j].dist; }
-        for (int j = m; j < k; ++j) { oi[j] = -1; od[j] = std::numeric_limits<float>::quiet_NaN(); } // Exports.cs:144
-    });
     if (!redo.empty()) // candidate heap outgrew LDS: exact re-run on the lock-step path
         return knn_query_lockstep(redo.data(), (int)redo.size(), k, out_ids, out_dists, err);
     return 0;

@@ -194,18 +194,23 @@ def test_device_and_host_traversal_agree_with_oracle_odd_shapes(Index, dim, metr
         assert (ids == want_ids).all() and d.tobytes() == want_d.tobytes(), traversal
 
 
-def test_candidate_heap_overflow_hands_back_to_lockstep_exactly(Index, monkeypatch):
-    # a tiny LDS candidate heap forces the hand-back path; results must not change
+@pytest.mark.parametrize("spill_cap,expect_handback", [("8", True), ("8192", False)])
+def test_candidate_heap_spill_and_handback_are_exact(Index, monkeypatch, spill_cap, expect_handback):
+    # a tiny LDS candidate heap forces (a) the HBM spill path, (b) with a tiny spill area too,
+    # the hand-back to the lock-step path; results must not change, for queries and for inserts
     x, q = uniform(4000, 64, 91), uniform(256, 64, 92)
     ref = oracle.OracleIndex(64, collection_size=4000, min_nn=64)
     ref.add_batched(x, 512)
     want_ids, want_d = ref.knn_query(q, 10)
     monkeypatch.setenv("HNSW_MI355X_CAND_CAP", "24")
+    monkeypatch.setenv("HNSW_MI355X_SPILL_CAP", spill_cap)
     ix = Index(64); ix.set_collection_size(4000); ix.set_min_nn(64); ix.set_insert_batch(512)
     ix.add(x)
+    assert ix.graph_hash() == ref.graph_hash()
+    ix.reset_stats()
     ids, d = ix.knn_query(q, 10)
     assert (ids == want_ids).all() and d.tobytes() == want_d.tobytes()
-    assert ix.stats()["search_overflows"] > 0
+    assert (ix.stats()["search_overflows"] > 0) == expect_handback
 
 
 def test_search_stats_count_device_evaluations(Index):
