@@ -236,52 +236,93 @@ __device__ __forceinline__ int nd_cmp(ND x, ND y)
     if (x.dist > y.dist) return 1;
     return dev_float_compare_to(x.dist, y.dist);
 }
-// Heap storage: `top` lives entirely in LDS; `cand` keeps its first `cap` entries in LDS and
-// spills the (rarely reached) deep leaves to a private HBM area, so the LDS footprint -- and
-// with it the number of resident waves -- is set by the common case, not the worst one.
+// Heap entries on the device are {id, key}: key = the distance's float bits mapped to an
+// unsigned integer with the same order (sign flip).  For every float except NaN and -0 the
+// integer order IS the float.CompareTo order the reference's comparers use
+// (DistanceComparer.cs:9-25), equal keys <=> equal distances, so every sift decision -- ties
+// included -- is unchanged; a traversal that meets a NaN or -0 distance is flagged and re-run on
+// the host path, where the comparers are restated literally.  Why keys: every value below is
+// wave-uniform; with integer keys pulled through readfirstlane the whole heap logic compiles to
+// SCALAR compares and branches (no exec-mask juggling), ~5x fewer instructions per sift level
+// than float compares on "divergent" VGPRs -- and this serial code, not memory, was the
+// bottleneck of the traversal kernels.
+__device__ __forceinline__ unsigned f2key(float d)
+{
+    unsigned u = __float_as_uint(d);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__device__ __forceinline__ bool key_unsafe(float d) { return d != d || __float_as_uint(d) == 0x80000000u; } // NaN or -0
+
+struct HEnt {
+    int id;
+    unsigned key;
+};
+__device__ __forceinline__ HEnt uniform_ent(unsigned long long v)
+{
+    HEnt e;
+    e.id = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    e.key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return e;
+}
+__device__ __forceinline__ unsigned long long pack_ent(HEnt e) { return (unsigned long long)(unsigned)e.id | ((unsigned long long)e.key << 32); }
+
+// `top` lives entirely in LDS; `cand` keeps its first `cap` entries in LDS and spills the
+// (rarely reached) deep leaves to a private HBM area, so the LDS footprint -- and with it the
+// number of resident waves -- is set by the common case, not the worst one.
 struct LdsHeap {
     ND *b;
-    __device__ __forceinline__ ND get(int i) const { return b[i]; }
-    __device__ __forceinline__ void set(int i, ND v) const { b[i] = v; }
+    __device__ __forceinline__ HEnt get(int i) const { return uniform_ent(*reinterpret_cast<const unsigned long long *>(b + i)); }
+    __device__ __forceinline__ void set(int i, HEnt v) const { *reinterpret_cast<unsigned long long *>(b + i) = pack_ent(v); }
 };
 struct SpillHeap {
     ND *b;
     int cap;
     ND *g;
-    __device__ __forceinline__ ND get(int i) const { return i < cap ? b[i] : g[i - cap]; }
-    __device__ __forceinline__ void set(int i, ND v) const { if (i < cap) b[i] = v; else g[i - cap] = v; }
+    __device__ __forceinline__ HEnt get(int i) const
+    {
+        return uniform_ent(i < cap ? *reinterpret_cast<const unsigned long long *>(b + i) : *reinterpret_cast<const unsigned long long *>(g + (i - cap)));
+    }
+    __device__ __forceinline__ void set(int i, HEnt v) const
+    {
+        if (i < cap) *reinterpret_cast<unsigned long long *>(b + i) = pack_ent(v);
+        else *reinterpret_cast<unsigned long long *>(g + (i - cap)) = pack_ent(v);
+    }
 };
+// comparer outcomes on keys: FartherFirst cmp(x,y) = sign(kx - ky); CloserFirst the reverse
+template <bool CLOSER> __device__ __forceinline__ bool cmp_le0(HEnt x, HEnt y) { return CLOSER ? x.key >= y.key : x.key <= y.key; }
+template <bool CLOSER> __device__ __forceinline__ bool cmp_lt0(HEnt x, HEnt y) { return CLOSER ? x.key > y.key : x.key < y.key; }
+
 template <bool CLOSER, class H>
-__device__ __forceinline__ void heap_push(const H &h, int &count, ND item) // BinaryHeap.cs:30-34, :89-107
+__device__ __forceinline__ void heap_push(const H &h, int &count, HEnt item) // BinaryHeap.cs:30-34, :89-107
 {
     int i = count++;
     while (i > 0) {
         int p = (i - 1) >> 1;
-        ND parent = h.get(p);
-        if (nd_cmp<CLOSER>(item, parent) <= 0) break;
+        HEnt parent = h.get(p);
+        if (cmp_le0<CLOSER>(item, parent)) break;
         h.set(i, parent);
         i = p;
     }
     h.set(i, item);
 }
 template <bool CLOSER, class H>
-__device__ __forceinline__ ND heap_pop(const H &h, int &count) // BinaryHeap.cs:53-87
+__device__ __forceinline__ HEnt heap_pop(const H &h, int &count) // BinaryHeap.cs:53-87
 {
-    ND result = h.get(0);
+    HEnt result = h.get(0);
     int n = --count;
-    ND item = h.get(n);
+    HEnt item = h.get(n);
     if (n != 0) {
         int i = 0, half = n >> 1;
         while (i < half) {
             int left = (i << 1) + 1, right = left + 1;
-            ND lv = h.get(left);
+            HEnt mv = h.get(left);
             int mc = left;
-            ND mv = lv;
             if (right < n) {
-                ND rv = h.get(right);
-                if (nd_cmp<CLOSER>(lv, rv) < 0) { mc = right; mv = rv; }
+                HEnt rv = h.get(right);
+                if (cmp_lt0<CLOSER>(mv, rv)) { mc = right; mv = rv; }
             }
-            if (nd_cmp<CLOSER>(mv, item) <= 0) break;
+            if (cmp_le0<CLOSER>(mv, item)) break;
             h.set(i, mv);
             i = mc;
         }
@@ -445,27 +486,46 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
     // ---- SearchLayer (GraphNavigator.cs:123-189) ----
     const int layer = jb.search_layer;
     int top_n = 0, cand_n = 0;
-    bool overflow = false;
+    bool overflow = false; // also raised for NaN / -0 distances (see f2key)
+    best = __builtin_amdgcn_readfirstlane(best);
+    cur = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cur)));
+    if (key_unsafe(cur)) overflow = true;
     {
-        ND e{best, cur};
+        HEnt e{best, f2key(cur)};
         heap_push<false>(top, top_n, e); // :134
         heap_push<true>(cand, cand_n, e); // :138
         if (lane == 0) atomicOr(&vis[best >> 5], 1u << (best & 31)); // :140
     }
-    float farthest = cur; // :135
-    while (cand_n > 0) {
-        ND c = heap_pop<true>(cand, cand_n);           // :146
-        if (c.dist > farthest && top_n >= k) break;    // :147-150
-        const int *l = G.list(c.id, layer);
-        const int n = l[0];
+    unsigned far_key = f2key(cur); // farthestResultDist :135
+    // Speculative prefetch of the NEXT expansion's out-edge list: while the current candidate
+    // rows are in flight, lanes 0..stride fetch the list of the heap's current root.  If that
+    // node is indeed popped next (it is, unless this expansion pushes something closer) its list
+    // is already in registers and one dependent memory round trip disappears.
+    int pre_id = -1, pre_a = 0, pre_b = 0;
+    const int lstride = layer == 0 ? G.stride0 : G.strideU;
+    while (cand_n > 0 && !overflow) {
+        HEnt c = heap_pop<true>(cand, cand_n);          // :146
+        if (c.key > far_key && top_n >= k) break;       // :147-150
+        int n, nb_a = 0, nb_b = 0; // this lane's neighbour ids (list positions lane and lane + 64)
+        if (c.id == pre_id) {
+            n = __builtin_amdgcn_readlane(pre_a, 0);
+            nb_a = __shfl(pre_a, (lane + 1) & 63, 64);            // list word lane + 1
+            const int w64 = __builtin_amdgcn_readlane(pre_b, 0);  // list word 64
+            if (lane == 63) nb_a = w64;
+            nb_b = __shfl(pre_b, (lane + 1) & 63, 64);            // list word lane + 65
+        } else {
+            const int *l = G.list(c.id, layer);
+            n = __builtin_amdgcn_readfirstlane(l[0]);
+            if (lane < n) nb_a = l[1 + lane];
+            if (lane + 64 < n) nb_b = l[65 + lane];
+        }
         int m = 0;
         __syncthreads();
         for (int base = 0; base < n; base += 64) { // :158-161 keep only unvisited, in list order
             const int i = base + lane;
             bool fresh = false;
-            int nb = 0;
+            const int nb = base == 0 ? nb_a : nb_b;
             if (i < n) {
-                nb = l[1 + i];
                 const unsigned bit = 1u << (nb & 31);
                 const unsigned old = atomicOr(&vis[nb >> 5], bit); // :181 (lists hold no duplicates)
                 fresh = (old & bit) == 0;
@@ -474,6 +534,13 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
             if (fresh) nbuf[m + pos] = nb;
             m += __popcll(mask);
+        }
+        pre_id = -1;
+        if (cand_n > 0) {
+            pre_id = cand.get(0).id;
+            const int *pl = G.list(pre_id, layer);
+            pre_a = lane < lstride ? pl[lane] : 0;
+            pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
         }
         __syncthreads();
         if (m == 0) continue;
@@ -487,23 +554,27 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
             const int i = base + lane;
             const float my_d = (i < m) ? dbuf[i] : 0.0f;
             const int my_id = (i < m) ? nbuf[i] : 0;
-            unsigned long long maybe = __ballot(i < m && (top_n < k || my_d < farthest));
+            const unsigned my_key = f2key(my_d);
+            if (__ballot(i < m && key_unsafe(my_d))) { overflow = true; break; }
+            unsigned long long maybe = __ballot(i < m && (top_n < k || my_key < far_key));
             while (maybe) {
                 const int src = __builtin_ctzll(maybe);
                 maybe &= maybe - 1;
-                const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_d), src));
-                if (top_n < k || d < farthest) { // :165
-                    ND sel{__builtin_amdgcn_readlane(my_id, src), d};
+                const unsigned dk = (unsigned)__builtin_amdgcn_readlane((int)my_key, src);
+                if (top_n < k || dk < far_key) { // :165
+                    HEnt sel{__builtin_amdgcn_readlane(my_id, src), dk};
                     if (cand_n >= cand_limit) { overflow = true; break; }
                     heap_push<true>(cand, cand_n, sel);               // :168
                     heap_push<false>(top, top_n, sel);                // :171
                     if (top_n > k) (void)heap_pop<false>(top, top_n); // :173-174
-                    farthest = top.get(0).dist;                       // :176-177
+                    far_key = top.get(0).key;                         // :176-177
                 }
             }
         }
-        if (overflow) break;
     }
+    // back to float distances for the callers (ToArray(): heap order, BinaryHeap.cs:41-44)
+    __syncthreads();
+    for (int i = lane; i < top_n; i += 64) L.top[i].dist = key2f(__float_as_uint(L.top[i].dist));
     __syncthreads();
     top_n_out = top_n;
     return !overflow;
@@ -1125,7 +1196,7 @@ bool Device::set_graph(const int *adj0, long long n, int stride0, const int *lev
                        long long pool_len, int strideU)
 {
     if (n < 0 || (n > 0 && (!adj0 || !level || !upper))) { set_dev_error("set_graph: bad argument"); return false; }
-    if (stride0 - 1 > kNbufCap || strideU - 1 > kNbufCap) { set_dev_error("set_graph: MaxEdges too large for the search kernel"); return false; }
+    if (stride0 - 1 > 128 || strideU - 1 > 128) { set_dev_error("set_graph: MaxEdges > 63 is not supported by the graph-resident kernels (use hnsw_mi355x_set_device_traversal(0))"); return false; }
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     if (n > g_cap_n_ || stride0 != g_stride0_) {
@@ -1163,7 +1234,7 @@ bool Device::set_graph(const int *adj0, long long n, int stride0, const int *lev
 // to 512 entries.  Beyond LDS + spill capacity the traversal is flagged for the lock-step path.
 static int cand_lds_cap(int k, int dim, bool heur)
 {
-    int cap = std::min(std::max((heur ? 6 : 4) * k, 256), 4096);
+    int cap = std::min(std::max(4 * k, 256), 4096);
     if (const char *e = std::getenv("HNSW_MI355X_CAND_CAP")) cap = std::max(1, std::atoi(e)); // tests: force spill / hand-back
     while (cap > 64 && search_lds_bytes(k, cap, dim, heur) > 64 * 1024) cap /= 2;
     return cap;
