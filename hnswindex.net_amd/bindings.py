@@ -106,6 +106,10 @@ lib.hnswdev_upload_rows.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, _F]
 lib.hnswdev_download_rows.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, _F]
 lib.hnswdev_dist_query_batch.argtypes = [ct.c_void_p, _F, ct.c_int, _I, _I, _F]
 lib.hnswdev_dist_pair_batch.argtypes = [ct.c_void_p, _I, _I, ct.c_int, _F]
+lib.hnswdev_graph_begin.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, _I]
+lib.hnswdev_graph_set_layer.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int]
+lib.hnswdev_graph_commit.argtypes = [ct.c_void_p]
+lib.hnswdev_knn_search.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _I, _F, _I]
 lib.hnswdev_sync.argtypes = [ct.c_void_p]
 lib.hnswdev_set_profiling.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnswdev_get_stats.argtypes = [ct.c_void_p, ct.POINTER(Stats)]
@@ -382,6 +386,26 @@ class DeviceBackend:
         self._check(lib.hnswdev_dist_pair_batch(self._ctx, a.ctypes.data_as(_I), b.ctypes.data_as(_I), a.size,
                                                 out.ctypes.data_as(_F)))
         return out
+
+    def set_graph(self, levels, layers, max_edges: int):
+        """layers: per layer a (counts[n], edges[n, stride]) pair, EdgeList order (as Index.export_edges)."""
+        lv = np.ascontiguousarray(levels, dtype=np.int32)
+        self._check(lib.hnswdev_graph_begin(self._ctx, lv.size, int(max_edges), lv.ctypes.data_as(_I)))
+        for layer, (counts, edges) in enumerate(layers):
+            c = np.ascontiguousarray(counts, dtype=np.int32)
+            e = np.ascontiguousarray(edges, dtype=np.int32)
+            self._check(lib.hnswdev_graph_set_layer(self._ctx, layer, c.ctypes.data_as(_I), e.ctypes.data_as(_I), e.shape[1]))
+        self._check(lib.hnswdev_graph_commit(self._ctx))
+
+    def knn_search(self, queries, entry_point: int, k_beam: int, k_out: int):
+        q = _as_2d_f32(queries, self.dim)
+        n = q.shape[0]
+        ids = np.empty((n, k_out), dtype=np.int32)
+        d = np.empty((n, k_out), dtype=np.float32)
+        flags = np.empty(n, dtype=np.int32)
+        self._check(lib.hnswdev_knn_search(self._ctx, q.ctypes.data_as(_F), n, int(entry_point), int(k_beam), int(k_out),
+                                           ids.ctypes.data_as(_I), d.ctypes.data_as(_F), flags.ctypes.data_as(_I)))
+        return ids, d, flags
 
     def set_profiling(self, on: bool):
         self._check(lib.hnswdev_set_profiling(self._ctx, int(on)))

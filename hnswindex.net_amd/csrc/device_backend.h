@@ -108,6 +108,12 @@ public:
     bool dist_query_batch(const float *queries, int nq, const int *offsets, const int *ids, float *out);
     bool dist_pair_batch(const int *a, const int *b, int n, float *out);
 
+    // C-ABI staging of a host graph given layer by layer (hnswdev_graph_*)
+    bool graph_begin(int n, int max_edges, const int *levels);
+    bool graph_set_layer(int layer, const int *counts, const int *edges, int stride);
+    bool graph_commit();
+    bool knn_search(const float *queries, int nq, int entry_point, int k_beam, int k_out, int *out_ids, float *out_d, int *out_flag);
+
     void set_profiling(bool on) { profiling_ = on; }
     void get_stats(hnswdev_stats *out);
     void reset_stats();
@@ -145,6 +151,8 @@ private:
     size_t s_lk_cap_[5] = {0, 0, 0, 0, 0};
     bool ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_job);
     void *pinned_stage(size_t bytes);
+    struct HostGraphStage;
+    HostGraphStage *hg_ = nullptr;
     void *h_stage_ = nullptr;
     size_t h_stage_cap_ = 0;
     bool insert_search_pass(const SearchJob *jobs, int njobs, int k, int cand_cap, int max_edges0, int *out_sel, int sel_stride,

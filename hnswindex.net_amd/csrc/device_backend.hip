@@ -274,6 +274,14 @@ struct LdsHeap {
     ND *b;
     __device__ __forceinline__ HEnt get(int i) const { return uniform_ent(*reinterpret_cast<const unsigned long long *>(b + i)); }
     __device__ __forceinline__ void set(int i, HEnt v) const { *reinterpret_cast<unsigned long long *>(b + i) = pack_ent(v); }
+    // both children in one LDS round trip (entry i + 1 may be one past the heap: never used then)
+    __device__ __forceinline__ void get2(int i, HEnt &x, HEnt &y) const
+    {
+        const unsigned long long *p = reinterpret_cast<const unsigned long long *>(b + i);
+        const unsigned long long vx = p[0], vy = p[1];
+        x = uniform_ent(vx);
+        y = uniform_ent(vy);
+    }
 };
 struct SpillHeap {
     ND *b;
@@ -287,6 +295,18 @@ struct SpillHeap {
     {
         if (i < cap) *reinterpret_cast<unsigned long long *>(b + i) = pack_ent(v);
         else *reinterpret_cast<unsigned long long *>(g + (i - cap)) = pack_ent(v);
+    }
+    __device__ __forceinline__ void get2(int i, HEnt &x, HEnt &y) const
+    {
+        if (i + 1 < cap) {
+            const unsigned long long *p = reinterpret_cast<const unsigned long long *>(b + i);
+            const unsigned long long vx = p[0], vy = p[1];
+            x = uniform_ent(vx);
+            y = uniform_ent(vy);
+        } else {
+            x = get(i);
+            y = get(i + 1); // i + 1 <= count <= cap + spill_cap - 1: inside the spill area
+        }
     }
 };
 // comparer outcomes on keys: FartherFirst cmp(x,y) = sign(kx - ky); CloserFirst the reverse
@@ -316,12 +336,10 @@ __device__ __forceinline__ HEnt heap_pop(const H &h, int &count) // BinaryHeap.c
         int i = 0, half = n >> 1;
         while (i < half) {
             int left = (i << 1) + 1, right = left + 1;
-            HEnt mv = h.get(left);
+            HEnt mv, rv;
+            h.get2(left, mv, rv);
             int mc = left;
-            if (right < n) {
-                HEnt rv = h.get(right);
-                if (cmp_lt0<CLOSER>(mv, rv)) { mc = right; mv = rv; }
-            }
+            if (right < n && cmp_lt0<CLOSER>(mv, rv)) { mc = right; mv = rv; }
             if (cmp_le0<CLOSER>(mv, item)) break;
             h.set(i, mv);
             i = mc;
@@ -1004,6 +1022,7 @@ Device::~Device()
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
     if (h_stage_) (void)hipHostFree(h_stage_);
+    delete hg_;
 }
 
 bool Device::reserve(long long capacity)
@@ -1274,7 +1293,7 @@ bool Device::ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_
         HIP_OK(hipMalloc(&s_flag_, sizeof(int) * s_jobs_cap_));
     }
     if (k > 0 && !grow_dev(&s_hits_, &s_hits_cap_, (size_t)chunk * k)) return false;
-    if (!grow_dev(&s_spill_, &s_spill_cap_, (size_t)chunk * kSpillCap)) return false;
+    if (!grow_dev(&s_spill_, &s_spill_cap_, (size_t)chunk * kSpillCap + 8)) return false; // +8: get2 may read one entry past a heap
     if (!s_evals_) HIP_OK(hipMalloc(&s_evals_, sizeof(unsigned long long)));
     if (!ev0_) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); ev0_ = a; ev1_ = b; }
     return true;
@@ -1574,6 +1593,74 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     return true;
 }
 
+// ---- C-ABI graph staging (layer by layer) -------------------------------------------------
+struct Device::HostGraphStage {
+    int n = 0, M = 0, stride0 = 0, strideU = 0, top = 0;
+    std::vector<int> level, adj0, pool;
+    std::vector<int64_t> upper;
+};
+
+bool Device::graph_begin(int n, int max_edges, const int *levels)
+{
+    if (n <= 0 || max_edges < 1 || !levels) { set_dev_error("graph_begin: bad argument"); return false; }
+    delete hg_;
+    hg_ = new HostGraphStage();
+    HostGraphStage &g = *hg_;
+    g.n = n; g.M = max_edges; g.stride0 = 2 * max_edges + 2; g.strideU = max_edges + 2;
+    g.level.assign(levels, levels + n);
+    g.adj0.assign((size_t)n * g.stride0, 0);
+    g.upper.assign((size_t)n, -1);
+    size_t pool_len = 0;
+    for (int i = 0; i < n; ++i) {
+        if (levels[i] < 0 || levels[i] > 200) { set_dev_error("graph_begin: level out of range"); return false; }
+        g.top = std::max(g.top, levels[i]);
+        if (levels[i] > 0) { g.upper[(size_t)i] = (int64_t)pool_len; pool_len += (size_t)levels[i] * g.strideU; }
+    }
+    g.pool.assign(pool_len, 0);
+    return true;
+}
+
+bool Device::graph_set_layer(int layer, const int *counts, const int *edges, int stride)
+{
+    if (!hg_) { set_dev_error("graph_set_layer: call hnswdev_graph_begin first"); return false; }
+    HostGraphStage &g = *hg_;
+    if (layer < 0 || !counts || !edges || stride < 1) { set_dev_error("graph_set_layer: bad argument"); return false; }
+    const int cap = layer == 0 ? 2 * g.M + 1 : g.M + 1;
+    for (int i = 0; i < g.n; ++i) {
+        if (g.level[(size_t)i] < layer) continue;
+        const int c = counts[i];
+        if (c < 0 || c > cap || c > stride) { set_dev_error("graph_set_layer: edge count exceeds MaxEdges(layer) + 1"); return false; }
+        int *l = layer == 0 ? g.adj0.data() + (size_t)i * g.stride0 : g.pool.data() + g.upper[(size_t)i] + (size_t)(layer - 1) * g.strideU;
+        l[0] = c;
+        for (int j = 0; j < c; ++j) {
+            const int e = edges[(size_t)i * stride + j];
+            if (e < 0 || e >= g.n || g.level[(size_t)e] < layer) { set_dev_error("graph_set_layer: edge to a node outside the layer"); return false; }
+            l[1 + j] = e;
+        }
+    }
+    return true;
+}
+
+bool Device::graph_commit()
+{
+    if (!hg_) { set_dev_error("graph_commit: nothing staged"); return false; }
+    HostGraphStage &g = *hg_;
+    if (g.n > n_rows_hw_) { set_dev_error("graph_commit: graph has more nodes than uploaded rows"); return false; }
+    return set_graph(g.adj0.data(), g.n, g.stride0, g.level.data(), g.upper.data(), g.pool.data(), (long long)g.pool.size(), g.strideU);
+}
+
+bool Device::knn_search(const float *queries, int nq, int entry_point, int k_beam, int k_out, int *out_ids, float *out_d, int *out_flag)
+{
+    if (nq <= 0) return true;
+    if (!hg_ || g_n_ <= 0) { set_dev_error("knn_search: no graph committed"); return false; }
+    if (entry_point < 0 || entry_point >= hg_->n || k_out < 1 || k_beam < k_out) { set_dev_error("knn_search: bad argument"); return false; }
+    if (!set_queries(queries, nq)) return false;
+    std::vector<SearchJob> jobs((size_t)nq);
+    const int top = hg_->level[(size_t)entry_point];
+    for (int i = 0; i < nq; ++i) jobs[(size_t)i] = SearchJob{i, entry_point, top, 0};
+    return search_batch(jobs.data(), nq, k_beam, k_out, out_ids, out_d, out_flag);
+}
+
 // ---- synchronous conveniences behind the C ABI ---------------------------------------
 bool Device::dist_query_batch(const float *queries, int nq, const int *offsets, const int *ids, float *out)
 {
@@ -1717,6 +1804,14 @@ DEV_API int hnswdev_dist_pair_batch(void *ctx, const int *a_ids, const int *b_id
 {
     CTX_OR_FAIL();
     return d->dist_pair_batch(a_ids, b_ids, n, out) ? 0 : -1;
+}
+DEV_API int hnswdev_graph_begin(void *ctx, int n, int max_edges, const int *levels) { CTX_OR_FAIL(); return d->graph_begin(n, max_edges, levels) ? 0 : -1; }
+DEV_API int hnswdev_graph_set_layer(void *ctx, int layer, const int *counts, const int *edges, int stride) { CTX_OR_FAIL(); return d->graph_set_layer(layer, counts, edges, stride) ? 0 : -1; }
+DEV_API int hnswdev_graph_commit(void *ctx) { CTX_OR_FAIL(); return d->graph_commit() ? 0 : -1; }
+DEV_API int hnswdev_knn_search(void *ctx, const float *queries, int nq, int entry_point, int k_beam, int k_out, int *out_ids, float *out_dists, int *out_flags)
+{
+    CTX_OR_FAIL();
+    return d->knn_search(queries, nq, entry_point, k_beam, k_out, out_ids, out_dists, out_flags) ? 0 : -1;
 }
 DEV_API int hnswdev_sync(void *ctx) { CTX_OR_FAIL(); return d->sync() ? 0 : -1; }
 DEV_API int hnswdev_set_profiling(void *ctx, int enabled) { CTX_OR_FAIL(); d->set_profiling(enabled != 0); return 0; }

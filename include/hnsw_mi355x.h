@@ -90,7 +90,7 @@ int hnsw_set_allow_removals(bool allow_removals);        /* :268 */
  * HNSW_MI355X_DEVICE environment variable, else 0). */
 int hnsw_mi355x_set_device(int device);
 /* Pending: cap on the snapshot batch of hnsw_add (1 = strictly sequential inserts;
- * default 4096).  See DESIGN.md "Add". */
+ * default 16384).  See DESIGN.md "Add". */
 int hnsw_mi355x_set_insert_batch(int max_batch);
 /* Pending: number of concurrent search slots of the lock-step driver (default 16384) and
  * host worker threads (default: min(hardware threads, 16)). */
@@ -165,6 +165,25 @@ int hnswdev_dist_query_batch(void *ctx, const float *queries, int nq, const int 
                              float *out);
 /* Distance(int a, int b): out[j] = metric(row[a_ids[j]], row[b_ids[j]]); synchronous. */
 int hnswdev_dist_pair_batch(void *ctx, const int *a_ids, const int *b_ids, int n, float *out);
+
+/* ---- graph-resident traversal: SearchLayerQuery + FindEntryPointQuery
+ *      (src/HNSWIndex/GraphNavigator.cs:39-82,194-256) for a batch of queries in one launch ---- */
+
+/* Describes the host graph to the context: n nodes, MaxEdges = max_edges, levels[i] = MaxLayer of
+ * node i (Node.cs:27).  Then one hnswdev_graph_set_layer per layer 0..max(levels), then commit. */
+int hnswdev_graph_begin(void *ctx, int n, int max_edges, const int *levels);
+/* counts[i] = OutEdges[layer].Count of node i (ignored where levels[i] < layer);
+ * edges[i*stride .. i*stride+counts[i]) = its ids in EdgeList order (Node.cs:31-107). */
+int hnswdev_graph_set_layer(void *ctx, int layer, const int *counts, const int *edges, int stride);
+/* Uploads the staged graph to HBM (replaces the previous one). */
+int hnswdev_graph_commit(void *ctx);
+/* KnnQuery for nq queries (nq x dim floats) from entry point `entry_point` (GraphData.EntryPoint):
+ * beam width k_beam = max(MinNN, k) (HNSWIndex.cs:115), first k_out results of the stable distance
+ * order (HNSWIndex.cs:121) into out_ids / out_dists (nq x k_out, padded with -1 / NaN).
+ * out_flags[i] = 1: query i met a case the device path hands back (candidate heap beyond its
+ * capacity, NaN or -0 distance) -- evaluate it with hnswdev_dist_query_batch instead. */
+int hnswdev_knn_search(void *ctx, const float *queries, int nq, int entry_point, int k_beam, int k_out, int *out_ids,
+                       float *out_dists, int *out_flags);
 
 int hnswdev_sync(void *ctx);
 int hnswdev_set_profiling(void *ctx, int enabled);

@@ -126,3 +126,35 @@ def test_linearity_style_properties_at_full_row_size(net):
     assert (dev.dist_pair_batch(a, a) == 0).all()
     sample = slice(0, 2000)
     assert ab[sample].tobytes() == oracle.dist_pairs("sq_euclid", rows, a[sample], b[sample]).tobytes()
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_knn_search_on_a_host_supplied_graph(net, metric):
+    # inner boundary, graph-resident form: a host (here: the oracle) owns the graph, hands it over
+    # layer by layer, and gets KnnQuery results identical to its own CPU traversal
+    n, dim, M = 5000, 64, 12
+    x, q = uniform(n, dim, 401), uniform(300, dim, 402)
+    if metric == "ucosine":
+        x, q = normalize_f32(x), normalize_f32(q)
+    ref = oracle.OracleIndex(dim, metric, max_edges=M, max_candidates=80, min_nn=48, collection_size=n)
+    ref.add(x)
+    lv = ref.levels()
+    layers = []
+    for L in range(int(lv.max()) + 1):
+        stride = 2 * M + 2
+        counts = np.full(n, -1, np.int32)
+        edges = np.zeros((n, stride), np.int32)
+        for i in np.nonzero(lv >= L)[0]:
+            e = ref.edges(int(i), L)
+            counts[i] = e.size
+            edges[i, :e.size] = e
+        layers.append((counts, edges))
+    dev = net.DeviceBackend(dim, metric, capacity=n)
+    dev.upload_rows(0, x)
+    dev.set_graph(lv, layers, M)
+    ids, d, flags = dev.knn_search(q, ref.entry_point, 48, 10)
+    want_ids, want_d = ref.knn_query(q, 10)
+    assert (flags == 0).all()
+    assert (ids == want_ids).all() and d.tobytes() == want_d.tobytes()
+    with pytest.raises(RuntimeError, match="bad argument"):
+        dev.knn_search(q, n + 5, 48, 10)

@@ -227,3 +227,35 @@ def test_search_stats_count_device_evaluations(Index):
     # same traversal => same evaluations, except that the oracle re-measures the layer-0 entry
     # point once per query (GraphNavigator.cs:200) and re-measures the start node on each upper layer
     assert abs(s["search_evals"] - ref.n_eval) <= 500 * (1 + ref.levels().max())
+
+
+def test_config_c1_full_size_sequential(Index):
+    # BASELINE.json configs[0]: 10k x 64 f32, sq_euclid, M=16, efConstruction=100, strictly
+    # sequential Add then KnnQuery k=10 (MinNN default 5 => ef = 10), against the oracle
+    n = 10000
+    x, q = uniform(n, 64, 65537), uniform(1000, 64, 65538)
+    ix = Index(64)
+    ix.set_collection_size(n); ix.set_max_edges(16); ix.set_max_candidates(100); ix.set_insert_batch(1)
+    ids = ix.add(x)
+    ref = oracle.OracleIndex(64, max_edges=16, max_candidates=100, collection_size=n)
+    assert (ids == ref.add(x)).all()
+    assert ix.graph_hash() == ref.graph_hash()
+    a_ids, a_d = ix.knn_query(q, 10)
+    b_ids, b_d = ref.knn_query(q, 10)
+    assert (a_ids == b_ids).all() and a_d.tobytes() == b_d.tobytes()
+
+
+def test_config_c3_shape_ucosine_m32_efc400(Index):
+    # BASELINE.json configs[2] at test size: dim 768, unit-normalised rows, ucosine, M=32,
+    # efConstruction=400 (DistributionRate left at 1/ln16), batched Add, ef=128
+    n = 3000
+    x, q = normalize_f32(uniform(n, 768, 65537)), normalize_f32(uniform(200, 768, 65538))
+    ix = Index(768, "ucosine")
+    ix.set_collection_size(n); ix.set_max_edges(32); ix.set_max_candidates(400); ix.set_min_nn(128); ix.set_insert_batch(512)
+    ix.add(x)
+    ref = oracle.OracleIndex(768, "ucosine", max_edges=32, max_candidates=400, min_nn=128, collection_size=n)
+    ref.add_batched(x, 512)
+    assert ix.graph_hash() == ref.graph_hash()
+    a_ids, a_d = ix.knn_query(q, 10)
+    b_ids, b_d = ref.knn_query(q, 10)
+    assert (a_ids == b_ids).all() and a_d.tobytes() == b_d.tobytes()
