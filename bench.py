@@ -83,10 +83,14 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; BENCH_BACKEND=gloo + several ranks on one card is only a rehearsal of
+    # the multi-rank code path on a single-GPU box
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL
+        dist.init_process_group(backend)  # "nccl" is RCCL on ROCm
     import hnswindex
     from hnswindex import Index
     dmod = hnswindex.net_amd.distributed
@@ -104,7 +108,7 @@ def main():
     ix.set_max_candidates(a.ef_construction)
     ix.set_min_nn(a.ef_search)             # ef = max(MinNN, k)  (HNSWIndex.cs:115)
     ix.set_allow_removals(False)           # build-rate runs drop in-edge upkeep
-    ix.set_device(local_rank)
+    ix.set_device(dev_index)
     ix.set_insert_batch(a.insert_batch)
     ix.set_device_traversal(a.traversal == "device")
     if a.slots:
@@ -138,7 +142,7 @@ def main():
     st = ix.stats()
     ix.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
