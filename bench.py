@@ -32,7 +32,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--n", type=int, default=1_000_000, help="indexed vectors (BASELINE C2: 1M)")
+    p.add_argument("--n", "--index-size", dest="n", type=int, default=1_000_000, help="indexed vectors (BASELINE C2: 1M)")
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--metric", default="sq_euclid")
     p.add_argument("--nq", type=int, default=10_000, help="queries per GPU per step")
@@ -40,7 +40,7 @@ def parse():
     p.add_argument("--max-edges", type=int, default=16)
     p.add_argument("--ef-construction", type=int, default=200)
     p.add_argument("--ef-search", type=int, default=128)
-    p.add_argument("--insert-batch", type=int, default=4096)
+    p.add_argument("--insert-batch", type=int, default=16384)
     p.add_argument("--slots", type=int, default=0, help="lock-step search slots (0 = library default)")
     p.add_argument("--threads", type=int, default=0, help="host threads of the driver (0 = library default)")
     p.add_argument("--recall-queries", type=int, default=1000)
