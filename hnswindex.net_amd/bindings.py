@@ -259,7 +259,7 @@ class Index:
         return ids.copy(), dists.copy()
 
     def range_query(self, queries: npt.ArrayLike, radius: float) -> Tuple[List[npt.NDArray[np.int32]], List[npt.NDArray[np.float32]]]:
-        """bindings.py:523-597 (the native call reports NotSupported this round)."""
+        """bindings.py:523-597."""
         q = _as_2d_f32(queries, self.dim)
         n = int(q.shape[0])
         ids_pp = (ct.c_void_p * n)()

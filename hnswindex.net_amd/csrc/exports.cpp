@@ -105,16 +105,36 @@ API int hnsw_knn_query(void *handle, const float *vectors, int count, int dim, i
     return 0;
 }
 
-API int hnsw_range_query(void *handle, const float *, int count, int, float, void **out_ids, void **out_dists, int *counts) // :151-197
+API void hnsw_free_results(void **ids_array, void **dists_array, int count);
+
+API int hnsw_range_query(void *handle, const float *vectors, int count, int dim, float range, void **out_ids, void **out_dists, int *counts) // :151-197
 {
     if (!handle) return 0;
-    for (int i = 0; i < count; ++i) { // the reference's failure path leaves every slot null / 0 (:186-191)
-        if (out_ids) out_ids[i] = nullptr;
-        if (out_dists) out_dists[i] = nullptr;
-        if (counts) counts[i] = 0;
+    if (count <= 0) return 0;
+    if (!vectors || !out_ids || !out_dists || !counts || dim <= 0) { set_error("System.ArgumentNullException: hnsw_range_query"); return -1; }
+    for (int i = 0; i < count; ++i) { out_ids[i] = nullptr; out_dists[i] = nullptr; counts[i] = 0; }
+    std::string err;
+    std::vector<std::vector<hnsw::NodeDist>> res;
+    if (static_cast<HnswIndex *>(handle)->range_query(vectors, count, dim, range, res, err) < 0) { set_error(err); return -1; }
+    for (int i = 0; i < count; ++i) { // callee-allocated per-query arrays (Marshal.AllocHGlobal :172-173), freed by hnsw_free_results
+        const int n = (int)res[(size_t)i].size();
+        if (n > 0) {
+            int *ids = static_cast<int *>(std::malloc(sizeof(int) * (size_t)n));
+            float *ds = static_cast<float *>(std::malloc(sizeof(float) * (size_t)n));
+            if (!ids || !ds) {
+                std::free(ids); std::free(ds);
+                hnsw_free_results(out_ids, out_dists, count);
+                for (int j = 0; j < count; ++j) counts[j] = 0;
+                set_error("System.OutOfMemoryException: hnsw_range_query");
+                return -1;
+            }
+            for (int j = 0; j < n; ++j) { ids[j] = res[(size_t)i][(size_t)j].id; ds[j] = res[(size_t)i][(size_t)j].dist; }
+            out_ids[i] = ids;
+            out_dists[i] = ds;
+        }
+        counts[i] = n;
     }
-    set_error("System.NotSupportedException: hnsw_range_query is outside the accelerated Add/KnnQuery path of this backend (SURVEY.md 8f rank 3)");
-    return -1;
+    return 0;
 }
 
 API void hnsw_free_results(void **ids_array, void **dists_array, int count) // :199-217

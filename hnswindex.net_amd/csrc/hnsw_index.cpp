@@ -220,6 +220,87 @@ struct QuerySource : JobSource {
 };
 
 // ------------------------------------------------------------------------------------
+// RangeQuery job: HNSWIndex.RangeQuery (src/HNSWIndex/HNSWIndex.cs:144-156) =
+// FindEntryPointQuery + GraphNavigator.SearchLayerRange (GraphNavigator.cs:262-325), no filter.
+// ------------------------------------------------------------------------------------
+struct RangeJob : Job {
+    const Graph *g;
+    int capacity, qi;
+    float range, farthest;
+    std::vector<NodeDist> *out;
+    Descent desc;
+    int stage = 0;
+
+    void begin_search(SlotScratch &sc)
+    {
+        const int maxE = g->max_edges_at(0);
+        sc.top.reset(maxE);      // :265
+        sc.cand.reset(maxE * 2); // :266
+        NodeDist e{desc.best, desc.cur}; // :268 (entry distance reused, same bits)
+        farthest = std::numeric_limits<float>::max(); // TDistance.MaxValue :269
+        if (e.dist <= range) { sc.top.push(e); farthest = e.dist; } // :271-275
+        sc.cand.push(e);         // :277
+        sc.visited.begin(capacity);
+        sc.visited.test_and_set(e.id); // :279
+    }
+    bool prepare(SlotIO &io, SlotScratch &sc) override
+    {
+        *io.qidx = qi;
+        if (stage == 0) {
+            if (desc.prepare(io)) return true;
+            begin_search(sc);
+            stage = 1;
+        }
+        while (sc.cand.count > 0) {
+            const NodeDist closest = sc.cand.peek();                             // :285
+            if (closest.dist > farthest && closest.dist > range) return false;  // :286-289
+            sc.cand.pop();                                                       // :290
+            const int *l = g->list(closest.id, 0);
+            int n = 0;
+            for (int i = 1; i <= l[0]; ++i)
+                if (!sc.visited.test_and_set(l[i])) io.ids[n++] = l[i];          // :297 / :318
+            if (n > 0) { *io.cnt = n; return true; }
+        }
+        return false;
+    }
+    void consume(const SlotIO &io, SlotScratch &sc) override
+    {
+        if (stage == 0) { desc.consume(io); return; }
+        const int n = *io.cnt;
+        for (int i = 0; i < n; ++i) {
+            const float d = io.dist[i];
+            if (d <= range) { // :302
+                NodeDist sel{io.ids[i], d};
+                sc.cand.push(sel);                                   // :305
+                sc.top.push(sel);                                    // :308
+                if (sc.top.peek().dist > range) sc.top.pop();        // :310-311
+                if (sc.top.count > 0) farthest = sc.top.peek().dist; // :313-314
+            }
+        }
+    }
+    void finish(SlotScratch &sc)
+    {
+        out->assign(sc.top.buf.begin(), sc.top.buf.begin() + sc.top.count);
+        std::stable_sort(out->begin(), out->end(), [](const NodeDist &a, const NodeDist &b) { return float_compare_to(a.dist, b.dist) < 0; }); // OrderBy :155
+    }
+};
+
+struct RangeSource : JobSource {
+    std::vector<RangeJob> jobs;
+    std::atomic<int> next{0};
+    Job *acquire(SlotScratch &) override
+    {
+        int i = next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= (int)jobs.size()) return nullptr;
+        RangeJob &j = jobs[(size_t)i];
+        j.desc.begin(j.g, j.g->entry, 0);
+        j.stage = 0;
+        return &j;
+    }
+    void release(Job *job, SlotScratch &sc) override { static_cast<RangeJob *>(job)->finish(sc); }
+};
+
+// ------------------------------------------------------------------------------------
 // Insert, search half: GraphConnector.AddNewConnections (src/HNSWIndex/GraphConnector.cs:172-181)
 // with ConnectAtLayer's search + heuristic (:189-190) for every layer of the new node,
 // against the graph as it stands at the start of the batch.
@@ -785,6 +866,26 @@ int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *o
     { Tick t(g_pt.set_queries); if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; } }
     if (p_.device_traversal) return knn_query_device(queries, count, k, out_ids, out_dists, err);
     return knn_query_lockstep(nullptr, count, k, out_ids, out_dists, err);
+}
+
+int HnswIndex::range_query(const float *queries, int count, int dim, float range, std::vector<std::vector<NodeDist>> &out, std::string &err)
+{
+    out.assign((size_t)std::max(count, 0), {});
+    if (count <= 0 || graph_.entry < 0) return 0; // HNSWIndex.cs:146
+    if (!ensure_dim(dim, err)) return -1;
+    if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; }
+    RangeSource src;
+    src.jobs.resize((size_t)count);
+    for (int i = 0; i < count; ++i) {
+        RangeJob &j = src.jobs[(size_t)i];
+        j.g = &graph_;
+        j.capacity = (int)capacity_;
+        j.qi = i;
+        j.range = range;
+        j.out = &out[(size_t)i];
+    }
+    if (!engine_->run(src, count)) { err = get_dev_error(); return -1; }
+    return 0;
 }
 
 uint64_t HnswIndex::graph_hash() const

@@ -40,6 +40,10 @@ public:
     // hnsw_knn_query: 0 or -1.
     int knn_query(const float *queries, int count, int dim, int k, int *out_ids, float *out_dists, std::string &err);
 
+    // hnsw_range_query (HNSWIndex.RangeQuery, src/HNSWIndex/HNSWIndex.cs:144-168): per query the
+    // in-range results ordered by distance.  Host lock-step traversal.
+    int range_query(const float *queries, int count, int dim, float range, std::vector<std::vector<NodeDist>> &out, std::string &err);
+
     int count() const { return graph_.length; }
     const Graph &graph() const { return graph_; }
     Device *device() { return dev_.get(); }

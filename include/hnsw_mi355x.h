@@ -66,7 +66,9 @@ int hnsw_remove(void *handle, const int *ids, int count);
  * (:144).  Returns 0 on success (and for a null handle), -1 on error. */
 int hnsw_knn_query(void *handle, const float *vectors, int count, int dim, int k, int *out_ids, float *out_dists);
 
-/* :151-197  RangeQuery.  SURVEY.md 8f "next": returns -1 and sets the last error. */
+/* :151-197  RangeQuery -> BatchRangeQuery (HNSWIndex.cs:144-168).  For query i, out_ids[i] /
+ * out_dists[i] receive callee-allocated arrays of counts[i] results ordered by distance (null when
+ * counts[i] == 0); release them with hnsw_free_results.  Returns 0, or -1 on error. */
 int hnsw_range_query(void *handle, const float *vectors, int count, int dim, float range, void **out_ids,
                      void **out_dists, int *counts);
 

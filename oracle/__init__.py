@@ -46,6 +46,7 @@ def lib():
         L.orc_add_batched.argtypes = [ct.c_void_p, _F, ct.c_int, _I, ct.c_int]
         L.orc_import_nodes.argtypes = [ct.c_void_p, _F, _I, ct.c_int, ct.c_int]
         L.orc_import_edges.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int, ct.c_int]
+        L.orc_range_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_float, ct.c_int, _I, _I, _F]
         L.orc_knn_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, _I, _F, ct.c_int]
         for name in ("orc_count", "orc_entry_point", "orc_capacity"):
             getattr(L, name).argtypes = [ct.c_void_p]
@@ -210,6 +211,18 @@ class OracleIndex:
         d = np.empty((n, k), dtype=np.float32)
         lib().orc_knn_query(self._h, _pf(q), n, k, _pi(ids), _pf(d), threads)
         return ids, d
+
+    def range_query(self, queries, radius, cap=None):
+        """HNSWIndex.RangeQuery per query: (list of id arrays, list of distance arrays)."""
+        q = _f32(queries).reshape(-1, self.dim)
+        n = q.shape[0]
+        cap = cap or max(1, self.count)
+        cnt = np.empty(n, dtype=np.int32)
+        ids = np.empty((n, cap), dtype=np.int32)
+        d = np.empty((n, cap), dtype=np.float32)
+        if lib().orc_range_query(self._h, _pf(q), n, float(radius), cap, _pi(cnt), _pi(ids), _pf(d)) != 0:
+            raise RuntimeError("orc_range_query: cap too small")
+        return [ids[i, :cnt[i]].copy() for i in range(n)], [d[i, :cnt[i]].copy() for i in range(n)]
 
     @property
     def count(self):

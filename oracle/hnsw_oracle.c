@@ -625,6 +625,44 @@ static int search_layer(sctx_t *c, int entry_id, int layer, int k, const float *
     return n;
 }
 
+/* GraphNavigator.SearchLayerRange (src/HNSWIndex/GraphNavigator.cs:262-325), no filter. */
+static int search_layer_range(sctx_t *c, int entry_id, int layer, float range, const float *q, nd_t **out)
+{
+    index_t *ix = c->ix;
+    heap_t top, cand;
+    heap_init(&top, max_edges_at(ix, layer), 0);      /* :265 */
+    heap_init(&cand, max_edges_at(ix, layer) * 2, 1); /* :266 */
+    nd_t entry = {entry_id, dist_iq(c, entry_id, q)}; /* :268 */
+    float farthest = 3.402823466e+38f;                /* TDistance.MaxValue :269 */
+    if (entry.dist <= range) { heap_push(&top, entry); farthest = entry.dist; } /* :271-275 */
+    heap_push(&cand, entry);                          /* :277 */
+    visited_next(c->vis, ix->capacity);
+    visited_add(c->vis, entry_id);                    /* :279 */
+    while (cand.count > 0) {
+        nd_t closest = cand.buf[0];                                   /* Peek :285 */
+        if (closest.dist > farthest && closest.dist > range) break;  /* :286-289 */
+        heap_pop(&cand);                                              /* :290 */
+        const edges_t *e = &ix->nodes[closest.id].out[layer];
+        for (int i = 0; i < e->count; ++i) {
+            int nb = e->buf[i];
+            if (visited_has(c->vis, nb)) continue;   /* :297 */
+            float d = dist_iq(c, nb, q);             /* :299 */
+            if (d <= range) {                        /* :302 */
+                nd_t sel = {nb, d};
+                heap_push(&cand, sel);               /* :305 */
+                heap_push(&top, sel);                /* :308 */
+                if (top.buf[0].dist > range) heap_pop(&top);       /* :310-311 */
+                if (top.count > 0) farthest = top.buf[0].dist;     /* :313-314 */
+            }
+            visited_add(c->vis, nb);                 /* :318 */
+        }
+    }
+    int n = top.count;
+    *out = top.buf;
+    heap_free(&cand);
+    return n;
+}
+
 /* src/HNSWIndex/Heuristic.cs:11-46.  `cands` is sorted in place (as the reference's span). */
 static edges_t relative_neighbor_pruning(sctx_t *c, nd_t *cands, int n, int max_edges)
 {
@@ -989,6 +1027,36 @@ ORC_API int orc_knn_query(void *h, const float *q, int n, int k, int *out_ids, f
         pthread_join(th[t], NULL);
         ix->n_eval += jobs[t].n_eval;
     }
+    return 0;
+}
+
+/* HNSWIndex.RangeQuery (src/HNSWIndex/HNSWIndex.cs:144-156): results of query i are written to
+ * out_ids/out_d starting at out_off[i] (caller sizes the buffers with cap per query); returns
+ * the total or -1 if cap is too small. */
+ORC_API int orc_range_query(void *h, const float *q, int n, float range, int cap, int *out_cnt, int *out_ids, float *out_d)
+{
+    index_t *ix = (index_t *)h;
+    if (!ix) return -1;
+    sctx_t c = {ix, &ix->vis, 0};
+    for (int i = 0; i < n; i++) {
+        out_cnt[i] = 0;
+        if (ix->count <= 0) continue;
+        const float *qi = q + (size_t)i * (size_t)ix->dim;
+        int ep = find_entry_point(&c, 0, qi);
+        nd_t *res;
+        int m = search_layer_range(&c, ep, 0, range, qi, &res);
+        for (int a = 1; a < m; a++) { /* OrderBy(c => c.Dist): stable */
+            nd_t t = res[a];
+            int j = a - 1;
+            while (j >= 0 && float_compare_to(t.dist, res[j].dist) < 0) { res[j + 1] = res[j]; j--; }
+            res[j + 1] = t;
+        }
+        if (m > cap) { free(res); return -1; }
+        for (int a = 0; a < m; a++) { out_ids[(size_t)i * cap + a] = res[a].id; out_d[(size_t)i * cap + a] = res[a].dist; }
+        out_cnt[i] = m;
+        free(res);
+    }
+    ix->n_eval += c.n_eval;
     return 0;
 }
 

@@ -158,8 +158,6 @@ def test_edge_cases_and_errors(Index):
     assert "dimension mismatch" in hnswindex.net_amd.last_error()
     with pytest.raises(RuntimeError, match="NotSupported"):
         ix.remove([0])
-    with pytest.raises(RuntimeError, match="NotSupported"):
-        ix.range_query(uniform(1, 16, 4), 1.0)
 
 
 def test_stats_count_every_evaluation_and_profiling_times_kernels(Index):
@@ -259,3 +257,23 @@ def test_config_c3_shape_ucosine_m32_efc400(Index):
     a_ids, a_d = ix.knn_query(q, 10)
     b_ids, b_d = ref.knn_query(q, 10)
     assert (a_ids == b_ids).all() and a_d.tobytes() == b_d.tobytes()
+
+
+@pytest.mark.parametrize("metric,radius", [("sq_euclid", 16.0), ("cosine", 0.2), ("ucosine", 0.2)])
+def test_range_query_matches_oracle(Index, metric, radius):
+    # bindings/__tests__/recall_test.py:49-58, GraphTests.cs:227-244: every result within the radius;
+    # and, against the oracle's SearchLayerRange restatement, the same ids / distance bits
+    n, dim = 2000, 128
+    x = uniform(n, dim, 111)
+    if metric == "ucosine":
+        x = normalize_f32(x)
+    ix = Index(dim, metric); ix.set_collection_size(100); ix.set_insert_batch(256)
+    ix.add(x)
+    ref = oracle.OracleIndex(dim, metric, collection_size=100); ref.add_batched(x, 256)
+    assert ix.graph_hash() == ref.graph_hash()
+    ids, dists = ix.range_query(x[:300], radius)
+    rids, rdists = ref.range_query(x[:300], radius)
+    assert sum(len(a) for a in ids) > 300
+    for a, b, c, d in zip(ids, dists, rids, rdists):
+        assert (b <= radius).all()
+        assert a.tolist() == c.tolist() and b.tobytes() == d.tobytes()

@@ -156,3 +156,14 @@ def test_empty_and_small_edge_cases():
     ids, d = ix.knn_query(uniform(3, 16, 1), 4)
     assert ((ids[:, :2] >= 0).all()) and (ids[:, 2:] == -1).all() and np.isnan(d[:, 2:]).all()
     assert (np.diff(d[:, :2], axis=1) >= 0).all()
+
+
+def test_range_query_results_within_radius_and_sorted():
+    # bindings/__tests__/recall_test.py:49-58; src/HNSWIndex.Tests/GraphTests.cs:227-244
+    x = uniform(2000, 128, 6)
+    ix = oracle.OracleIndex(128, collection_size=100)
+    ix.add(x)
+    ids, d = ix.range_query(x[:200], 16.0)
+    assert sum(len(a) for a in ids) > 200
+    for a, b in zip(ids, d):
+        assert (b <= 16.0).all() and (np.diff(b) >= 0).all() and len(set(a.tolist())) == len(a)
