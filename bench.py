@@ -219,12 +219,14 @@ def main():
         }
 
     qps = nq_total * a.steps / dt
+    shape = (a.dim, a.metric, a.max_edges, a.ef_construction)
+    cfg_name = {(128, "sq_euclid", 16, 200): "C2" if a.n <= 1_000_000 else "C4-size", (768, "ucosine", 32, 400): "C3"}.get(shape, "custom")
     out = {
         "metric": "knn_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"C2: {a.n}x{a.dim} f32 {a.metric}, M={a.max_edges} efConstruction={a.ef_construction} "
+            "workload": f"{cfg_name}: {a.n}x{a.dim} f32 {a.metric}, M={a.max_edges} efConstruction={a.ef_construction} "
                         f"efSearch={a.ef_search} k={a.k}; step = batched knn_query of {a.nq} queries per GPU "
                         f"(query set sharded over ranks, one all-gather of top-k)",
             "n": a.n, "dim": a.dim, "queries_per_gpu_per_step": a.nq, "k": a.k, "max_edges": a.max_edges,

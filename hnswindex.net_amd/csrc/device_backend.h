@@ -76,6 +76,9 @@ public:
     // Mirrors the host adjacency in HBM (layer 0: n x stride0 ints [count, e...]; upper layers:
     // per-node offset into a pool of strideU-int blocks).  Full replace.
     long long graph_nodes() const { return g_n_; }
+    // Can the graph-resident kernels run this shape?  (LDS budget for beam width k at this dim;
+    // MaxEdges <= 63.)  When not, callers use the host lock-step traversal instead.
+    bool traversal_fits(int k, bool with_heuristic, int max_edges) const;
     bool set_graph(const int *adj0, long long n, int stride0, const int *level, const int64_t *upper, const int *pool,
                    long long pool_len, int strideU);
     // Runs njobs KnnQuery traversals with beam width k and returns the first k_out results of

@@ -706,12 +706,20 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
         double sbc = 0.0;
         if (METRIC == M_COS) sbc = row_sn[c.id];
         __syncthreads();
-        measure_all<METRIC>(rows, row_sn, dim, L.qs2, sbc, acc, L.dbuf, rc, lane); // distanceFnc(s.Id, candidateId) :34
-        __syncthreads();
-        evals += (unsigned long long)rc;
+        // accepted ids are measured in chunks, in acceptance order, stopping at the first chunk
+        // that rejects (the reference breaks at the first hit, :34; later pairs cannot change the
+        // outcome) -- with long rows this saves most of the traffic of rejected candidates
+        const int chunk = dim >= 512 ? 16 : 32;
         bool ok = true;
-        for (int j = 0; j < rc; ++j)
-            if (L.dbuf[j] < c.dist) { ok = false; break; }
+        for (int a0 = 0; a0 < rc && ok; a0 += chunk) {
+            const int an = min(chunk, rc - a0);
+            measure_all<METRIC>(rows, row_sn, dim, L.qs2, sbc, acc + a0, L.dbuf, an, lane); // distanceFnc(s.Id, candidateId) :34
+            __syncthreads();
+            evals += (unsigned long long)an;
+            const float dj = lane < an ? L.dbuf[lane] : 0.0f;
+            ok = __ballot(lane < an && dj < c.dist) == 0ull;
+            __syncthreads();
+        }
         if (ok) { if (lane == 0) acc[rc] = c.id; rc++; }
         __syncthreads();
     }
@@ -1372,6 +1380,13 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     if (!insert_search_pass(jobs, njobs, k, cap, max_edges0, out_sel, sel_stride, out_cnt, out_first, out_flag)) return false;
     for (int i = 0; i < njobs; ++i) stats_.search_overflows += (uint64_t)(out_flag[i] != 0);
     return true;
+}
+
+bool Device::traversal_fits(int k, bool with_heuristic, int max_edges) const
+{
+    if (k < 1 || 2 * max_edges + 1 > 128) return false;
+    const int cap = cand_lds_cap(k, dim_, with_heuristic);
+    return search_lds_bytes(k, cap, dim_, with_heuristic) <= 64 * 1024 && search_lds_bytes(kNbufCap, 0, dim_, true) <= 64 * 1024;
 }
 
 bool Device::graph_append_nodes(long long first, long long n, const int *level, const int64_t *upper, const int *pool,

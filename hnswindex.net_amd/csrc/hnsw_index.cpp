@@ -737,7 +737,7 @@ bool HnswIndex::link_half_device(int first_id, int n, const Selection &sel, std:
 bool HnswIndex::insert_batch(int first_id, int n, std::string &err)
 {
     Selection sel((size_t)n);
-    if (p_.device_traversal) {
+    if (p_.device_traversal && dev_->traversal_fits(p_.max_candidates, true, p_.max_edges)) {
         if (!search_half_device(first_id, n, sel, err)) return false;
         return link_half_device(first_id, n, sel, err); // keeps the HBM mirror in step
     }
@@ -864,7 +864,8 @@ int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *o
     }
     if (!ensure_dim(dim, err)) return -1;
     { Tick t(g_pt.set_queries); if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; } }
-    if (p_.device_traversal) return knn_query_device(queries, count, k, out_ids, out_dists, err);
+    if (p_.device_traversal && dev_->traversal_fits(std::max(p_.min_nn, k), false, p_.max_edges))
+        return knn_query_device(queries, count, k, out_ids, out_dists, err);
     return knn_query_lockstep(nullptr, count, k, out_ids, out_dists, err);
 }
 

@@ -277,3 +277,20 @@ def test_range_query_matches_oracle(Index, metric, radius):
     for a, b, c, d in zip(ids, dists, rids, rdists):
         assert (b <= radius).all()
         assert a.tolist() == c.tolist() and b.tobytes() == d.tobytes()
+
+
+def test_shapes_beyond_the_device_kernels_fall_back_to_host_traversal(Index):
+    # MaxEdges > 63 and beam widths beyond the LDS budget are served by the lock-step path --
+    # same results, no error
+    x, q = uniform(1500, 32, 131), uniform(64, 32, 132)
+    ref = oracle.OracleIndex(32, max_edges=70, max_candidates=90, collection_size=1500); ref.add_batched(x, 128)
+    ix = Index(32); ix.set_collection_size(1500); ix.set_max_edges(70); ix.set_max_candidates(90); ix.set_insert_batch(128)
+    ix.add(x)
+    assert ix.graph_hash() == ref.graph_hash()
+    a, b = ix.knn_query(q, 5), ref.knn_query(q, 5)
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
+    ref2 = oracle.OracleIndex(32, collection_size=1500); ref2.add_batched(x, 128)
+    iy = Index(32); iy.set_collection_size(1500); iy.set_insert_batch(128)
+    iy.add(x)
+    a, b = iy.knn_query(q[:8], 1400), ref2.knn_query(q[:8], 1400)   # k = 1400 of 1500: huge beam
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
