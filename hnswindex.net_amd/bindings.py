@@ -78,9 +78,11 @@ lib.hnsw_get_last_error_utf8.restype = ct.c_int
 lib.hnsw_get_last_error_utf8.argtypes = [ct.c_void_p, ct.c_int]
 
 # ---- additions ---------------------------------------------------------------------------
-for _name in ("hnsw_mi355x_count", "hnsw_mi355x_entry_point", "hnsw_mi355x_reset_stats"):
+for _name in ("hnsw_mi355x_count", "hnsw_mi355x_length", "hnsw_mi355x_entry_point", "hnsw_mi355x_reset_stats"):
     getattr(lib, _name).restype = ct.c_int
     getattr(lib, _name).argtypes = [ct.c_void_p]
+lib.hnsw_mi355x_active_ids.restype = ct.c_int
+lib.hnsw_mi355x_active_ids.argtypes = [ct.c_void_p, _I, ct.c_int]
 lib.hnsw_mi355x_node_max_layer.restype = ct.c_int
 lib.hnsw_mi355x_node_max_layer.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnsw_mi355x_get_out_edges.restype = ct.c_int
@@ -294,15 +296,26 @@ class Index:
     def max_layer(self, i: int) -> int:
         return lib.hnsw_mi355x_node_max_layer(self._h, int(i))
 
+    @property
+    def length(self) -> int:
+        """Slots ever allocated; every id is < length (removed slots are reused by later adds)."""
+        return lib.hnsw_mi355x_length(self._h) if self._h else 0
+
+    def ids(self):
+        """HNSWIndex.Ids(): live ids."""
+        out = np.empty(max(1, self.count), dtype=np.int32)
+        n = lib.hnsw_mi355x_active_ids(self._h, out.ctypes.data_as(_I), out.size) if self._h else 0
+        return out[:n].copy()
+
     def levels(self):
-        out = np.empty(self.count, dtype=np.int32)
+        out = np.empty(self.length, dtype=np.int32)
         if out.size:
             lib.hnsw_mi355x_export_levels(self._h, out.ctypes.data_as(_I), out.size)
         return out
 
     def export_edges(self, layer: int, stride: int):
         """(counts[n], edges[n, stride]) of one layer; counts == -1 where the node is absent."""
-        n = self.count
+        n = self.length
         counts = np.empty(n, dtype=np.int32)
         edges = np.zeros((n, stride), dtype=np.int32)
         if n and lib.hnsw_mi355x_export_edges(self._h, int(layer), counts.ctypes.data_as(_I), edges.ctypes.data_as(_I),

@@ -90,8 +90,9 @@ API int hnsw_remove(void *handle, const int *ids, int count) // :102-117
 {
     if (!handle) return 0;
     if (!ids || count <= 0) return 0;
-    set_error("System.NotSupportedException: hnsw_remove is outside the accelerated Add/KnnQuery path of this backend (SURVEY.md 8f rank 4)");
-    return -1;
+    std::string err;
+    if (static_cast<HnswIndex *>(handle)->remove(ids, count, err) < 0) { set_error(err); return -1; }
+    return 0;
 }
 
 API int hnsw_knn_query(void *handle, const float *vectors, int count, int dim, int k, int *out_ids, float *out_dists) // :119-149
@@ -175,6 +176,15 @@ API int hnsw_set_distribution_rate(float dist_rate) // :247 -- crosses the ABI a
 
 // ---- introspection / counters ----
 API int hnsw_mi355x_count(void *h) { return h ? static_cast<HnswIndex *>(h)->count() : 0; }
+API int hnsw_mi355x_length(void *h) { return h ? static_cast<HnswIndex *>(h)->graph().length : 0; }
+API int hnsw_mi355x_active_ids(void *h, int *out, int cap)
+{
+    if (!h || !out) return -1;
+    const hnsw::Graph &g = static_cast<HnswIndex *>(h)->graph();
+    int n = std::min(g.count, cap);
+    std::memcpy(out, g.dense.data(), sizeof(int) * (size_t)n);
+    return g.count;
+}
 API int hnsw_mi355x_entry_point(void *h) { return h ? static_cast<HnswIndex *>(h)->graph().entry : -1; }
 API int hnsw_mi355x_node_max_layer(void *h, int id)
 {

@@ -71,18 +71,23 @@ struct Descent {
 struct Expand {
     const Graph *g = nullptr;
     int layer = 0, k = 0;
+    int exclude = -1; // the filter `id => id != removedNode.Id` of GraphConnector.cs:96 (-1: none)
     float farthest = 0.f;
 
-    void begin(const Graph *graph, SlotScratch &sc, int capacity, int entry, float entry_dist, int at_layer, int kk)
+    void begin(const Graph *graph, SlotScratch &sc, int capacity, int entry, float entry_dist, int at_layer, int kk, int exclude_id = -1)
     {
         g = graph;
         layer = at_layer;
         k = kk;
+        exclude = exclude_id;
         sc.top.reset(k);      // :126
         sc.cand.reset(k * 2); // :127
         NodeDist e{entry, entry_dist};
-        sc.top.push(e);       // :134
-        farthest = entry_dist; // :135
+        farthest = std::numeric_limits<float>::max(); // TDistance.MaxValue :130
+        if (entry != exclude) { // filterFnc(entryPointId) :132
+            sc.top.push(e);       // :134
+            farthest = entry_dist; // :135
+        }
         sc.cand.push(e);      // :138
         sc.visited.begin(capacity);
         sc.visited.test_and_set(entry); // :140
@@ -110,9 +115,9 @@ struct Expand {
             if (sc.top.count < k || d < farthest) { // :165
                 NodeDist sel{io.ids[i], d};
                 sc.cand.push(sel);                  // :168
-                sc.top.push(sel);                   // :171
+                if (sel.id != exclude) sc.top.push(sel); // :170-171
                 if (sc.top.count > k) sc.top.pop(); // :173-174
-                farthest = sc.top.peek().dist;      // :176-177
+                if (sc.top.count > 0) farthest = sc.top.peek().dist; // :176-177
             }
         }
     }
@@ -434,6 +439,121 @@ struct LinkSource : JobSource {
     void release(Job *, SlotScratch &) override {}
 };
 
+// ------------------------------------------------------------------------------------
+// Removal (GraphConnector.RemoveConnectionsAtLayer, src/HNSWIndex/GraphConnector.cs:90-167).
+// ------------------------------------------------------------------------------------
+// :96  SearchLayer(removedNode.Id, layer, RemoveMaxCandidates, Items[removedNode.Id], id => id != removedNode.Id)
+struct RemoveSearchJob : Job {
+    const Graph *g;
+    int capacity, removed, layer, k;
+    std::vector<NodeDist> result; // heap order
+    Expand exp;
+    int stage = 0;
+    bool prepare(SlotIO &io, SlotScratch &sc) override
+    {
+        *io.qidx = ~removed;
+        if (stage == 0) { io.ids[0] = removed; *io.cnt = 1; return true; } // :129 Distance(entry, query)
+        return exp.prepare(io, sc);
+    }
+    void consume(const SlotIO &io, SlotScratch &sc) override
+    {
+        if (stage == 0) { exp.begin(g, sc, capacity, removed, io.dist[0], layer, k, removed); stage = 1; return; }
+        exp.consume(io, sc);
+    }
+    void finish(SlotScratch &sc) { result.assign(sc.top.buf.begin(), sc.top.buf.begin() + sc.top.count); }
+};
+
+// :100-165  one affected node: drop the edge to the removed node, re-select its neighbours
+// among (old neighbours + search candidates), apply the difference to its own list.
+struct AffectedJob : Job {
+    Graph *g;
+    int aid, layer, removed;
+    const std::vector<NodeDist> *sc_cands;
+    std::vector<int> old_ids;
+    std::vector<NodeDist> cands;
+    std::vector<int> in_remove, in_add; // in-edge deltas: (old -> aid) dropped, (w -> aid) added
+    size_t pos = 0;
+    int stage = 0; // 0 gather, 1 distances, 2 prune
+    Prune prune;
+
+    static bool has(const std::vector<int> &v, int x) { return std::find(v.begin(), v.end(), x) != v.end(); }
+    static void swap_remove(int *l, int x) // EdgeList.Remove, Node.cs:79-93
+    {
+        for (int i = 1; i <= l[0]; ++i)
+            if (l[i] == x) { int last = l[0]--; if (i != last) l[i] = l[last]; return; }
+    }
+    bool prepare(SlotIO &io, SlotScratch &) override
+    {
+        if (stage == 0) {
+            int *l = g->list(aid, layer);
+            swap_remove(l, removed); // RemoveOutEdge :104
+            old_ids.assign(l + 1, l + 1 + l[0]); // :110-111
+            cands.clear();
+            for (int id : old_ids) cands.push_back(NodeDist{id, 0.f}); // :115-120
+            for (const NodeDist &c : *sc_cands) { // :123-129
+                if (c.id == aid || has(old_ids, c.id)) continue;
+                cands.push_back(NodeDist{c.id, 0.f});
+            }
+            pos = 0;
+            stage = 1;
+        }
+        if (stage == 1) {
+            if (pos < cands.size()) { // Distance(id, affectedNodeId) in chunks of one task
+                const int n = (int)std::min<size_t>((size_t)io.stride, cands.size() - pos);
+                *io.qidx = ~aid;
+                for (int i = 0; i < n; ++i) io.ids[i] = cands[pos + (size_t)i].id;
+                *io.cnt = n;
+                return true;
+            }
+            prune.cands = cands;
+            prune.begin(g->max_edges_at(layer)); // :131
+            stage = 2;
+        }
+        return prune.prepare(io);
+    }
+    void consume(const SlotIO &io, SlotScratch &) override
+    {
+        if (stage == 1) {
+            const int n = *io.cnt;
+            for (int i = 0; i < n; ++i) cands[pos + (size_t)i].dist = io.dist[i];
+            pos += (size_t)n;
+        } else {
+            prune.consume(io);
+        }
+    }
+    void finish()
+    {
+        const std::vector<int> &nw = prune.acc;
+        int *l = g->list(aid, layer);
+        for (int o : old_ids) { // :135-143
+            if (has(nw, o)) continue;
+            swap_remove(l, o);
+            in_remove.push_back(o);
+        }
+        for (int w : nw) { // :146-164
+            if (has(old_ids, w)) continue;
+            if (g->removed[(size_t)w]) continue; // :155
+            l[1 + l[0]] = w;
+            l[0]++;
+            in_add.push_back(w);
+        }
+    }
+};
+
+template <class J>
+struct VecSource : JobSource {
+    std::vector<J> jobs;
+    std::atomic<int> next{0};
+    Job *acquire(SlotScratch &) override
+    {
+        int i = next.fetch_add(1, std::memory_order_relaxed);
+        return i < (int)jobs.size() ? &jobs[(size_t)i] : nullptr;
+    }
+    void release(Job *job, SlotScratch &sc) override { finish_job(static_cast<J *>(job), sc); }
+    static void finish_job(RemoveSearchJob *j, SlotScratch &sc) { j->finish(sc); }
+    static void finish_job(AffectedJob *j, SlotScratch &) { j->finish(); }
+};
+
 template <class F>
 void parallel_for(int n, int threads, F fn)
 {
@@ -550,7 +670,7 @@ bool HnswIndex::ensure_capacity(long long need, std::string &err)
 
 // ---- search half --------------------------------------------------------------------------
 // Host traversal on the lock-step engine for the listed items (indices into the batch).
-bool HnswIndex::search_half_lockstep(int first_id, const std::vector<int> &items, Selection &sel, std::string &err)
+bool HnswIndex::search_half_lockstep(const std::vector<int> &bid, const std::vector<int> &items, Selection &sel, std::string &err)
 {
     if (items.empty()) return true;
     InsertSource src;
@@ -559,7 +679,7 @@ bool HnswIndex::search_half_lockstep(int first_id, const std::vector<int> &items
         InsertJob &j = src.jobs[t];
         j.g = &graph_;
         j.capacity = (int)capacity_;
-        j.id = first_id + items[t];
+        j.id = bid[(size_t)items[t]];
         j.level = graph_.level[(size_t)j.id];
         j.efc = p_.max_candidates;
     }
@@ -570,18 +690,19 @@ bool HnswIndex::search_half_lockstep(int first_id, const std::vector<int> &items
 
 // Graph-resident traversal: one fused kernel launch per layer (search + heuristic) for the whole
 // batch; items whose candidate heap outgrew LDS are redone on the lock-step path.
-bool HnswIndex::search_half_device(int first_id, int n, Selection &sel, std::string &err)
+bool HnswIndex::search_half_device(const std::vector<int> &bid, Selection &sel, std::string &err)
 {
     { Tick t(g_pt.sync_graph); if (!sync_graph(err)) return false; }
     Tick t_all(g_pt.search_half);
     g_pt.batches++;
+    const int n = (int)bid.size();
     const int top = graph_.top_layer(), ep = graph_.entry;
     const int sel_stride = 2 * p_.max_edges;
     std::vector<int> l0((size_t)n), next_entry((size_t)n, ep);
     std::vector<char> redo((size_t)n, 0);
     int maxl = 0;
     for (int i = 0; i < n; ++i) {
-        const int lvl = graph_.level[(size_t)(first_id + i)];
+        const int lvl = graph_.level[(size_t)bid[(size_t)i]];
         sel[(size_t)i].assign((size_t)lvl + 1, {});
         l0[(size_t)i] = std::min(lvl, top); // GraphConnector.cs:176
         maxl = std::max(maxl, l0[(size_t)i]);
@@ -593,7 +714,7 @@ bool HnswIndex::search_half_device(int first_id, int n, Selection &sel, std::str
         jobs.clear(); who.clear();
         for (int i = 0; i < n; ++i) {
             if (redo[(size_t)i] || l0[(size_t)i] < L) continue;
-            const int id = first_id + i;
+            const int id = bid[(size_t)i];
             // first layer of the item: FindEntryPoint from the top (:174); below: entry = selected[0] (:216,:179)
             jobs.push_back(L == l0[(size_t)i] ? SearchJob{~id, ep, top, L} : SearchJob{~id, next_entry[(size_t)i], L, L});
             who.push_back(i);
@@ -613,7 +734,7 @@ bool HnswIndex::search_half_device(int first_id, int n, Selection &sel, std::str
     }
     std::vector<int> again;
     for (int i = 0; i < n; ++i) if (redo[(size_t)i]) again.push_back(i);
-    return search_half_lockstep(first_id, again, sel, err);
+    return search_half_lockstep(bid, again, sel, err);
 }
 
 // ---- link half ----------------------------------------------------------------------------
@@ -625,13 +746,14 @@ struct LinkGroup {
 };
 // currNode.OutEdges[layer] = selected (:192) and the back-edge appends grouped per
 // (neighbour, layer), in item order.
-void collect_groups(Graph &g, int first_id, int n, const std::vector<std::vector<std::vector<int>>> &sel, std::vector<LinkGroup> &groups)
+void collect_groups(Graph &g, const std::vector<int> &bid, const std::vector<std::vector<std::vector<int>>> &sel, std::vector<LinkGroup> &groups)
 {
     std::unordered_map<uint64_t, size_t> where;
+    const int n = (int)bid.size();
     where.reserve((size_t)n * 40);
     const int top = g.top_layer();
     for (int i = 0; i < n; ++i) {
-        const int id = first_id + i;
+        const int id = bid[(size_t)i];
         for (int layer = std::min(g.level[(size_t)id], top); layer >= 0; --layer) {
             const std::vector<int> &s = sel[(size_t)i][(size_t)layer];
             int *l = g.list(id, layer);
@@ -652,10 +774,10 @@ void collect_groups(Graph &g, int first_id, int n, const std::vector<std::vector
 }
 } // namespace
 
-bool HnswIndex::link_half_lockstep(int first_id, int n, const Selection &sel, std::string &err)
+bool HnswIndex::link_half_lockstep(const std::vector<int> &bid, const Selection &sel, std::string &err)
 {
     std::vector<LinkGroup> groups;
-    collect_groups(graph_, first_id, n, sel, groups);
+    collect_groups(graph_, bid, sel, groups);
     LinkSource links;
     links.jobs.resize(groups.size());
     for (size_t t = 0; t < groups.size(); ++t) {
@@ -672,8 +794,9 @@ bool HnswIndex::link_half_lockstep(int first_id, int n, const Selection &sel, st
 // The whole link half as ONE launch on the HBM mirror (graph_link_kernel): the host only groups
 // the back-edge appends per (neighbour, layer) list -- array-indexed for layer 0 -- and copies the
 // final lists back into its own graph.  The mirror stays in step, so no re-upload follows.
-bool HnswIndex::link_half_device(int first_id, int n, const Selection &sel, std::string &err)
+bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &sel, std::string &err)
 {
+    const int n = (int)bid.size();
     const int M2 = 2 * p_.max_edges, row_stride = 3 + M2, list_stride = graph_.stride0;
     const int top = graph_.top_layer();
     std::vector<int> rows, g_node, g_layer, g_cnt;
@@ -685,7 +808,7 @@ bool HnswIndex::link_half_device(int first_id, int n, const Selection &sel, std:
         rows.reserve((size_t)n * row_stride);
         seq.reserve((size_t)n * M2);
         for (int i = 0; i < n; ++i) {
-            const int id = first_id + i;
+            const int id = bid[(size_t)i];
             for (int layer = std::min(graph_.level[(size_t)id], top); layer >= 0; --layer) {
                 const std::vector<int> &s = sel[(size_t)i][(size_t)layer];
                 int *l = graph_.list(id, layer); // currNode.OutEdges[layer] = selected (:192), host copy
@@ -733,60 +856,68 @@ bool HnswIndex::link_half_device(int first_id, int n, const Selection &sel, std:
     return true;
 }
 
-// One snapshot batch: ids [first_id, first_id + n) are nodes without edges yet.
-bool HnswIndex::insert_batch(int first_id, int n, std::string &err)
+// One snapshot batch: the nodes `bid` (in insertion order) have no edges yet.
+bool HnswIndex::insert_batch(const std::vector<int> &bid, std::string &err)
 {
+    const int n = (int)bid.size();
     Selection sel((size_t)n);
     if (p_.device_traversal && dev_->traversal_fits(p_.max_candidates, true, p_.max_edges)) {
-        if (!search_half_device(first_id, n, sel, err)) return false;
-        return link_half_device(first_id, n, sel, err); // keeps the HBM mirror in step
+        if (!search_half_device(bid, sel, err)) return false;
+        return link_half_device(bid, sel, err); // keeps the HBM mirror in step
     }
     std::vector<int> all((size_t)n);
     for (int i = 0; i < n; ++i) all[(size_t)i] = i;
-    if (!search_half_lockstep(first_id, all, sel, err)) return false;
+    if (!search_half_lockstep(bid, all, sel, err)) return false;
     graph_dirty_ = true;
-    return link_half_lockstep(first_id, n, sel, err);
+    return link_half_lockstep(bid, sel, err);
 }
 
 int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::string &err)
 {
     if (!ensure_dim(dim, err)) return -1;
-    // GraphData.AddItem (src/HNSWIndex/GraphData.cs:79-118): one RNG draw per item, in order.
-    std::vector<int> ids((size_t)count);
-    int n_new = 0;
+    // GraphData.AddItem (src/HNSWIndex/GraphData.cs:79-118): one RNG draw per item, in order;
+    // vacated slots are reused first when removals are allowed (:85-91)
+    std::vector<int> ids((size_t)count), fresh; // fresh: the new nodes, in insertion order
+    fresh.reserve((size_t)count);
+    bool any_reused = false;
     const int first_new = graph_.length;
     for (int i = 0; i < count; ++i) {
         int lvl = level_from_uniform(rng_.next_single(), p_.distribution_rate);
         if (lvl < 0) { ids[(size_t)i] = -1; ++skipped_; continue; } // :82
         if (lvl > 200) { err = "level draw out of range"; return -1; }
-        ids[(size_t)i] = graph_.add_node(lvl);
-        ++n_new;
+        ids[(size_t)i] = graph_.add_node(lvl, p_.allow_removals, &any_reused);
+        fresh.push_back(ids[(size_t)i]);
     }
     if (!ensure_capacity(graph_.length, err)) return -1;
+    if (any_reused) graph_dirty_ = true; // existing rows of the HBM mirror changed: full re-upload
     // rows -> HBM (id == row index)
-    if (n_new == count) {
+    if (!any_reused && (int)fresh.size() == count) {
         if (!dev_->upload_rows(first_new, count, vectors)) { err = get_dev_error(); return -1; }
     } else {
         for (int i = 0; i < count; ++i)
             if (ids[(size_t)i] >= 0 && !dev_->upload_rows(ids[(size_t)i], 1, vectors + (size_t)i * dim)) { err = get_dev_error(); return -1; }
     }
     // GraphConnector.ConnectNewNode (:24-47), batched
-    int pos = first_new;
-    const int end = graph_.length;
+    const int m = (int)fresh.size();
     const int bmax = std::max(1, p_.insert_batch);
-    while (pos < end) {
-        if (graph_.entry < 0) { graph_.entry = pos++; continue; } // :28-33
+    int p = 0;
+    std::vector<int> bid;
+    while (p < m) {
+        if (graph_.entry < 0) { graph_.entry = fresh[(size_t)p++]; continue; } // :28-33
         const int top = graph_.top_layer();
-        if (graph_.level[(size_t)pos] > top) { // new entry point: alone, under the "entry point lock" (:36-41)
-            if (!insert_batch(pos, 1, err)) return -1;
-            graph_.entry = pos++;
+        bid.clear();
+        bid.push_back(fresh[(size_t)p]);
+        if (graph_.level[(size_t)fresh[(size_t)p]] > top) { // new entry point: alone, under the "entry point lock" (:36-41)
+            if (!insert_batch(bid, err)) return -1;
+            graph_.entry = fresh[(size_t)p++];
             continue;
         }
-        int b = std::min(bmax, std::max(1, pos / kBatchGrowthDiv));
-        int n = 1;
-        while (n < b && pos + n < end && graph_.level[(size_t)(pos + n)] <= top) ++n;
-        if (!insert_batch(pos, n, err)) return -1;
-        pos += n;
+        const int linked = graph_.count - (m - p); // nodes already linked (== the id when nothing was ever removed)
+        const int b = std::min(bmax, std::max(1, linked / kBatchGrowthDiv));
+        while ((int)bid.size() < b && p + (int)bid.size() < m && graph_.level[(size_t)fresh[(size_t)(p + (int)bid.size())]] <= top)
+            bid.push_back(fresh[(size_t)(p + (int)bid.size())]);
+        if (!insert_batch(bid, err)) return -1;
+        p += (int)bid.size();
     }
     if (out_ids) for (int i = 0; i < count; ++i) out_ids[i] = ids[(size_t)i];
     return count;
@@ -858,7 +989,7 @@ int HnswIndex::knn_query_device(const float *, int count, int k, int *out_ids, f
 int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *out_ids, float *out_dists, std::string &err)
 {
     if (count <= 0) return 0;
-    if (k < 1 || graph_.entry < 0) { // HNSWIndex.cs:109: empty result lists, padded by the export
+    if (k < 1 || graph_.entry < 0 || graph_.count <= 0) { // HNSWIndex.cs:109: empty result lists, padded by the export
         for (long long j = 0; j < (long long)count * std::max(k, 0); ++j) { out_ids[j] = -1; out_dists[j] = std::numeric_limits<float>::quiet_NaN(); }
         return 0;
     }
@@ -889,6 +1020,94 @@ int HnswIndex::range_query(const float *queries, int count, int dim, float range
     return 0;
 }
 
+// ---- HNSWIndex.Remove (src/HNSWIndex/HNSWIndex.cs:83-102) ------------------------------------
+// The reference keeps ordered in-edge lists (Node.InEdges); only their CONTENT matters for the
+// out-graph (each affected node is re-linked from its own state and the shared candidate list,
+// GraphConnector.cs:100-165), so the in-edge sets are rebuilt here by transposing the out-lists
+// once per call and kept current with the deltas of each step.  Ids are removed in order.
+int HnswIndex::remove(const int *ids, int count, std::string &err)
+{
+    if (!p_.allow_removals) { err = "System.InvalidOperationException: Removals are disabled in this index instance."; return -1; } // :85-86
+    if (count <= 0) return 0;
+    for (int t = 0; t < count; ++t) {
+        const int id = ids[t];
+        if (id < 0 || id >= graph_.length || graph_.removed[(size_t)id]) { err = "System.IndexOutOfRangeException: hnsw_remove: id " + std::to_string(id) + " is not in the index"; return -1; }
+        for (int u = 0; u < t; ++u) if (ids[u] == id) { err = "System.ArgumentException: hnsw_remove: duplicate id " + std::to_string(id); return -1; }
+    }
+    Graph &g = graph_;
+    // in-edge sets: layer 0 by node, upper layers by (node, layer)
+    std::vector<std::vector<int>> in0((size_t)g.length);
+    std::unordered_map<uint64_t, std::vector<int>> inU;
+    auto in_of = [&](int node, int layer) -> std::vector<int> & {
+        return layer == 0 ? in0[(size_t)node] : inU[((uint64_t)(uint32_t)node << 8) | (uint64_t)(uint32_t)layer];
+    };
+    for (int a = 0; a < g.count; ++a) {
+        const int i = g.dense[(size_t)a];
+        for (int layer = 0; layer <= g.level[(size_t)i]; ++layer) {
+            const int *l = g.list(i, layer);
+            for (int e = 1; e <= l[0]; ++e) in_of(l[e], layer).push_back(i);
+        }
+    }
+    auto erase_from = [](std::vector<int> &v, int x) {
+        auto it = std::find(v.begin(), v.end(), x);
+        if (it != v.end()) { *it = v.back(); v.pop_back(); }
+    };
+    graph_dirty_ = true;
+    for (int t = 0; t < count; ++t) {
+        const int id = ids[t];
+        g.removed[(size_t)id] = 1; // item.IsRemoved = true, GraphConnector.cs:55-57
+        for (int layer = g.level[(size_t)id]; layer >= 0; --layer) { // :59-66
+            // ReplaceEntryPointIfNeeded :72-85
+            if (id == g.entry) {
+                const int *el = g.list(g.entry, layer);
+                if (el[0] > 0) { // GraphData.TryReplaceEntryPoint :146-167
+                    int repl = -1, maxc = -1;
+                    for (int e = 1; e <= el[0]; ++e) {
+                        const int c = g.list(el[e], layer)[0];
+                        if (c > maxc) { maxc = c; repl = el[e]; }
+                    }
+                    g.entry = repl;
+                } else if (layer == 0) {
+                    if (g.count == 1) g.entry = -1;
+                    else { // GraphData.ForceReplaceEntryPoint :173-190
+                        int best_layer = -1, best_id = -1;
+                        for (int a = 0; a < g.count; ++a) {
+                            const int c = g.dense[(size_t)a];
+                            if (g.level[(size_t)c] > best_layer) { best_layer = g.level[(size_t)c]; best_id = c; }
+                        }
+                        g.entry = best_id;
+                    }
+                }
+            }
+            // RemoveConnectionsAtLayer :90-167
+            const int *rl = g.list(id, layer);
+            for (int e = 1; e <= rl[0]; ++e) erase_from(in_of(rl[e], layer), id); // DetachOutgoingReferences :277-288
+            const std::vector<int> affected = in_of(id, layer);                   // :95
+            VecSource<RemoveSearchJob> ssrc;
+            ssrc.jobs.resize(1);
+            RemoveSearchJob &sj = ssrc.jobs[0];
+            sj.g = &g; sj.capacity = (int)capacity_; sj.removed = id; sj.layer = layer; sj.k = p_.remove_max_candidates;
+            if (!engine_->run(ssrc, 1)) { err = get_dev_error(); return -1; }
+            if (!affected.empty()) {
+                VecSource<AffectedJob> asrc;
+                asrc.jobs.resize(affected.size());
+                for (size_t a = 0; a < affected.size(); ++a) {
+                    AffectedJob &aj = asrc.jobs[a];
+                    aj.g = &g; aj.aid = affected[a]; aj.layer = layer; aj.removed = id; aj.sc_cands = &sj.result;
+                }
+                if (!engine_->run(asrc, (long long)affected.size())) { err = get_dev_error(); return -1; }
+                for (AffectedJob &aj : asrc.jobs) {
+                    for (int o : aj.in_remove) erase_from(in_of(o, layer), aj.aid);
+                    for (int w : aj.in_add) in_of(w, layer).push_back(aj.aid);
+                }
+            }
+            in_of(id, layer).clear();
+            if (layer == 0) g.retire(id); // GraphData.RemoveItem :124-128
+        }
+    }
+    return 0;
+}
+
 uint64_t HnswIndex::graph_hash() const
 {
     uint64_t x = 1469598103934665603ULL;
@@ -898,6 +1117,7 @@ uint64_t HnswIndex::graph_hash() const
     };
     mix(graph_.entry);
     for (int i = 0; i < graph_.length; ++i) {
+        if (graph_.removed[(size_t)i]) { mix(-2); continue; } // a vacated slot: its stale lists are unreachable
         mix(graph_.level[(size_t)i]);
         for (int l = 0; l <= graph_.level[(size_t)i]; ++l) {
             const int *e = graph_.list(i, l);

@@ -44,7 +44,10 @@ public:
     // in-range results ordered by distance.  Host lock-step traversal.
     int range_query(const float *queries, int count, int dim, float range, std::vector<std::vector<NodeDist>> &out, std::string &err);
 
-    int count() const { return graph_.length; }
+    // hnsw_remove (HNSWIndex.Remove, src/HNSWIndex/HNSWIndex.cs:83-102), ids in order.
+    int remove(const int *ids, int count, std::string &err);
+
+    int count() const { return graph_.count; }
     const Graph &graph() const { return graph_; }
     Device *device() { return dev_.get(); }
     uint64_t graph_hash() const;
@@ -54,12 +57,12 @@ private:
     HnswIndex() = default;
     bool ensure_dim(int dim, std::string &err);
     bool ensure_capacity(long long need, std::string &err);
-    bool insert_batch(int first_id, int n, std::string &err);
+    bool insert_batch(const std::vector<int> &bid, std::string &err);
     using Selection = std::vector<std::vector<std::vector<int>>>; // [item][layer] -> selected neighbour ids
-    bool search_half_lockstep(int first_id, const std::vector<int> &items, Selection &sel, std::string &err);
-    bool search_half_device(int first_id, int n, Selection &sel, std::string &err);
-    bool link_half_lockstep(int first_id, int n, const Selection &sel, std::string &err);
-    bool link_half_device(int first_id, int n, const Selection &sel, std::string &err);
+    bool search_half_lockstep(const std::vector<int> &bid, const std::vector<int> &items, Selection &sel, std::string &err);
+    bool search_half_device(const std::vector<int> &bid, Selection &sel, std::string &err);
+    bool link_half_lockstep(const std::vector<int> &bid, const Selection &sel, std::string &err);
+    bool link_half_device(const std::vector<int> &bid, const Selection &sel, std::string &err);
     bool sync_graph(std::string &err);
     int knn_query_device(const float *queries, int count, int k, int *out_ids, float *out_dists, std::string &err);
     int knn_query_lockstep(const int *which, int count, int k, int *out_ids, float *out_dists, std::string &err);

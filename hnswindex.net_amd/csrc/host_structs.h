@@ -277,7 +277,12 @@ struct Graph {
     std::vector<int64_t> upper; // per node: offset into pool (-1 if level 0)
     std::vector<int> pool;      // blocks of strideU per (node, layer >= 1)
     int entry = -1;
-    int length = 0;
+    int length = 0; // slots ever allocated (GraphData.Length)
+    // ActiveSet (src/HNSWIndex/ActiveSet.cs:10-97: dense/sparse, swap-with-last removal),
+    // IsRemoved flags (Node.cs:18) and RemovedIndexes (GraphData.cs:19: LIFO slot reuse)
+    std::vector<int> dense, sparse, removed_stack;
+    std::vector<char> removed;
+    int count = 0; // GraphData.Count
 
     void configure(int M)
     {
@@ -292,20 +297,44 @@ struct Graph {
         upper.reserve((size_t)capacity);
         adj0.reserve((size_t)capacity * stride0);
     }
-    // GraphData.NewNode :224-242
-    int add_node(int top_layer)
+    // GraphData.AddItem :85-115 + NewNode :224-242.  reuse: pop the most recently vacated slot.
+    int add_node(int top_layer, bool reuse, bool *reused = nullptr)
     {
-        int id = length++;
-        level.push_back(top_layer);
-        adj0.resize((size_t)length * stride0, 0);
-        adj0[(size_t)id * stride0] = 0;
+        int id;
+        if (reuse && !removed_stack.empty()) {
+            id = removed_stack.back();
+            removed_stack.pop_back();
+            level[(size_t)id] = top_layer;
+            std::memset(adj0.data() + (size_t)id * stride0, 0, sizeof(int) * (size_t)stride0);
+            removed[(size_t)id] = 0;
+            if (reused) *reused = true;
+        } else {
+            id = length++;
+            level.push_back(top_layer);
+            adj0.resize((size_t)length * stride0, 0);
+            upper.push_back(-1);
+            removed.push_back(0);
+            sparse.push_back(0);
+            dense.push_back(0);
+        }
         if (top_layer > 0) {
-            upper.push_back((int64_t)pool.size());
+            upper[(size_t)id] = (int64_t)pool.size();
             pool.resize(pool.size() + (size_t)top_layer * strideU, 0);
         } else {
-            upper.push_back(-1);
+            upper[(size_t)id] = -1;
         }
+        dense[(size_t)count] = id; // ActiveSet.Add :72-80
+        sparse[(size_t)id] = count;
+        ++count;
         return id;
+    }
+    // GraphData.RemoveItem :124-128 + ActiveSet.Remove :85-97
+    void retire(int id)
+    {
+        removed_stack.push_back(id);
+        const int idx = sparse[(size_t)id], last = --count, last_id = dense[(size_t)last];
+        dense[(size_t)idx] = last_id;
+        sparse[(size_t)last_id] = idx;
     }
     // pointer to [count, e0, e1, ...] of (id, layer)
     inline int *list(int id, int layer)

@@ -57,8 +57,9 @@ void hnsw_free(void *handle);
  * HNSWIndex.Add(item) (HNSWIndex.cs:55-65). */
 int hnsw_add(void *handle, const float *vectors, int count, int dim, int *out_ids);
 
-/* :102-117  Remove.  Not on the hot path (out of scope this round):
- * returns -1 and sets the last error; 0 for a null handle / null ids / count <= 0. */
+/* :102-117  Remove -> HNSWIndex.Remove(List<int>) (HNSWIndex.cs:83-102); the ids are removed in
+ * the order given (the reference uses Parallel.For).  Returns 0; 0 for a null handle / null ids /
+ * count <= 0; -1 on error (removals disabled: InvalidOperationException; unknown id). */
 int hnsw_remove(void *handle, const int *ids, int count);
 
 /* :119-149  KnnQuery -> BatchKnnQuery (HNSWIndex.cs:129-137).  out_ids / out_dists are
@@ -103,7 +104,10 @@ int hnsw_mi355x_set_host_threads(int threads);
 int hnsw_mi355x_set_device_traversal(int enabled);
 
 /* Graph introspection for parity checks (reads host state only). */
-int hnsw_mi355x_count(void *handle);
+int hnsw_mi355x_count(void *handle);   /* HNSWIndex.Count: live items */
+int hnsw_mi355x_length(void *handle);  /* slots ever allocated (ids are < length) */
+/* HNSWIndex.Ids(): the live ids in ActiveSet order; returns Count. */
+int hnsw_mi355x_active_ids(void *handle, int *out, int cap);
 int hnsw_mi355x_entry_point(void *handle);
 int hnsw_mi355x_node_max_layer(void *handle, int id);
 /* Copies up to cap out-edge ids of (id, layer); returns the edge count or -1. */

@@ -47,6 +47,11 @@ def lib():
         L.orc_import_nodes.argtypes = [ct.c_void_p, _F, _I, ct.c_int, ct.c_int]
         L.orc_import_edges.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int, ct.c_int]
         L.orc_range_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_float, ct.c_int, _I, _I, _F]
+        L.orc_remove.argtypes = [ct.c_void_p, _I, ct.c_int]
+        L.orc_active_ids.argtypes = [ct.c_void_p, _I, ct.c_int]
+        L.orc_length.argtypes = [ct.c_void_p]
+        L.orc_set_remove_max_candidates.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_set_remove_max_candidates.restype = None
         L.orc_knn_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, _I, _F, ct.c_int]
         for name in ("orc_count", "orc_entry_point", "orc_capacity"):
             getattr(L, name).argtypes = [ct.c_void_p]
@@ -162,7 +167,8 @@ class OracleIndex:
     the float32 Add/KnnQuery path, plus graph introspection for parity checks."""
 
     def __init__(self, dim, metric="sq_euclid", *, max_edges=16, distribution_rate=None, min_nn=5,
-                 max_candidates=100, collection_size=65536, random_seed=31337, allow_removals=True, use_avx=True):
+                 max_candidates=100, collection_size=65536, random_seed=31337, allow_removals=True, use_avx=True,
+                 remove_max_candidates=100):
         import math
         if distribution_rate is None:
             distribution_rate = 1.0 / math.log(16)  # HNSWParameters.cs:19
@@ -171,6 +177,7 @@ class OracleIndex:
                                    collection_size, random_seed, int(allow_removals), int(use_avx))
         if not self._h:
             raise RuntimeError("orc_create failed")
+        lib().orc_set_remove_max_candidates(self._h, int(remove_max_candidates))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -235,8 +242,24 @@ class OracleIndex:
     def max_layer(self, i):
         return lib().orc_node_max_layer(self._h, int(i))
 
+    def remove(self, ids):
+        """HNSWIndex.Remove per id, in order (HNSWIndex.cs:83-102)."""
+        a = _i32(ids).ravel()
+        if lib().orc_remove(self._h, _pi(a), a.size) != 0:
+            raise RuntimeError("orc_remove: removals disabled or invalid id")
+
+    def active_ids(self):
+        out = np.empty(max(1, self.count), dtype=np.int32)
+        n = lib().orc_active_ids(self._h, _pi(out), out.size)
+        return out[:n].copy()
+
+    @property
+    def length(self):
+        """Slots ever allocated (GraphData.Length)."""
+        return lib().orc_length(self._h)
+
     def levels(self):
-        return np.array([self.max_layer(i) for i in range(self.count)], dtype=np.int32)
+        return np.array([self.max_layer(i) for i in range(self.length)], dtype=np.int32)
 
     def edges(self, i, layer, incoming=False):
         buf = np.empty(4096, dtype=np.int32)

@@ -459,7 +459,7 @@ static void dotnet_sort_nd(nd_t *k, int n)
  * EdgeList / Node -- src/HNSWIndex/Node.cs:31-107 (append; swap-with-last removal).
  * ---------------------------------------------------------------------------------- */
 typedef struct { int *buf; int count, cap; } edges_t;
-typedef struct { int max_layer; edges_t *out, *in; } node_t;
+typedef struct { int max_layer; edges_t *out, *in; int is_removed; } node_t;
 
 static edges_t edges_new(int cap)
 {
@@ -506,13 +506,16 @@ typedef struct {
 
 typedef struct {
     int dim, metric;
-    int max_edges, min_nn, max_candidates, seed, allow_removals;
+    int max_edges, min_nn, max_candidates, seed, allow_removals, remove_max_candidates;
     double dist_rate;
     int capacity, length, count, entry;
     float *items; /* row-major length x dim: Items[id] (GraphData.cs:18) */
     node_t *nodes;
     dotnet_rng rng;
     metric_fn dist;
+    /* ActiveSet (src/HNSWIndex/ActiveSet.cs:10-97) + RemovedIndexes (GraphData.cs:19, LIFO) */
+    int *dense, *sparse, *removed_stack;
+    int n_removed_stack;
     visited_t vis;          /* used by the single-threaded paths */
     uint64_t n_eval;        /* distance evaluations (SURVEY 8d N_eval) */
 } index_t;
@@ -589,15 +592,24 @@ static int find_entry_point(sctx_t *c, int dst_layer, const float *q)
 
 /* GraphNavigator.cs:123-189 (SearchLayer) == :194-256 (SearchLayerQuery) minus locks.
  * Returns the top-candidate heap's buffer prefix (heap order) in *out (malloc'd). */
+static int search_layer_f(sctx_t *c, int entry_id, int layer, int k, const float *q, nd_t **out, int exclude_id);
 static int search_layer(sctx_t *c, int entry_id, int layer, int k, const float *q, nd_t **out)
+{
+    return search_layer_f(c, entry_id, layer, k, q, out, -1);
+}
+/* exclude_id >= 0: the filter `id => id != removedNode.Id` of GraphConnector.cs:96 */
+static int search_layer_f(sctx_t *c, int entry_id, int layer, int k, const float *q, nd_t **out, int exclude_id)
 {
     index_t *ix = c->ix;
     heap_t top, cand;
     heap_init(&top, k, 0);      /* :126 fartherFirst */
     heap_init(&cand, k * 2, 1); /* :127 closerFirst */
     nd_t entry = {entry_id, dist_iq(c, entry_id, q)}; /* :129 */
-    heap_push(&top, entry);     /* :134 */
-    float farthest = entry.dist; /* :135 */
+    float farthest = 3.402823466e+38f;   /* TDistance.MaxValue :130 */
+    if (entry_id != exclude_id) {        /* filterFnc(entryPointId) :132 */
+        heap_push(&top, entry);          /* :134 */
+        farthest = entry.dist;           /* :135 */
+    }
     heap_push(&cand, entry);    /* :138 */
     visited_next(c->vis, ix->capacity);
     visited_add(c->vis, entry_id); /* :140 */
@@ -612,7 +624,7 @@ static int search_layer(sctx_t *c, int entry_id, int layer, int k, const float *
             if (top.count < k || d < farthest) {                /* :165 */
                 nd_t sel = {nb, d};
                 heap_push(&cand, sel);                          /* :168 */
-                heap_push(&top, sel);                           /* :171 */
+                if (sel.id != exclude_id) heap_push(&top, sel); /* :170-171 */
                 if (top.count > k) heap_pop(&top);              /* :173-174 */
                 if (top.count > 0) farthest = top.buf[0].dist;  /* :176-177 */
             }
@@ -760,7 +772,45 @@ static void grow(index_t *ix) /* GraphData.cs:98-111 */
     ix->items = (float *)realloc(ix->items, sizeof(float) * (size_t)nc * (size_t)ix->dim);
     ix->nodes = (node_t *)realloc(ix->nodes, sizeof(node_t) * (size_t)nc);
     memset(ix->nodes + ix->capacity, 0, sizeof(node_t) * (size_t)(nc - ix->capacity));
+    ix->dense = (int *)realloc(ix->dense, sizeof(int) * (size_t)nc);
+    ix->sparse = (int *)realloc(ix->sparse, sizeof(int) * (size_t)nc);
+    ix->removed_stack = (int *)realloc(ix->removed_stack, sizeof(int) * (size_t)nc);
     ix->capacity = nc;
+}
+
+static void node_free_lists(node_t *nd)
+{
+    if (!nd->out) return;
+    for (int l = 0; l <= nd->max_layer; l++) {
+        free(nd->out[l].buf);
+        if (nd->in) free(nd->in[l].buf);
+    }
+    free(nd->out);
+    free(nd->in);
+    nd->out = nd->in = NULL;
+}
+
+/* GraphData.AddItem (src/HNSWIndex/GraphData.cs:79-118): level draw, then either the most
+ * recently vacated slot (RemovedIndexes.TryPop, :85-91) or a fresh one; ActiveSet.Add. */
+static int alloc_node(index_t *ix, const float *v)
+{
+    int top_layer = level_from_uniform(rng_next_single(&ix->rng), ix->dist_rate); /* :81 */
+    if (top_layer < 0) return -1;                                                 /* :82 */
+    int id;
+    if (ix->allow_removals && ix->n_removed_stack > 0) {
+        id = ix->removed_stack[--ix->n_removed_stack];
+        node_free_lists(&ix->nodes[id]);
+    } else {
+        id = ix->length++;
+        if (ix->length > ix->capacity) grow(ix);
+    }
+    node_init(ix, &ix->nodes[id], top_layer);
+    ix->nodes[id].is_removed = 0;
+    memcpy(ix->items + (size_t)id * (size_t)ix->dim, v, sizeof(float) * (size_t)ix->dim);
+    ix->dense[ix->count] = id; /* ActiveSet.Add :72-80 */
+    ix->sparse[id] = ix->count;
+    ix->count++;
+    return id;
 }
 
 /* HNSWIndex.Add(item) src/HNSWIndex/HNSWIndex.cs:55-65 -> GraphData.AddItem :79-118 ->
@@ -768,13 +818,8 @@ static void grow(index_t *ix) /* GraphData.cs:98-111 */
 static int add_one(sctx_t *c, const float *v)
 {
     index_t *ix = c->ix;
-    int top_layer = level_from_uniform(rng_next_single(&ix->rng), ix->dist_rate); /* :81 */
-    if (top_layer < 0) return -1;                                                 /* :82 */
-    int id = ix->length++;
-    if (ix->length > ix->capacity) grow(ix);
-    node_init(ix, &ix->nodes[id], top_layer);
-    memcpy(ix->items + (size_t)id * (size_t)ix->dim, v, sizeof(float) * (size_t)ix->dim);
-    ix->count++;
+    int id = alloc_node(ix, v);
+    if (id < 0) return -1;
     if (ix->entry < 0) { ix->entry = id; return id; } /* GraphConnector.cs:28-33 */
     node_t *cur = &ix->nodes[id];
     int top = ix->nodes[ix->entry].max_layer; /* GetTopLayer :195-198 */
@@ -803,18 +848,6 @@ static int add_one(sctx_t *c, const float *v)
  * exceeds the current top layer is inserted alone (the reference holds the entry-point lock
  * for it, GraphConnector.cs:27-41).  max_batch == 1 is exactly orc_add.
  * ---------------------------------------------------------------------------------- */
-static int alloc_node(index_t *ix, const float *v)
-{
-    int top_layer = level_from_uniform(rng_next_single(&ix->rng), ix->dist_rate);
-    if (top_layer < 0) return -1;
-    int id = ix->length++;
-    if (ix->length > ix->capacity) grow(ix);
-    node_init(ix, &ix->nodes[id], top_layer);
-    memcpy(ix->items + (size_t)id * (size_t)ix->dim, v, sizeof(float) * (size_t)ix->dim);
-    ix->count++;
-    return id;
-}
-
 static void batch_search(sctx_t *c, int id, edges_t *sel /* [max_layer+1] */)
 {
     index_t *ix = c->ix;
@@ -860,40 +893,166 @@ ORC_API int orc_add_batched(void *h, const float *v, int n, int *out_ids, int ma
     if (!ix || !v || n <= 0) return 0;
     if (max_batch < 1) max_batch = 1;
     sctx_t c = {ix, &ix->vis, 0};
-    int first = ix->length;
+    int *ids = (int *)malloc(sizeof(int) * (size_t)n);
+    int m = 0;
     for (int i = 0; i < n; i++) {
         int id = alloc_node(ix, v + (size_t)i * (size_t)ix->dim);
         if (out_ids) out_ids[i] = id;
+        if (id >= 0) ids[m++] = id;
     }
-    int pos = first, end = ix->length;
-    while (pos < end) {
-        if (ix->entry < 0) { ix->entry = pos++; continue; }
+    int p = 0;
+    while (p < m) {
+        if (ix->entry < 0) { ix->entry = ids[p++]; continue; }
         int top = ix->nodes[ix->entry].max_layer;
         int nb = 1, new_ep = 0;
-        if (ix->nodes[pos].max_layer > top) {
+        if (ix->nodes[ids[p]].max_layer > top) {
             new_ep = 1;
         } else {
-            int b = pos / 32;
+            int linked = ix->count - (m - p); /* nodes already linked (== the id when nothing was ever removed) */
+            int b = linked / 32;
             if (b < 1) b = 1;
             if (b > max_batch) b = max_batch;
-            while (nb < b && pos + nb < end && ix->nodes[pos + nb].max_layer <= top) nb++;
+            while (nb < b && p + nb < m && ix->nodes[ids[p + nb]].max_layer <= top) nb++;
         }
         edges_t **sels = (edges_t **)malloc(sizeof(edges_t *) * (size_t)nb);
         for (int i = 0; i < nb; i++) {
-            sels[i] = (edges_t *)calloc((size_t)ix->nodes[pos + i].max_layer + 1, sizeof(edges_t));
-            batch_search(&c, pos + i, sels[i]);
+            sels[i] = (edges_t *)calloc((size_t)ix->nodes[ids[p + i]].max_layer + 1, sizeof(edges_t));
+            batch_search(&c, ids[p + i], sels[i]);
         }
         for (int i = 0; i < nb; i++) {
-            batch_link(&c, pos + i, sels[i]);
+            batch_link(&c, ids[p + i], sels[i]);
             free(sels[i]);
         }
         free(sels);
-        if (new_ep) ix->entry = pos;
-        pos += nb;
+        if (new_ep) ix->entry = ids[p];
+        p += nb;
     }
+    free(ids);
     ix->n_eval += c.n_eval;
     return n;
 }
+
+/* ------------------------------------------------------------------------------------
+ * Removal: HNSWIndex.Remove (src/HNSWIndex/HNSWIndex.cs:83-102) ->
+ * GraphConnector.RemoveNodeConnections (GraphConnector.cs:53-167), single-threaded (the region
+ * locker, GraphLocker.cs, only serialises concurrent removals).
+ * ---------------------------------------------------------------------------------- */
+static int try_replace_entry_point(index_t *ix, int layer) /* GraphData.cs:146-167 */
+{
+    const edges_t *e = &ix->nodes[ix->entry].out[layer];
+    if (e->count <= 0) return 0;
+    int repl = -1, maxc = -1;
+    for (int i = 0; i < e->count; i++) {
+        int nb = e->buf[i];
+        int cnt = ix->nodes[nb].out[layer].count;
+        if (cnt > maxc) { maxc = cnt; repl = nb; }
+    }
+    ix->entry = repl;
+    return 1;
+}
+static void force_replace_entry_point(index_t *ix) /* GraphData.cs:173-190 */
+{
+    if (ix->count == 0) return;
+    int best_layer = -1, best_id = -1;
+    for (int i = 0; i < ix->count; i++) {
+        int id = ix->dense[i];
+        if (ix->nodes[id].max_layer > best_layer) { best_layer = ix->nodes[id].max_layer; best_id = id; }
+    }
+    ix->entry = best_id;
+}
+static void replace_entry_point_if_needed(index_t *ix, int removed, int layer) /* GraphConnector.cs:72-85 */
+{
+    if (removed != ix->entry) return;
+    if (try_replace_entry_point(ix, layer)) return;
+    if (layer > 0) return;
+    if (ix->count == 1) { ix->entry = -1; return; }
+    force_replace_entry_point(ix);
+}
+static int in_list(const int *a, int n, int v)
+{
+    for (int i = 0; i < n; i++) if (a[i] == v) return 1;
+    return 0;
+}
+static void remove_connections_at_layer(sctx_t *c, int removed, int layer) /* GraphConnector.cs:90-167 */
+{
+    index_t *ix = c->ix;
+    const int max_edges = max_edges_at(ix, layer);
+    node_t *rn = &ix->nodes[removed];
+    for (int i = 0; i < rn->out[layer].count; i++) /* DetachOutgoingReferences :277-288 */
+        edges_remove(&ix->nodes[rn->out[layer].buf[i]].in[layer], removed);
+    int n_aff = rn->in[layer].count; /* :95 */
+    int *affected = (int *)malloc(sizeof(int) * (size_t)(n_aff > 0 ? n_aff : 1));
+    memcpy(affected, rn->in[layer].buf, sizeof(int) * (size_t)n_aff);
+    nd_t *sc;
+    int n_sc = search_layer_f(c, removed, layer, ix->remove_max_candidates, item(ix, removed), &sc, removed); /* :96 */
+    nd_t *cd = (nd_t *)malloc(sizeof(nd_t) * (size_t)(n_sc + max_edges + 2));
+    int *old_ids = (int *)malloc(sizeof(int) * (size_t)(max_edges + 2));
+    for (int a = 0; a < n_aff; a++) {
+        const int aid = affected[a];
+        node_t *an = &ix->nodes[aid];
+        edges_remove(&an->out[layer], removed); /* RemoveOutEdge :104 */
+        const int old_count = an->out[layer].count;
+        memcpy(old_ids, an->out[layer].buf, sizeof(int) * (size_t)old_count); /* :110-111 */
+        int cc = 0;
+        for (int j = 0; j < old_count; j++) { cd[cc].id = old_ids[j]; cd[cc].dist = dist_ii(c, old_ids[j], aid); cc++; } /* :115-120 */
+        for (int j = 0; j < n_sc; j++) { /* :123-129 */
+            int cid = sc[j].id;
+            if (cid == aid) continue;
+            if (in_list(old_ids, old_count, cid)) continue;
+            cd[cc].id = cid; cd[cc].dist = dist_ii(c, cid, aid); cc++;
+        }
+        edges_t nw = relative_neighbor_pruning(c, cd, cc, max_edges); /* :131 */
+        for (int j = 0; j < old_count; j++) { /* :135-143 old neighbours no longer selected */
+            int o = old_ids[j];
+            if (in_list(nw.buf, nw.count, o)) continue;
+            edges_remove(&an->out[layer], o);
+            edges_remove(&ix->nodes[o].in[layer], aid);
+        }
+        for (int j = 0; j < nw.count; j++) { /* :146-164 newly selected neighbours */
+            int w = nw.buf[j];
+            if (in_list(old_ids, old_count, w)) continue;
+            if (ix->nodes[w].is_removed) continue; /* :155 */
+            edges_add(&an->out[layer], w);
+            edges_add(&ix->nodes[w].in[layer], aid);
+        }
+        free(nw.buf);
+    }
+    free(cd); free(old_ids); free(sc); free(affected);
+}
+
+ORC_API int orc_remove(void *h, const int *ids, int n)
+{
+    index_t *ix = (index_t *)h;
+    if (!ix) return 0;
+    if (!ix->allow_removals) return -1; /* InvalidOperationException, HNSWIndex.cs:85-86 */
+    sctx_t c = {ix, &ix->vis, 0};
+    for (int t = 0; t < n; t++) {
+        const int id = ids[t];
+        if (id < 0 || id >= ix->length || ix->nodes[id].is_removed || !ix->nodes[id].out) return -1;
+        ix->nodes[id].is_removed = 1; /* :55-57 */
+        for (int layer = ix->nodes[id].max_layer; layer >= 0; layer--) { /* :59-66 */
+            replace_entry_point_if_needed(ix, id, layer);
+            remove_connections_at_layer(&c, id, layer);
+            if (layer == 0) { /* GraphData.RemoveItem :124-128 */
+                ix->removed_stack[ix->n_removed_stack++] = id;
+                int idx = ix->sparse[id], last = --ix->count, last_id = ix->dense[last]; /* ActiveSet.Remove :85-97 */
+                ix->dense[idx] = last_id;
+                ix->sparse[last_id] = idx;
+            }
+        }
+    }
+    ix->n_eval += c.n_eval;
+    return 0;
+}
+
+ORC_API int orc_active_ids(void *h, int *out, int cap)
+{
+    index_t *ix = (index_t *)h;
+    int n = ix->count < cap ? ix->count : cap;
+    memcpy(out, ix->dense, sizeof(int) * (size_t)n);
+    return ix->count;
+}
+ORC_API int orc_length(void *h) { return ((index_t *)h)->length; }
 
 /* ------------------------------------------------------------------------------------
  * C API (ctypes)
@@ -908,6 +1067,10 @@ ORC_API void *orc_create(int dim, int metric, int max_edges, double dist_rate, i
     ix->capacity = collection_size > 0 ? collection_size : 1;
     ix->items = (float *)malloc(sizeof(float) * (size_t)ix->capacity * (size_t)dim);
     ix->nodes = (node_t *)calloc((size_t)ix->capacity, sizeof(node_t));
+    ix->remove_max_candidates = 100; /* HNSWParameters.cs:37 */
+    ix->dense = (int *)malloc(sizeof(int) * (size_t)ix->capacity);
+    ix->sparse = (int *)malloc(sizeof(int) * (size_t)ix->capacity);
+    ix->removed_stack = (int *)malloc(sizeof(int) * (size_t)ix->capacity);
     ix->entry = -1;
     /* RandomSeed < 0 => unseeded Random() (GraphData.cs:42): not reproducible by design;
      * the oracle seeds with |seed| so that runs stay deterministic. */
@@ -921,16 +1084,9 @@ ORC_API void orc_free(void *h)
 {
     index_t *ix = (index_t *)h;
     if (!ix) return;
-    for (int i = 0; i < ix->length; i++) {
-        node_t *nd = &ix->nodes[i];
-        for (int l = 0; l <= nd->max_layer; l++) {
-            free(nd->out[l].buf);
-            if (nd->in) free(nd->in[l].buf);
-        }
-        free(nd->out);
-        free(nd->in);
-    }
+    for (int i = 0; i < ix->length; i++) node_free_lists(&ix->nodes[i]);
     free(ix->nodes);
+    free(ix->dense); free(ix->sparse); free(ix->removed_stack);
     free(ix->items);
     visited_free(&ix->vis);
     free(ix);
@@ -1069,7 +1225,7 @@ ORC_API int orc_import_nodes(void *h, const float *items, const int *levels, int
     if (!ix || ix->length != 0 || n <= 0) return -1;
     while (ix->capacity < n) grow(ix);
     memcpy(ix->items, items, sizeof(float) * (size_t)n * (size_t)ix->dim);
-    for (int i = 0; i < n; i++) node_init(ix, &ix->nodes[i], levels[i]);
+    for (int i = 0; i < n; i++) { node_init(ix, &ix->nodes[i], levels[i]); ix->dense[i] = i; ix->sparse[i] = i; }
     ix->length = n;
     ix->count = n;
     ix->entry = entry;
@@ -1110,6 +1266,7 @@ ORC_API int orc_get_edges(void *h, int id, int layer, int incoming, int *out, in
 }
 ORC_API uint64_t orc_n_eval(void *h) { return ((index_t *)h)->n_eval; }
 ORC_API void orc_reset_n_eval(void *h) { ((index_t *)h)->n_eval = 0; }
+ORC_API void orc_set_remove_max_candidates(void *h, int v) { ((index_t *)h)->remove_max_candidates = v; }
 ORC_API const float *orc_items(void *h) { return ((index_t *)h)->items; }
 
 /* FNV-1a over (max_layer, per-layer out-edge lists) of every node: one number that pins
@@ -1122,6 +1279,7 @@ ORC_API uint64_t orc_graph_hash(void *h)
     MIX(ix->entry);
     for (int i = 0; i < ix->length; i++) {
         node_t *nd = &ix->nodes[i];
+        if (nd->is_removed) { MIX(-2); continue; } /* a removed slot: its stale lists are unreachable */
         MIX(nd->max_layer);
         for (int l = 0; l <= nd->max_layer; l++) {
             MIX(nd->out[l].count);

@@ -156,8 +156,6 @@ def test_edge_cases_and_errors(Index):
     v = uniform(1, 8, 3); out = np.zeros(1, np.int32)
     assert lib.hnsw_add(ix._h, v.ctypes.data_as(F), 1, 8, out.ctypes.data_as(I)) == -1
     assert "dimension mismatch" in hnswindex.net_amd.last_error()
-    with pytest.raises(RuntimeError, match="NotSupported"):
-        ix.remove([0])
 
 
 def test_stats_count_every_evaluation_and_profiling_times_kernels(Index):
@@ -294,3 +292,58 @@ def test_shapes_beyond_the_device_kernels_fall_back_to_host_traversal(Index):
     iy.add(x)
     a, b = iy.knn_query(q[:8], 1400), ref2.knn_query(q[:8], 1400)   # k = 1400 of 1500: huge beam
     assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
+
+
+def test_removal_matches_oracle_and_reference_thresholds(Index):
+    # src/HNSWIndex.Tests/GraphTests.cs:122-171 (recall after removing every other node >= 0.98 x
+    # before), GraphResizeTests.cs:60-93 (Count, Ids), bindings/__tests__/recall_test.py:18-34
+    n, dim = 2000, 128
+    x = normalize_f32(uniform(n, dim, 65537))
+    ix = Index(dim, "ucosine"); ix.set_collection_size(64); ix.set_insert_batch(1)
+    ids = ix.add(x)
+    ref = oracle.OracleIndex(dim, "ucosine", collection_size=64)
+    ref.add(x)
+    before = self_recall_at_1(ix, x, ids)
+    ix.remove(ids[1::2])
+    ref.remove(ids[1::2])
+    assert ix.count == n // 2 == ref.count
+    assert sorted(ix.ids().tolist()) == ids[0::2].tolist()
+    assert ix.ids().tolist() == ref.active_ids().tolist()          # ActiveSet order too
+    assert ix.graph_hash() == ref.graph_hash() and ix.entry_point == ref.entry_point
+    res, d = ix.knn_query(x[0::2], 10)
+    rres, rd = ref.knn_query(x[0::2], 10)
+    assert (res == rres).all() and d.tobytes() == rd.tobytes()
+    assert np.isin(res, ids[0::2]).all()                            # removed ids never come back
+    after = float((res[:, 0] == ids[0::2]).mean())
+    assert before * 0.98 < after
+    # vacated slots are reused LIFO by later adds (GraphData.cs:85-91), results stay in step
+    more = normalize_f32(uniform(300, dim, 777))
+    a, b = ix.add(more), ref.add(more)                              # both strictly sequential
+    assert (a == b).all() and a[0] == ids[1::2][-1]
+    assert ix.graph_hash() == ref.graph_hash()
+    res, d = ix.knn_query(x[:200], 5)
+    rres, rd = ref.knn_query(x[:200], 5)
+    assert (res == rres).all() and d.tobytes() == rd.tobytes()
+
+
+def test_remove_all_one_by_one_and_disabled_removals(Index):
+    # GraphResizeTests.cs:95-109 (Count after every Remove), ParametersTests.cs:87 (Remove throws)
+    x = uniform(200, 16, 5)
+    ix = Index(16); ix.set_collection_size(10)
+    ids = ix.add(x)
+    ref = oracle.OracleIndex(16, collection_size=10); ref.add_batched(x, 16384)
+    for k, i in enumerate(ids):
+        ix.remove([i]); ref.remove([i])
+        assert ix.count == 200 - k - 1
+        if k % 37 == 0:
+            assert ix.graph_hash() == ref.graph_hash() and ix.entry_point == ref.entry_point
+    assert ix.entry_point == -1
+    kid, kd = ix.knn_query(x[:2], 3)
+    assert (kid == -1).all() and np.isnan(kd).all()
+    assert ix.add(x[:3]).tolist() == ref.add_batched(x[:3], 16384).tolist()   # rebuilt from empty, reusing slots
+    iy = Index(16); iy.set_allow_removals(False)
+    iy.add(x)
+    with pytest.raises(RuntimeError, match="InvalidOperationException"):
+        iy.remove([0])
+    with pytest.raises(RuntimeError, match="not in the index"):
+        ix.remove([100000])

@@ -167,3 +167,40 @@ def test_range_query_results_within_radius_and_sorted():
     assert sum(len(a) for a in ids) > 200
     for a, b in zip(ids, d):
         assert (b <= 16.0).all() and (np.diff(b) >= 0).all() and len(set(a.tolist())) == len(a)
+
+
+def test_removal_reference_thresholds_and_structure():
+    # src/HNSWIndex.Tests/GraphTests.cs:122-171; GraphResizeTests.cs:60-109; recall_test.py:18-34
+    x = normalize_f32(uniform(2000, 128, 65537))
+    ix = oracle.OracleIndex(128, "ucosine")
+    ids = ix.add(x)
+    before = self_recall_at_1(ix, x, ids)
+    ix.remove(ids[1::2])
+    assert ix.count == 1000 and set(ix.active_ids().tolist()) == set(ids[0::2].tolist())
+    res, _ = ix.knn_query(x[0::2], 1)
+    assert before * 0.98 < float((res[:, 0] == ids[0::2]).mean())
+    act, lv = set(ix.active_ids().tolist()), ix.levels()
+    out_total = in_total = 0
+    for i in act:                                   # in/out balance and no edge to a removed node
+        for layer in range(lv[i] + 1):
+            o = ix.edges(i, layer)
+            out_total += o.size
+            in_total += ix.edges(i, layer, incoming=True).size
+            assert all(int(j) in act for j in o)
+    assert out_total == in_total
+    assert ix.add(uniform(3, 128, 9)).tolist() == [int(ids[1::2][-1]), int(ids[1::2][-2]), int(ids[1::2][-3])]  # LIFO slot reuse
+
+
+def test_remove_all_then_rebuild_and_disabled_removals():
+    x = uniform(300, 16, 1)
+    ix = oracle.OracleIndex(16, collection_size=10)
+    ids = ix.add(x)
+    for k, i in enumerate(ids):
+        ix.remove([i])
+        assert ix.count == 300 - k - 1
+    assert ix.entry_point == -1
+    assert ix.add(x[:2]).tolist() == [299, 298] and ix.entry_point == 299
+    iy = oracle.OracleIndex(16, allow_removals=False)
+    iy.add(x)
+    with pytest.raises(RuntimeError):
+        iy.remove([0])
