@@ -102,11 +102,6 @@ public:
     //  out_lists: ngroups x list_stride ints [cnt, ids...]: the final adjacency list of every group.
     bool link_batch(const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
                     const int *g_items, int ngroups, int max_edges0, int *out_lists, int list_stride);
-    // PruneOverflow for njobs adjacency lists.  recs: njobs x in_stride ints [node, cnt, ids...];
-    // job_max_edges[j] = MaxEdges(layer of job j).  out_sel / out_cnt: the new lists.
-    bool prune_batch(const int *recs, int njobs, int in_stride, const int *job_max_edges, int *out_sel, int sel_stride,
-                     int *out_cnt);
-
     // C-ABI conveniences (synchronous; validate ids on the host before launching).
     bool dist_query_batch(const float *queries, int nq, const int *offsets, const int *ids, float *out);
     bool dist_pair_batch(const int *a, const int *b, int n, float *out);
@@ -145,9 +140,9 @@ private:
     int *s_cnt_ = nullptr, *s_flag_ = nullptr;
     unsigned long long *s_evals_ = nullptr;
     size_t s_jobs_cap_ = 0, s_hits_cap_ = 0;
-    int *s_sel_ = nullptr, *s_in_ = nullptr, *s_jme_ = nullptr;
+    int *s_sel_ = nullptr;
     float *s_first_ = nullptr;
-    size_t s_sel_cap_ = 0, s_in_cap_ = 0, s_jme_cap_ = 0, s_first_cap_ = 0;
+    size_t s_sel_cap_ = 0, s_first_cap_ = 0;
     SearchHit *s_spill_ = nullptr;
     size_t s_spill_cap_ = 0;
     int *s_lk_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

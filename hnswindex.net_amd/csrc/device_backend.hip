@@ -842,40 +842,6 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
     }
 }
 
-// Insert, link half: GraphConnector.PruneOverflow (GraphConnector.cs:222-262) for one
-// overflowing adjacency list: distances node<->edges (:230-234), sort + heuristic (:235).
-// in: per job [node, cnt, ids[cnt]] (stride in_stride); out: new list.
-template <int METRIC>
-__global__ void __launch_bounds__(64)
-graph_prune_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, const int *__restrict__ in,
-                   int in_stride, int k_cap, int *__restrict__ out_sel, int sel_stride, int *__restrict__ out_cnt,
-                   const int *__restrict__ job_max_edges, unsigned long long *__restrict__ eval_counter)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SearchLds L = carve_lds(smem, k_cap, 0, dim);
-    const int lane = threadIdx.x;
-    const int job = blockIdx.x;
-    const int *rec = in + (size_t)job * in_stride;
-    const int node = rec[0], n = rec[1];
-    const float *q = rows + (size_t)node * dim;
-    double sb = 0.0;
-    if (METRIC == M_COS) sb = row_sn[node];
-    for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
-    for (int i = lane; i < n; i += 64) L.nbuf[i] = rec[2 + i];
-    __syncthreads();
-    unsigned long long evals = (unsigned long long)n;
-    measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, L.nbuf, L.dbuf, n, lane); // Distance(cand, node.Id) :233
-    __syncthreads();
-    for (int i = lane; i < n; i += 64) L.top[i] = ND{L.nbuf[i], L.dbuf[i]};
-    __syncthreads();
-    const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, n, job_max_edges[job], L, lane, evals);
-    for (int i = lane; i < rc; i += 64) out_sel[(size_t)job * sel_stride + i] = L.acc[i];
-    if (lane == 0) {
-        out_cnt[job] = rc;
-        atomicAdd(eval_counter, evals);
-    }
-}
-
 // Insert, link half, on the HBM mirror.  (a) new nodes' own lists.
 __global__ void __launch_bounds__(64)
 graph_write_rows_kernel(int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool,
@@ -977,6 +943,13 @@ __global__ void sqrt_rn_kernel(const double *in, double *out, int n)
 // ------------------------------------------------------------------------------------
 // host side of the context
 // ------------------------------------------------------------------------------------
+// C-ABI graph staging (hnswdev_graph_*): the host graph flattened layer by layer
+struct Device::HostGraphStage {
+    int n = 0, M = 0, stride0 = 0, strideU = 0, top = 0;
+    std::vector<int> level, adj0, pool;
+    std::vector<int64_t> upper;
+};
+
 static inline hipStream_t S(void *p) { return (hipStream_t)p; }
 
 bool Device::bind()
@@ -1025,7 +998,7 @@ Device::~Device()
     if (d_queries_) (void)hipFree(d_queries_);
     if (d_q_sn_) (void)hipFree(d_q_sn_);
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_in_, (void *)s_jme_, (void *)s_first_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_first_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -1479,50 +1452,6 @@ bool Device::link_batch(const int *rows, int nrows, int row_stride, const int *g
 }
 
 
-bool Device::prune_batch(const int *recs, int njobs, int in_stride, const int *job_max_edges, int *out_sel, int sel_stride, int *out_cnt)
-{
-    if (njobs <= 0) return true;
-    if (!recs || !job_max_edges || !out_sel || !out_cnt || in_stride < 3) { set_dev_error("prune_batch: bad argument"); return false; }
-    for (int j = 0; j < njobs; ++j) {
-        const int *r = recs + (size_t)j * in_stride;
-        bool ok = r[0] >= 0 && r[0] < n_rows_hw_ && r[1] >= 1 && r[1] <= in_stride - 2 && r[1] <= kNbufCap &&
-                  job_max_edges[j] >= 1 && job_max_edges[j] <= sel_stride;
-        for (int i = 0; ok && i < r[1]; ++i) ok = r[2 + i] >= 0 && r[2 + i] < n_rows_hw_;
-        if (!ok) { set_dev_error("prune_batch: record outside the uploaded rows / limits"); return false; }
-    }
-    if (!bind()) return false;
-    hipStream_t st = S(stream_);
-    if (!ensure_search_scratch(1, 0, 4)) return false;
-    if (!grow_dev(&s_in_, &s_in_cap_, (size_t)njobs * in_stride) || !grow_dev(&s_jme_, &s_jme_cap_, (size_t)njobs) ||
-        !grow_dev(&s_sel_, &s_sel_cap_, (size_t)njobs * sel_stride))
-        return false;
-    if ((size_t)njobs > s_jobs_cap_) { // s_cnt_ is sized with s_jobs_
-        if (!ensure_search_scratch(njobs, 0, 4)) return false;
-    }
-    HIP_OK(hipMemcpyAsync(s_in_, recs, sizeof(int) * (size_t)njobs * in_stride, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(s_jme_, job_max_edges, sizeof(int) * (size_t)njobs, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
-    const int k_cap = kNbufCap;
-    const size_t lds = search_lds_bytes(k_cap, 0, dim_);
-#define LAUNCH(M)                                                                                                        \
-    hipLaunchKernelGGL(graph_prune_kernel<M>, dim3(njobs), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, s_in_, in_stride, k_cap, \
-                       s_sel_, sel_stride, s_cnt_, s_jme_, s_evals_)
-    if (metric_ == M_SQ) LAUNCH(M_SQ);
-    else if (metric_ == M_COS) LAUNCH(M_COS);
-    else LAUNCH(M_UCOS);
-#undef LAUNCH
-    HIP_OK(hipGetLastError());
-    unsigned long long ev = 0;
-    HIP_OK(hipMemcpyAsync(out_sel, s_sel_, sizeof(int) * (size_t)njobs * sel_stride, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(out_cnt, s_cnt_, sizeof(int) * (size_t)njobs, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(&ev, s_evals_, sizeof(ev), hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    stats_.search_launches++;
-    stats_.search_evals += ev;
-    return true;
-}
-
-
 // Pinned host staging (grown on demand): DMA to/from pageable user memory runs at ~2 GB/s,
 // through a pinned bounce buffer at PCIe rate.
 void *Device::pinned_stage(size_t bytes)
@@ -1609,12 +1538,6 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
 }
 
 // ---- C-ABI graph staging (layer by layer) -------------------------------------------------
-struct Device::HostGraphStage {
-    int n = 0, M = 0, stride0 = 0, strideU = 0, top = 0;
-    std::vector<int> level, adj0, pool;
-    std::vector<int64_t> upper;
-};
-
 bool Device::graph_begin(int n, int max_edges, const int *levels)
 {
     if (n <= 0 || max_edges < 1 || !levels) { set_dev_error("graph_begin: bad argument"); return false; }
