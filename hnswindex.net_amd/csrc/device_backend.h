@@ -85,11 +85,13 @@ public:
     // the stable distance order (padded with -1 / NaN); out_flag: 1 where the candidate heap
     // outgrew LDS + spill capacity (caller re-runs that job on the lock-step path).  Synchronous.
     bool search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag);
-    // Insert, search half, fused on the device: traversal with beam k (= MaxCandidates) followed
-    // by RelativeNeighborPruning.  jobs[].qref must be ~item_id.  max_edges0 = MaxEdges(0) = 2M.
-    // out_sel: njobs x sel_stride selected ids; out_first: search distance of selected[0].
+    // Insert, search half, fused on the device: for every job (new item) the descent from
+    // (entry, entry_layer) to search_layer = the item's first layer, then on every layer from there
+    // down to 0 the traversal with beam k (= MaxCandidates) + RelativeNeighborPruning, the next
+    // layer entering at selected[0].  jobs[].qref must be ~item_id.  max_edges0 = MaxEdges(0) = 2M.
+    // out_sel: njobs x nlayers x sel_stride selected ids, out_cnt: njobs x nlayers (slot = layer).
     bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int *out_sel, int sel_stride,
-                             int *out_cnt, float *out_first, int *out_flag);
+                             int nlayers, int *out_cnt, int *out_flag);
     // Keeps the HBM graph mirror in step with nodes appended on the host since the last call:
     // levels / upper offsets of nodes [first, first+n) and the pool tail [pool_from, pool_len).
     // Returns false (with no error set) when capacity is exceeded: caller falls back to set_graph.
@@ -140,9 +142,8 @@ private:
     int *s_cnt_ = nullptr, *s_flag_ = nullptr;
     unsigned long long *s_evals_ = nullptr;
     size_t s_jobs_cap_ = 0, s_hits_cap_ = 0;
-    int *s_sel_ = nullptr;
-    float *s_first_ = nullptr;
-    size_t s_sel_cap_ = 0, s_first_cap_ = 0;
+    int *s_sel_ = nullptr, *s_lcnt_ = nullptr;
+    size_t s_sel_cap_ = 0, s_lcnt_cap_ = 0;
     SearchHit *s_spill_ = nullptr;
     size_t s_spill_cap_ = 0;
     int *s_lk_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -154,7 +155,7 @@ private:
     void *h_stage_ = nullptr;
     size_t h_stage_cap_ = 0;
     bool insert_search_pass(const SearchJob *jobs, int njobs, int k, int cand_cap, int max_edges0, int *out_sel, int sel_stride,
-                            int *out_cnt, float *out_first, int *out_flag);
+                            int nlayers, int *out_cnt, int *out_flag);
     void *ev0_ = nullptr, *ev1_ = nullptr;
     void *stream_ = nullptr;
     bool profiling_ = false;

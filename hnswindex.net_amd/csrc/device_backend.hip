@@ -799,23 +799,26 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     }
 }
 
-// Insert, search half, fused: ConnectAtLayer's SearchLayer + RelativeNeighborPruning
-// (GraphConnector.cs:189-190) for one (item, layer).  Output: the selected neighbour ids (in
-// selection order) and the search distance of selected[0] (the next layer's entry, :216).
+// Insert, search half, fused: for one new item, GraphConnector.AddNewConnections' whole loop
+// (GraphConnector.cs:172-181): FindEntryPoint, then for every layer of the item ConnectAtLayer's
+// SearchLayer + RelativeNeighborPruning (:189-190) with the next layer's entry = selected[0]
+// (:216).  One launch serves every layer of every item of a batch (the few multi-layer items
+// clear their visited bitset between layers).  Output per (job, layer): the selected ids in
+// selection order.  jobs[].search_layer = the item's first layer min(level, top).
 template <int METRIC>
 __global__ void __launch_bounds__(64)
 graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
-                           int *__restrict__ out_sel, int sel_stride, int *__restrict__ out_cnt, float *__restrict__ out_first_dist,
+                           int *__restrict__ out_sel, int sel_stride, int nlayers, int *__restrict__ out_cnt,
                            int *__restrict__ out_flag, unsigned long long *__restrict__ eval_counter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchLds L = carve_lds(smem, k, cand_cap, dim);
     const int lane = threadIdx.x;
     const int job = blockIdx.x;
-    const SearchJob jb = jobs[job];
+    SearchJob jb = jobs[job];
     unsigned *vis = visited + (size_t)job * (size_t)vis_words;
     const GraphView G{adj0, stride0, upper, pool, strideU};
     const int item = ~jb.qref;
@@ -824,19 +827,29 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
     if (METRIC == M_COS) sb = row_sn[item];
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
     unsigned long long evals = 0;
-    int top_n = 0;
-    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)job * spill_cap, spill_cap, vis, L, lane, top_n, evals);
-    int rc = 0;
-    float first = 0.f;
-    if (ok) {
-        const int max_edges = jb.search_layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
-        rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals);
-        first = L.top[0].dist; // selected[0] is cands[0] in both Heuristic paths
-        for (int i = lane; i < rc; i += 64) out_sel[(size_t)job * sel_stride + i] = L.acc[i];
+    bool ok = true;
+    const int first_layer = jb.search_layer;
+    for (int layer = first_layer; layer >= 0 && ok; --layer) {
+        if (layer != first_layer) { // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
+            __syncthreads();
+            for (long long w = lane; w < vis_words; w += 64) vis[w] = 0u;
+            __syncthreads();
+        }
+        int top_n = 0;
+        ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)job * spill_cap, spill_cap, vis, L, lane, top_n, evals);
+        if (!ok) break;
+        const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
+        const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals);
+        const size_t slot = (size_t)job * nlayers + layer;
+        for (int i = lane; i < rc; i += 64) out_sel[slot * sel_stride + i] = L.acc[i];
+        if (lane == 0) out_cnt[slot] = rc;
+        const int next_entry = __builtin_amdgcn_readfirstlane(L.acc[0]); // :216 selected[0] -> bestPeer of the next layer (:179)
+        jb.entry = next_entry;
+        jb.entry_layer = layer - 1;
+        jb.search_layer = layer - 1;
+        __syncthreads();
     }
     if (lane == 0) {
-        out_cnt[job] = rc;
-        out_first_dist[job] = first;
         out_flag[job] = ok ? 0 : 1;
         atomicAdd(eval_counter, evals);
     }
@@ -998,7 +1011,7 @@ Device::~Device()
     if (d_queries_) (void)hipFree(d_queries_);
     if (d_q_sn_) (void)hipFree(d_q_sn_);
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_first_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -1035,7 +1048,18 @@ bool Device::upload_rows(int first_id, int n, const float *rows)
         return false;
     }
     if (!bind()) return false;
-    HIP_OK(hipMemcpyAsync(d_rows_ + (size_t)first_id * dim_, rows, (size_t)n * dim_ * sizeof(float), hipMemcpyHostToDevice, S(stream_)));
+    {   // pageable -> pinned bounce buffer -> HBM, 64 MiB at a time
+        const size_t row_bytes = (size_t)dim_ * sizeof(float);
+        const size_t chunk_rows = std::max<size_t>(1, (64u << 20) / row_bytes);
+        char *hs = static_cast<char *>(pinned_stage(std::min<size_t>((size_t)n, chunk_rows) * row_bytes));
+        if (!hs) return false;
+        for (size_t r0 = 0; r0 < (size_t)n; r0 += chunk_rows) {
+            const size_t nr = std::min(chunk_rows, (size_t)n - r0);
+            memcpy(hs, rows + r0 * dim_, nr * row_bytes);
+            HIP_OK(hipMemcpyAsync(d_rows_ + ((size_t)first_id + r0) * dim_, hs, nr * row_bytes, hipMemcpyHostToDevice, S(stream_)));
+            HIP_OK(hipStreamSynchronize(S(stream_))); // the bounce buffer is reused
+        }
+    }
     if (metric_ == M_COS) {
         int blocks = (int)(((long long)n * 8 + 255) / 256);
         hipLaunchKernelGGL(row_sqrtnorm_kernel, dim3(blocks), dim3(256), 0, S(stream_), d_rows_, dim_, (long long)first_id, n, d_row_sn_);
@@ -1292,7 +1316,7 @@ static bool jobs_valid(const SearchJob *jobs, int njobs, long long g_n, long lon
 }
 
 bool Device::insert_search_pass(const SearchJob *jobs, int njobs, int k, int cand_cap, int max_edges0, int *out_sel, int sel_stride,
-                                int *out_cnt, float *out_first, int *out_flag)
+                                int nlayers, int *out_cnt, int *out_flag)
 {
     if (njobs <= 0) return true;
     if (!bind()) return false;
@@ -1301,7 +1325,7 @@ bool Device::insert_search_pass(const SearchJob *jobs, int njobs, int k, int can
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
     long long chunk = std::min<long long>(njobs, std::max<long long>(256, (8LL << 30) / (long long)std::max<size_t>(vis_bytes_per_job, 1)));
     if (!ensure_search_scratch(chunk, 0, vis_bytes_per_job)) return false;
-    if (!grow_dev(&s_sel_, &s_sel_cap_, (size_t)chunk * sel_stride) || !grow_dev(&s_first_, &s_first_cap_, (size_t)chunk)) return false;
+    if (!grow_dev(&s_sel_, &s_sel_cap_, (size_t)chunk * nlayers * sel_stride) || !grow_dev(&s_lcnt_, &s_lcnt_cap_, (size_t)chunk * nlayers)) return false;
     for (long long off = 0; off < njobs; off += chunk) {
         const int nj = (int)std::min<long long>(chunk, njobs - off);
         HIP_OK(hipMemcpyAsync(s_jobs_, jobs + off, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
@@ -1313,7 +1337,7 @@ bool Device::insert_search_pass(const SearchJob *jobs, int njobs, int k, int can
 #define LAUNCH(M)                                                                                                          \
     hipLaunchKernelGGL(graph_insert_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(), max_edges0, s_visited_, vis_words, s_sel_, sel_stride, \
-                       s_cnt_, s_first_, s_flag_, s_evals_)
+                       nlayers, s_lcnt_, s_flag_, s_evals_)
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
         else LAUNCH(M_UCOS);
@@ -1321,9 +1345,8 @@ bool Device::insert_search_pass(const SearchJob *jobs, int njobs, int k, int can
         HIP_OK(hipGetLastError());
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         unsigned long long ev = 0;
-        HIP_OK(hipMemcpyAsync(out_sel + (size_t)off * sel_stride, s_sel_, sizeof(int) * (size_t)nj * sel_stride, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(out_cnt + off, s_cnt_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(out_first + off, s_first_, sizeof(float) * (size_t)nj, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(out_sel + (size_t)off * nlayers * sel_stride, s_sel_, sizeof(int) * (size_t)nj * nlayers * sel_stride, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(out_cnt + (size_t)off * nlayers, s_lcnt_, sizeof(int) * (size_t)nj * nlayers, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(out_flag + off, s_flag_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(&ev, s_evals_, sizeof(ev), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
@@ -1341,16 +1364,17 @@ bool Device::insert_search_pass(const SearchJob *jobs, int njobs, int k, int can
 }
 
 bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int *out_sel, int sel_stride,
-                                 int *out_cnt, float *out_first, int *out_flag)
+                                 int nlayers, int *out_cnt, int *out_flag)
 {
     if (njobs <= 0) return true;
-    if (!jobs || !out_sel || !out_cnt || !out_first || !out_flag || k < 1 || sel_stride < max_edges0) { set_dev_error("insert_search_batch: bad argument"); return false; }
+    if (!jobs || !out_sel || !out_cnt || !out_flag || k < 1 || sel_stride < max_edges0 || nlayers < 1) { set_dev_error("insert_search_batch: bad argument"); return false; }
+    for (int i = 0; i < njobs; ++i) if (jobs[i].search_layer >= nlayers) { set_dev_error("insert_search_batch: nlayers too small"); return false; }
     if (g_n_ <= 0) { set_dev_error("insert_search_batch: no graph uploaded"); return false; }
     for (int i = 0; i < njobs; ++i) if (jobs[i].qref >= 0) { set_dev_error("insert_search_batch: qref must name a stored row"); return false; }
     if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("insert_search_batch: job outside the uploaded graph / rows"); return false; }
     const int cap = cand_lds_cap(k, dim_, true);
     if (search_lds_bytes(k, cap, dim_, true) > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
-    if (!insert_search_pass(jobs, njobs, k, cap, max_edges0, out_sel, sel_stride, out_cnt, out_first, out_flag)) return false;
+    if (!insert_search_pass(jobs, njobs, k, cap, max_edges0, out_sel, sel_stride, nlayers, out_cnt, out_flag)) return false;
     for (int i = 0; i < njobs; ++i) stats_.search_overflows += (uint64_t)(out_flag[i] != 0);
     return true;
 }

@@ -688,8 +688,8 @@ bool HnswIndex::search_half_lockstep(const std::vector<int> &bid, const std::vec
     return true;
 }
 
-// Graph-resident traversal: one fused kernel launch per layer (search + heuristic) for the whole
-// batch; items whose candidate heap outgrew LDS are redone on the lock-step path.
+// Graph-resident traversal: ONE fused kernel launch (descent + per-layer search + heuristic) for
+// the whole batch; items the device hands back are redone on the lock-step path.
 bool HnswIndex::search_half_device(const std::vector<int> &bid, Selection &sel, std::string &err)
 {
     { Tick t(g_pt.sync_graph); if (!sync_graph(err)) return false; }
@@ -698,7 +698,7 @@ bool HnswIndex::search_half_device(const std::vector<int> &bid, Selection &sel, 
     const int n = (int)bid.size();
     const int top = graph_.top_layer(), ep = graph_.entry;
     const int sel_stride = 2 * p_.max_edges;
-    std::vector<int> l0((size_t)n), next_entry((size_t)n, ep);
+    std::vector<int> l0((size_t)n);
     std::vector<char> redo((size_t)n, 0);
     int maxl = 0;
     for (int i = 0; i < n; ++i) {
@@ -707,29 +707,27 @@ bool HnswIndex::search_half_device(const std::vector<int> &bid, Selection &sel, 
         l0[(size_t)i] = std::min(lvl, top); // GraphConnector.cs:176
         maxl = std::max(maxl, l0[(size_t)i]);
     }
-    std::vector<SearchJob> jobs;
-    std::vector<int> who, out_sel, out_cnt, out_flag;
-    std::vector<float> out_first;
-    for (int L = maxl; L >= 0; --L) {
-        jobs.clear(); who.clear();
-        for (int i = 0; i < n; ++i) {
-            if (redo[(size_t)i] || l0[(size_t)i] < L) continue;
-            const int id = bid[(size_t)i];
-            // first layer of the item: FindEntryPoint from the top (:174); below: entry = selected[0] (:216,:179)
-            jobs.push_back(L == l0[(size_t)i] ? SearchJob{~id, ep, top, L} : SearchJob{~id, next_entry[(size_t)i], L, L});
-            who.push_back(i);
-        }
-        if (jobs.empty()) continue;
-        const int nj = (int)jobs.size();
-        out_sel.resize((size_t)nj * sel_stride); out_cnt.resize((size_t)nj); out_flag.resize((size_t)nj); out_first.resize((size_t)nj);
-        if (!dev_->insert_search_batch(jobs.data(), nj, p_.max_candidates, 2 * p_.max_edges, out_sel.data(), sel_stride,
-                                       out_cnt.data(), out_first.data(), out_flag.data())) { err = get_dev_error(); return false; }
-        for (int t = 0; t < nj; ++t) {
-            const int i = who[(size_t)t];
-            if (out_flag[(size_t)t]) { redo[(size_t)i] = 1; continue; }
-            const int *ids = out_sel.data() + (size_t)t * sel_stride;
-            sel[(size_t)i][(size_t)L].assign(ids, ids + out_cnt[(size_t)t]);
-            next_entry[(size_t)i] = ids[0];
+    // one launch: every item walks all its layers on the device; multi-layer items go first so
+    // that the longest traversals start with the launch
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return l0[(size_t)a] > l0[(size_t)b]; });
+    const int nlayers = maxl + 1;
+    std::vector<SearchJob> jobs((size_t)n);
+    for (int t = 0; t < n; ++t) {
+        const int i = order[(size_t)t];
+        jobs[(size_t)t] = SearchJob{~bid[(size_t)i], ep, top, l0[(size_t)i]}; // FindEntryPoint from the top (:174), first layer :176
+    }
+    std::vector<int> out_sel((size_t)n * nlayers * sel_stride), out_cnt((size_t)n * nlayers), out_flag((size_t)n);
+    if (!dev_->insert_search_batch(jobs.data(), n, p_.max_candidates, 2 * p_.max_edges, out_sel.data(), sel_stride, nlayers,
+                                   out_cnt.data(), out_flag.data())) { err = get_dev_error(); return false; }
+    for (int t = 0; t < n; ++t) {
+        const int i = order[(size_t)t];
+        if (out_flag[(size_t)t]) { redo[(size_t)i] = 1; continue; }
+        for (int L = l0[(size_t)i]; L >= 0; --L) {
+            const size_t slot = (size_t)t * nlayers + L;
+            const int *ids = out_sel.data() + slot * sel_stride;
+            sel[(size_t)i][(size_t)L].assign(ids, ids + out_cnt[slot]);
         }
     }
     std::vector<int> again;
@@ -881,6 +879,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
     fresh.reserve((size_t)count);
     bool any_reused = false;
     const int first_new = graph_.length;
+    graph_.reserve(graph_.length + count);
     for (int i = 0; i < count; ++i) {
         int lvl = level_from_uniform(rng_.next_single(), p_.distribution_rate);
         if (lvl < 0) { ids[(size_t)i] = -1; ++skipped_; continue; } // :82

@@ -296,6 +296,9 @@ struct Graph {
         level.reserve((size_t)capacity);
         upper.reserve((size_t)capacity);
         adj0.reserve((size_t)capacity * stride0);
+        removed.reserve((size_t)capacity);
+        dense.reserve((size_t)capacity);
+        sparse.reserve((size_t)capacity);
     }
     // GraphData.AddItem :85-115 + NewNode :224-242.  reuse: pop the most recently vacated slot.
     int add_node(int top_layer, bool reuse, bool *reused = nullptr)
