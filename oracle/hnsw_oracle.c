@@ -844,7 +844,7 @@ static int add_one(sctx_t *c, const float *v)
  *       (GraphConnector.cs:174-179, :189-190; next entry = selected[0], :216)
  *   link half, items in id order: OutEdges = selected (:192), back-edges and
  *       PruneOverflow (:196-214).
- * A batch is at most max(1, linked/32) items (capped by max_batch); an item whose level
+ * A batch is at most max(1, linked/16) items (capped by max_batch); an item whose level
  * exceeds the current top layer is inserted alone (the reference holds the entry-point lock
  * for it, GraphConnector.cs:27-41).  max_batch == 1 is exactly orc_add.
  * ---------------------------------------------------------------------------------- */
@@ -909,7 +909,7 @@ ORC_API int orc_add_batched(void *h, const float *v, int n, int *out_ids, int ma
             new_ep = 1;
         } else {
             int linked = ix->count - (m - p); /* nodes already linked (== the id when nothing was ever removed) */
-            int b = linked / 32;
+            int b = linked / 16;
             if (b < 1) b = 1;
             if (b > max_batch) b = max_batch;
             while (nb < b && p + nb < m && ix->nodes[ids[p + nb]].max_layer <= top) nb++;
