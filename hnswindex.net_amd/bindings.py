@@ -81,6 +81,10 @@ lib.hnsw_get_last_error_utf8.argtypes = [ct.c_void_p, ct.c_int]
 for _name in ("hnsw_mi355x_count", "hnsw_mi355x_length", "hnsw_mi355x_entry_point", "hnsw_mi355x_reset_stats"):
     getattr(lib, _name).restype = ct.c_int
     getattr(lib, _name).argtypes = [ct.c_void_p]
+lib.hnsw_mi355x_set_queries.restype = ct.c_int
+lib.hnsw_mi355x_set_queries.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int]
+lib.hnsw_mi355x_knn_query_resident.restype = ct.c_int
+lib.hnsw_mi355x_knn_query_resident.argtypes = [ct.c_void_p, ct.c_int, _I, _F]
 lib.hnsw_mi355x_active_ids.restype = ct.c_int
 lib.hnsw_mi355x_active_ids.argtypes = [ct.c_void_p, _I, ct.c_int]
 lib.hnsw_mi355x_node_max_layer.restype = ct.c_int
@@ -282,6 +286,21 @@ class Index:
                 dists.append(np.ctypeslib.as_array(ct.cast(dists_pp[i], _F), shape=(m,)).copy())
         finally:
             lib.hnsw_free_results(ids_pp, dists_pp, n)
+        return ids, dists
+
+    # ---- measurement aid: query set resident in HBM across calls ----
+    def set_resident_queries(self, queries: npt.ArrayLike):
+        q = _as_2d_f32(queries, self.dim)
+        self._resident_n = int(q.shape[0])
+        if lib.hnsw_mi355x_set_queries(self._h, q.ctypes.data_as(_F), self._resident_n, self.dim) < 0:
+            raise RuntimeError(last_error())
+
+    def knn_query_resident(self, k: int):
+        n = self._resident_n
+        ids = np.empty((n, k), dtype=np.int32)
+        dists = np.empty((n, k), dtype=np.float32)
+        if lib.hnsw_mi355x_knn_query_resident(self._h, k, ids.ctypes.data_as(_I), dists.ctypes.data_as(_F)) < 0:
+            raise RuntimeError(last_error())
         return ids, dists
 
     # ---- introspection (parity checks, measurement) ----

@@ -176,6 +176,21 @@ API int hnsw_set_distribution_rate(float dist_rate) // :247 -- crosses the ABI a
 
 // ---- introspection / counters ----
 API int hnsw_mi355x_count(void *h) { return h ? static_cast<HnswIndex *>(h)->count() : 0; }
+// measurement aid: queries resident in HBM across calls (bench.py's timed region)
+API int hnsw_mi355x_set_queries(void *h, const float *queries, int count, int dim)
+{
+    if (!h || !queries || count <= 0 || dim <= 0) return -1;
+    std::string err;
+    if (static_cast<HnswIndex *>(h)->set_resident_queries(queries, count, dim, err) < 0) { set_error(err); return -1; }
+    return 0;
+}
+API int hnsw_mi355x_knn_query_resident(void *h, int k, int *out_ids, float *out_dists)
+{
+    if (!h || !out_ids || !out_dists) return -1;
+    std::string err;
+    if (static_cast<HnswIndex *>(h)->knn_query_resident(k, out_ids, out_dists, err) < 0) { set_error(err); return -1; }
+    return 0;
+}
 API int hnsw_mi355x_length(void *h) { return h ? static_cast<HnswIndex *>(h)->graph().length : 0; }
 API int hnsw_mi355x_active_ids(void *h, int *out, int cap)
 {

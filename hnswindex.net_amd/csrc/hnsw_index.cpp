@@ -992,10 +992,29 @@ int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *o
         for (long long j = 0; j < (long long)count * std::max(k, 0); ++j) { out_ids[j] = -1; out_dists[j] = std::numeric_limits<float>::quiet_NaN(); }
         return 0;
     }
+    if (set_resident_queries(queries, count, dim, err) < 0) return -1;
+    return knn_query_resident(k, out_ids, out_dists, err);
+}
+
+int HnswIndex::set_resident_queries(const float *queries, int count, int dim, std::string &err)
+{
     if (!ensure_dim(dim, err)) return -1;
-    { Tick t(g_pt.set_queries); if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; } }
+    Tick t(g_pt.set_queries);
+    if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; }
+    resident_queries_ = count;
+    return 0;
+}
+
+int HnswIndex::knn_query_resident(int k, int *out_ids, float *out_dists, std::string &err)
+{
+    const int count = resident_queries_;
+    if (count <= 0) return 0;
+    if (k < 1 || graph_.entry < 0 || graph_.count <= 0) {
+        for (long long j = 0; j < (long long)count * std::max(k, 0); ++j) { out_ids[j] = -1; out_dists[j] = std::numeric_limits<float>::quiet_NaN(); }
+        return 0;
+    }
     if (p_.device_traversal && dev_->traversal_fits(std::max(p_.min_nn, k), false, p_.max_edges))
-        return knn_query_device(queries, count, k, out_ids, out_dists, err);
+        return knn_query_device(nullptr, count, k, out_ids, out_dists, err);
     return knn_query_lockstep(nullptr, count, k, out_ids, out_dists, err);
 }
 

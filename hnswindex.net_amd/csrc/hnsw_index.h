@@ -40,6 +40,11 @@ public:
     // hnsw_knn_query: 0 or -1.
     int knn_query(const float *queries, int count, int dim, int k, int *out_ids, float *out_dists, std::string &err);
 
+    // Measurement aid: upload a query set once (resident in HBM), then run KnnQuery on it any
+    // number of times without host->device traffic for the inputs.
+    int set_resident_queries(const float *queries, int count, int dim, std::string &err);
+    int knn_query_resident(int k, int *out_ids, float *out_dists, std::string &err);
+
     // hnsw_range_query (HNSWIndex.RangeQuery, src/HNSWIndex/HNSWIndex.cs:144-168): per query the
     // in-range results ordered by distance.  Host lock-step traversal.
     int range_query(const float *queries, int count, int dim, float range, std::vector<std::vector<NodeDist>> &out, std::string &err);
@@ -80,6 +85,7 @@ private:
     int device_ordinal_ = 0;
     int threads_ = 1;
     bool profiling_ = false;
+    int resident_queries_ = 0;
     bool graph_dirty_ = true;       // HBM mirror needs a full re-upload
     long long dev_pool_len_ = 0;    // pool ints already mirrored
     std::vector<int> grp_of_node0_; // link half: group index per layer-0 neighbour (-1 = none)

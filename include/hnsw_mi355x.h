@@ -103,6 +103,12 @@ int hnsw_mi355x_set_host_threads(int threads);
  * 0 = traversal on the host, distances batched to the device step by step.  Same results. */
 int hnsw_mi355x_set_device_traversal(int enabled);
 
+/* Measurement aid: hnsw_mi355x_set_queries uploads a query set (count x dim) once; every later
+ * hnsw_mi355x_knn_query_resident(k) is hnsw_knn_query on that set with the inputs already in HBM
+ * (out arrays: count x k). */
+int hnsw_mi355x_set_queries(void *handle, const float *queries, int count, int dim);
+int hnsw_mi355x_knn_query_resident(void *handle, int k, int *out_ids, float *out_dists);
+
 /* Graph introspection for parity checks (reads host state only). */
 int hnsw_mi355x_count(void *handle);   /* HNSWIndex.Count: live items */
 int hnsw_mi355x_length(void *handle);  /* slots ever allocated (ids are < length) */

@@ -347,3 +347,14 @@ def test_remove_all_one_by_one_and_disabled_removals(Index):
         iy.remove([0])
     with pytest.raises(RuntimeError, match="not in the index"):
         ix.remove([100000])
+
+
+def test_resident_query_set_gives_the_same_answers(Index):
+    x, q = uniform(3000, 64, 141), uniform(400, 64, 142)
+    ix = Index(64); ix.set_collection_size(3000)
+    ix.add(x)
+    a_ids, a_d = ix.knn_query(q, 10)
+    ix.set_resident_queries(q)
+    for _ in range(2):
+        b_ids, b_d = ix.knn_query_resident(10)
+        assert (a_ids == b_ids).all() and a_d.tobytes() == b_d.tobytes()
