@@ -249,6 +249,8 @@ def main():
             "add_mode": f"snapshot-batched, cap {a.insert_batch}", "parallelism": f"query-shard x{world}, index replicated",
         },
         "recall_at_10": round(recall, 4),
+        "recall_note": "exact brute-force ground truth; i.i.d. uniform data (the reference's test distribution) has no "
+                       "neighbourhood structure at this size -- the CPU path returns the same ids (see cpu_baseline)",
         "pcie_inclusive_queries_per_sec": round(nq_total / dt_pcie, 1),
         "add_per_sec": round(a.n / build_s, 1), "build_seconds": round(build_s, 2),
         "build_evals": build_stats["evals"] + build_stats["search_evals"],
