@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Copies the summaries produced by tools/run_profiles.sh (gpurun_out/profiles/) into profiles/
+under the round's prefix and derives rN_pmc_traffic.json.   python tools/install_profiles.py r1"""
+import json
+import re
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+src, dst, r = ROOT / "gpurun_out" / "profiles", ROOT / "profiles", sys.argv[1]
+shutil.copy(src / "s_kernel_stats.csv", dst / f"{r}_bench_1m_kernel_stats.csv")
+shutil.copy(src / "kernel_stats.json", dst / f"{r}_bench_1m_kernel_stats.json")
+shutil.copy(src / "pmc_fetch.json", dst / f"{r}_pmc_fetch_size.json")
+shutil.copy(src / "pmc_write.json", dst / f"{r}_pmc_write_size.json")
+shutil.copy(src / "pmc_calibration.json", dst / f"{r}_pmc_calibration_kbench.json")
+(dst / f"{r}_pmc_calibration_kbench.log").write_text("".join(l for l in open(src / "kbench_calibration.log") if l.startswith(("N=", "v1"))))
+for f in ("bench_under_rocprof", "bench_pmc_fetch", "bench_pmc_write"):
+    (dst / f"{r}_{f}.json").write_text("".join(l for l in open(src / f"{f}.log") if l.startswith('{"metric"')))
+plain = ROOT / "gpurun_out" / "bench_1m_final.log"
+if plain.exists():
+    (dst / f"{r}_bench_1m_plain.json").write_text("".join(l for l in open(plain) if l.startswith('{"metric"')))
+K = "void hnsw::graph_search_kernel<0>"
+fetch = json.load(open(dst / f"{r}_pmc_fetch_size.json"))["counters"][K]["FETCH_SIZE"]["avg_per_dispatch"]
+write = json.load(open(dst / f"{r}_pmc_write_size.json"))["counters"][K]["WRITE_SIZE"]["avg_per_dispatch"]
+cal = json.load(open(dst / f"{r}_pmc_calibration_kbench.json"))["counters"]["v1"]["FETCH_SIZE"]["avg_per_dispatch"]
+m = re.search(r"single ([0-9.]+) us \(([0-9.]+) GB/s\)", [l for l in open(dst / f"{r}_pmc_calibration_kbench.log") if l.startswith("v1")][0])
+known = float(m.group(2)) * 1e9 * float(m.group(1)) * 1e-6
+factor = known / (cal * 1024)
+b = json.load(open(dst / f"{r}_bench_pmc_fetch.json"))
+alg = b["roofline"]["evals_per_launch"] * b["roofline"]["bytes_per_eval"]
+out = {"round": int(r[1:]), "kernel": "graph_search_kernel<sq_euclid>",
+       "workload": {"n": 1000000, "dim": 128, "nq": 10000, "ef_search": 128, "k": 10, "max_edges": 16},
+       "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
+       "fetch_calibration": {"method": "tools/kbench (same 8-lane strided-dword row gather), 32768 slots x ~21 distinct random 512-B rows of a 2 GB matrix",
+                             "known_bytes_per_launch": known, "FETCH_SIZE_KB_per_launch": cal, "factor": factor},
+       "traffic_bytes_per_launch": fetch * 1024 * factor + write * 1024, "algorithmic_bytes_per_launch": alg}
+out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / alg
+json.dump(out, open(dst / f"{r}_pmc_traffic.json", "w"), indent=1)
+ks = json.load(open(dst / f"{r}_bench_1m_kernel_stats.json"))
+for k in ks["kernel_stats"]:
+    print(k["name"][:60], k["calls"], round(k["total_ns"] / 1e9, 3), "s  avg", round(k["avg_ns"] / 1e3, 1), "us")
+for f in (f"{r}_bench_under_rocprof", f"{r}_bench_1m_plain"):
+    j = json.load(open(dst / f"{f}.json"))
+    print(f, j["value"], j["add_per_sec"], j["roofline"]["avg_launch_us"], j["roofline"]["frac"], j.get("cpu_baseline") and j["cpu_baseline"]["value"])
+print("traffic/algorithmic", out["traffic_over_algorithmic"], "factor", factor)
