@@ -46,14 +46,22 @@ def parse():
     p.add_argument("--recall-queries", type=int, default=1000)
     p.add_argument("--cpu-queries", type=int, default=4000, help="bounded cpu_baseline sample (all-cores leg)")
     p.add_argument("--cpu-adds", type=int, default=3000, help="bounded cpu_baseline sample of sequential inserts")
+    p.add_argument("--data", choices=["uniform", "clustered"], default="uniform",
+                   help="uniform: i.i.d. U[0,1) (the reference's test data, BASELINE.md); clustered: 1000-centre Gaussian "
+                        "mixture, only to show recall on data that has neighbourhood structure")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--traversal", choices=["device", "host"], default="device",
                    help="device: graph-resident search kernel (default); host: lock-step traversal on host threads")
     return p.parse_args()
 
 
-def make_data(n, dim, seed, metric):
-    x = np.random.default_rng(seed).random((n, dim), dtype=np.float32)  # Utils.cs:35-49: uniform [0,1)
+def make_data(n, dim, seed, metric, kind="uniform"):
+    rng = np.random.default_rng(seed)
+    if kind == "clustered":
+        centres = np.random.default_rng(4242).random((1000, dim), dtype=np.float32)
+        x = centres[rng.integers(0, 1000, n)] + (0.05 * rng.standard_normal((n, dim))).astype(np.float32)
+    else:
+        x = rng.random((n, dim), dtype=np.float32)  # Utils.cs:35-49: uniform [0,1)
     if metric == "ucosine":
         x = (x / np.sqrt((x * x).sum(axis=1, dtype=np.float32, keepdims=True))).astype(np.float32)
     return x
@@ -101,7 +109,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---------------- setup (untimed): data, index build, resident queries ----------------
-    x = make_data(a.n, a.dim, 65537, a.metric)
+    x = make_data(a.n, a.dim, 65537, a.metric, a.data)
     ix = Index(a.dim, a.metric)
     ix.set_collection_size(a.n)            # avoid the doubling resize (GraphData.cs:98-111)
     ix.set_max_edges(a.max_edges)
@@ -124,7 +132,7 @@ def main():
     build_stats = ix.stats()
 
     nq_total = a.nq * world
-    q_all = make_data(nq_total, a.dim, 65538, a.metric)  # queries distinct from the base vectors
+    q_all = make_data(nq_total, a.dim, 65538, a.metric, a.data)  # queries distinct from the base vectors
 
     # this rank's shard of the query set is uploaded ONCE, before the timed region: the timed steps
     # start with their inputs resident in HBM (per-step PCIe traffic: the k ids + distances back)
@@ -219,7 +227,7 @@ def main():
         parity_ids = bool((c_ids == res_ids[:nm]).all())
         parity_d = bool(c_d.tobytes() == np.ascontiguousarray(res_d[:nm]).tobytes())
         # Add baseline: sequential inserts of fresh vectors into the same 1M graph, one thread
-        extra = make_data(a.cpu_adds, a.dim, 65539, a.metric)
+        extra = make_data(a.cpu_adds, a.dim, 65539, a.metric, a.data)
         t0 = time.perf_counter(); ref.add(extra); ta = time.perf_counter() - t0
         cpu = {
             "value": round(nm / tm, 1), "unit": "queries/s", "cores": cores, "kind": "port",
@@ -239,7 +247,7 @@ def main():
     out = {
         "metric": "knn_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if a.data == "uniform" else "synthetic (clustered)",
         "config": {
             "workload": f"{cfg_name}: {a.n}x{a.dim} f32 {a.metric}, M={a.max_edges} efConstruction={a.ef_construction} "
                         f"efSearch={a.ef_search} k={a.k}; step = batched knn_query of {a.nq} queries per GPU "
