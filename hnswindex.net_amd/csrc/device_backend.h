@@ -76,6 +76,8 @@ public:
     // Mirrors the host adjacency in HBM (layer 0: n x stride0 ints [count, e...]; upper layers:
     // per-node offset into a pool of strideU-int blocks).  Full replace.
     long long graph_nodes() const { return g_n_; }
+    // capacity of the kernels' id / distance scratch: the longest adjacency list, rounded up to 8
+    int nbcap() const { int m = (g_stride0_ > g_strideU_ ? g_stride0_ : g_strideU_) - 1; m = (m + 7) & ~7; return m < 8 ? 8 : m; }
     // Can the graph-resident kernels run this shape?  (LDS budget for beam width k at this dim;
     // MaxEdges <= 63.)  When not, callers use the host lock-step traversal instead.
     bool traversal_fits(int k, bool with_heuristic, int max_edges) const;

@@ -414,7 +414,7 @@ __device__ __forceinline__ void measure_all(const float *rows, const double *row
 }
 
 constexpr int kSpillCap = 8192; // candidate-heap entries per traversal that may spill to HBM
-constexpr int kNbufCap = 136; // >= 2*M + 1 (checked on the host in set_graph)
+constexpr int kNbufCap = 136; // upper bound of the id / distance scratch (2*M + 1 <= 128, set_graph)
 
 // LDS carve-up shared by the traversal kernels
 struct SearchLds {
@@ -422,30 +422,31 @@ struct SearchLds {
     ND *cand;   // cand_cap
     float *qs;  // dim (padded to 4)
     float *qs2; // dim (padded to 4): second vector (heuristic / prune)
-    int *nbuf;  // kNbufCap
-    float *dbuf; // kNbufCap
-    int *acc;   // kNbufCap: accepted ids of the heuristic
+    int *nbuf;  // nbcap
+    float *dbuf; // nbcap
+    int *acc;   // nbcap: accepted ids of the heuristic
     int *stk;   // 3 * 40: introsort work stack
 };
 // heur: also room for the heuristic (second vector, accepted ids, introsort stack)
-__host__ __device__ inline size_t search_lds_bytes(int k, int cand_cap, int dim, bool heur = true)
+// nbcap: capacity of the id / distance scratch = longest adjacency list, rounded up to 8
+__host__ __device__ inline size_t search_lds_bytes(int k, int cand_cap, int dim, bool heur, int nbcap)
 {
-    size_t b = sizeof(ND) * (size_t)(k + 1 + cand_cap) + sizeof(float) * (size_t)((dim + 3) & ~3) + 2u * 4u * kNbufCap;
-    if (heur) b += sizeof(float) * (size_t)((dim + 3) & ~3) + 4u * kNbufCap + 4u * 3u * 40u;
+    size_t b = sizeof(ND) * (size_t)(k + 1 + cand_cap) + sizeof(float) * (size_t)((dim + 3) & ~3) + 2u * 4u * (size_t)nbcap;
+    if (heur) b += sizeof(float) * (size_t)((dim + 3) & ~3) + 4u * (size_t)nbcap + 4u * 3u * 40u;
     return b;
 }
-__device__ __forceinline__ SearchLds carve_lds(unsigned char *smem, int k, int cand_cap, int dim)
+__device__ __forceinline__ SearchLds carve_lds(unsigned char *smem, int k, int cand_cap, int dim, int nbcap)
 {
     SearchLds L;
     L.top = reinterpret_cast<ND *>(smem);
     L.cand = L.top + (k + 1);
     L.qs = reinterpret_cast<float *>(L.cand + cand_cap);
     L.nbuf = reinterpret_cast<int *>(L.qs + ((dim + 3) & ~3));
-    L.dbuf = reinterpret_cast<float *>(L.nbuf + kNbufCap);
+    L.dbuf = reinterpret_cast<float *>(L.nbuf + nbcap);
     // heuristic-only regions (present when the launch sized LDS with heur = true)
-    L.qs2 = L.dbuf + kNbufCap;
+    L.qs2 = L.dbuf + nbcap;
     L.acc = reinterpret_cast<int *>(L.qs2 + ((dim + 3) & ~3));
-    L.stk = L.acc + kNbufCap;
+    L.stk = L.acc + nbcap;
     return L;
 }
 
@@ -734,10 +735,10 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
                     const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill, int spill_cap,
                     unsigned *__restrict__ visited, long long vis_words, int k_out, int *__restrict__ out_ids,
                     float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
-                    unsigned long long *__restrict__ eval_counter)
+                    unsigned long long *__restrict__ eval_counter, int nbcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SearchLds L = carve_lds(smem, k, cand_cap, dim);
+    const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
     const int job = blockIdx.x;
     const SearchJob jb = jobs[job];
@@ -812,10 +813,10 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
                            int *__restrict__ out_sel, int sel_stride, int nlayers, int *__restrict__ out_cnt,
-                           int *__restrict__ out_flag, unsigned long long *__restrict__ eval_counter)
+                           int *__restrict__ out_flag, unsigned long long *__restrict__ eval_counter, int nbcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SearchLds L = carve_lds(smem, k, cand_cap, dim);
+    const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
     const int job = blockIdx.x;
     SearchJob jb = jobs[job];
@@ -877,10 +878,10 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
                   int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
                   const int *__restrict__ g_node, const int *__restrict__ g_layer, const int *__restrict__ g_off,
                   const int *__restrict__ g_items, int max_edges0, int k_cap, int *__restrict__ out_lists, int list_stride,
-                  unsigned long long *__restrict__ eval_counter)
+                  unsigned long long *__restrict__ eval_counter, int nbcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SearchLds L = carve_lds(smem, k_cap, 0, dim);
+    const SearchLds L = carve_lds(smem, k_cap, 0, dim, nbcap);
     const int lane = threadIdx.x;
     const int g = blockIdx.x;
     const int node = g_node[g], layer = g_layer[g];
@@ -1256,11 +1257,11 @@ bool Device::set_graph(const int *adj0, long long n, int stride0, const int *lev
 // near 500 entries at ef = 128), the rest spills to HBM (SpillHeap).  A smaller LDS footprint means
 // more resident waves to hide memory latency: 7.6 -> 6.1 ms per 10k-query launch going from 1024
 // to 512 entries.  Beyond LDS + spill capacity the traversal is flagged for the lock-step path.
-static int cand_lds_cap(int k, int dim, bool heur)
+static int cand_lds_cap(int k, int dim, bool heur, int nbcap)
 {
     int cap = std::min(std::max(4 * k, 256), 4096);
     if (const char *e = std::getenv("HNSW_MI355X_CAND_CAP")) cap = std::max(1, std::atoi(e)); // tests: force spill / hand-back
-    while (cap > 64 && search_lds_bytes(k, cap, dim, heur) > 64 * 1024) cap /= 2;
+    while (cap > 64 && search_lds_bytes(k, cap, dim, heur, nbcap) > 64 * 1024) cap /= 2;
     return cap;
 }
 static int spill_cap_for_tests()
@@ -1333,11 +1334,11 @@ bool Device::insert_search_pass(const SearchJob *jobs, int njobs, int k, int can
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-        const size_t lds = search_lds_bytes(k, cand_cap, dim_);
+        const size_t lds = search_lds_bytes(k, cand_cap, dim_, true, nbcap());
 #define LAUNCH(M)                                                                                                          \
     hipLaunchKernelGGL(graph_insert_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(), max_edges0, s_visited_, vis_words, s_sel_, sel_stride, \
-                       nlayers, s_lcnt_, s_flag_, s_evals_)
+                       nlayers, s_lcnt_, s_flag_, s_evals_, nbcap())
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
         else LAUNCH(M_UCOS);
@@ -1372,8 +1373,8 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     if (g_n_ <= 0) { set_dev_error("insert_search_batch: no graph uploaded"); return false; }
     for (int i = 0; i < njobs; ++i) if (jobs[i].qref >= 0) { set_dev_error("insert_search_batch: qref must name a stored row"); return false; }
     if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("insert_search_batch: job outside the uploaded graph / rows"); return false; }
-    const int cap = cand_lds_cap(k, dim_, true);
-    if (search_lds_bytes(k, cap, dim_, true) > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
+    const int cap = cand_lds_cap(k, dim_, true, nbcap());
+    if (search_lds_bytes(k, cap, dim_, true, nbcap()) > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
     if (!insert_search_pass(jobs, njobs, k, cap, max_edges0, out_sel, sel_stride, nlayers, out_cnt, out_flag)) return false;
     for (int i = 0; i < njobs; ++i) stats_.search_overflows += (uint64_t)(out_flag[i] != 0);
     return true;
@@ -1382,8 +1383,9 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
 bool Device::traversal_fits(int k, bool with_heuristic, int max_edges) const
 {
     if (k < 1 || 2 * max_edges + 1 > 128) return false;
-    const int cap = cand_lds_cap(k, dim_, with_heuristic);
-    return search_lds_bytes(k, cap, dim_, with_heuristic) <= 64 * 1024 && search_lds_bytes(kNbufCap, 0, dim_, true) <= 64 * 1024;
+    const int nb = std::max(8, (2 * max_edges + 1 + 7) & ~7);
+    const int cap = cand_lds_cap(k, dim_, with_heuristic, nb);
+    return search_lds_bytes(k, cap, dim_, with_heuristic, nb) <= 64 * 1024 && search_lds_bytes(nb, 0, dim_, true, nb) <= 64 * 1024;
 }
 
 bool Device::graph_append_nodes(long long first, long long n, const int *level, const int64_t *upper, const int *pool,
@@ -1425,7 +1427,7 @@ bool Device::link_batch(const int *rows, int nrows, int row_stride, const int *g
         if (g_node[g] < 0 || g_node[g] >= g_n_ || g_layer[g] < 0 || g_off[g + 1] < g_off[g]) { set_dev_error("link_batch: group outside the graph"); return false; }
     for (int t = 0; t < total; ++t)
         if (g_items[t] < 0 || g_items[t] >= g_n_) { set_dev_error("link_batch: item outside the graph"); return false; }
-    if (list_stride < max_edges0 + 1 || max_edges0 + 1 > kNbufCap) { set_dev_error("link_batch: list stride too small"); return false; }
+    if (list_stride < max_edges0 + 1 || max_edges0 + 1 > nbcap()) { set_dev_error("link_batch: list stride too small"); return false; }
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     if (!ensure_search_scratch(1, 0, 4)) return false;
@@ -1444,12 +1446,12 @@ bool Device::link_batch(const int *rows, int nrows, int row_stride, const int *g
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-        const int k_cap = kNbufCap;
-        const size_t lds = search_lds_bytes(k_cap, 0, dim_);
+        const int k_cap = nbcap();
+        const size_t lds = search_lds_bytes(k_cap, 0, dim_, true, nbcap());
 #define LAUNCH(M)                                                                                                          \
     hipLaunchKernelGGL(graph_link_kernel<M>, dim3(ngroups), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_,  \
                        g_upper_, g_pool_, g_strideU_, s_lk_[1], s_lk_[1] + ngroups, s_lk_[2], s_lk_[3], max_edges0, k_cap,    \
-                       s_lk_[4], list_stride, s_evals_)
+                       s_lk_[4], list_stride, s_evals_, nbcap())
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
         else LAUNCH(M_UCOS);
@@ -1499,8 +1501,8 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     if (!jobs || !out_ids || !out_d || !out_flag || k < 1 || k_out < 1) { set_dev_error("search_batch: bad argument"); return false; }
     if (g_n_ <= 0) { set_dev_error("search_batch: no graph uploaded"); return false; }
     if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("search_batch: job outside the uploaded graph / rows / queries"); return false; }
-    const int cand_cap = cand_lds_cap(k, dim_, false);
-    const size_t lds = search_lds_bytes(k, cand_cap, dim_, false);
+    const int cand_cap = cand_lds_cap(k, dim_, false, nbcap());
+    const size_t lds = search_lds_bytes(k, cand_cap, dim_, false, nbcap());
     if (lds > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
     if (!bind()) return false;
     hipStream_t st = S(stream_);
@@ -1531,7 +1533,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
 #define LAUNCH(M)                                                                                                          \
     hipLaunchKernelGGL(graph_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_,     \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_)
+                       spill_cap_for_tests(), s_visited_, vis_words, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap())
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
         else LAUNCH(M_UCOS);
