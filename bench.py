@@ -30,8 +30,8 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--n", "--index-size", dest="n", type=int, default=1_000_000, help="indexed vectors (BASELINE C2: 1M)")
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--metric", default="sq_euclid")

@@ -42,6 +42,7 @@ struct SearchJob {
     int entry;        // entry node id
     int entry_layer;  // layer the descent starts at (== search_layer: no descent)
     int search_layer; // layer of the beam search
+    int aux;          // insert search: index of the item's first upper-layer output slot (-1: none)
 };
 struct SearchHit {
     int id;
@@ -90,10 +91,16 @@ public:
     // Insert, search half, fused on the device: for every job (new item) the descent from
     // (entry, entry_layer) to search_layer = the item's first layer, then on every layer from there
     // down to 0 the traversal with beam k (= MaxCandidates) + RelativeNeighborPruning, the next
-    // layer entering at selected[0].  jobs[].qref must be ~item_id.  max_edges0 = MaxEdges(0) = 2M.
-    // out_sel: njobs x nlayers x sel_stride selected ids, out_cnt: njobs x nlayers (slot = layer).
-    bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int *out_sel, int sel_stride,
-                             int nlayers, int *out_cnt, int *out_flag);
+    // layer entering at selected[0].  jobs[].qref must be ~item_id; jobs[].aux = the item's first
+    // upper-layer output slot (layer L >= 1 goes to slot aux + L - 1), n_upper = slots in total.
+    // Results stay in pinned host buffers owned by the context (valid until the next call):
+    //   sel0 [njobs x sel_stride] / cnt0 [njobs]: layer 0;  selU [n_upper x sel_stride] / cntU;
+    //   flag [njobs]: 1 = handed back.  sel_stride = max_edges0 = MaxEdges(0) = 2M.
+    struct InsertResults {
+        const int *sel0, *cnt0, *selU, *cntU, *flag;
+        int sel_stride;
+    };
+    bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res);
     // Keeps the HBM graph mirror in step with nodes appended on the host since the last call:
     // levels / upper offsets of nodes [first, first+n) and the pool tail [pool_from, pool_len).
     // Returns false (with no error set) when capacity is exceeded: caller falls back to set_graph.
@@ -144,8 +151,10 @@ private:
     int *s_cnt_ = nullptr, *s_flag_ = nullptr;
     unsigned long long *s_evals_ = nullptr;
     size_t s_jobs_cap_ = 0, s_hits_cap_ = 0;
-    int *s_sel_ = nullptr, *s_lcnt_ = nullptr;
-    size_t s_sel_cap_ = 0, s_lcnt_cap_ = 0;
+    int *s_sel_ = nullptr, *s_lcnt_ = nullptr, *s_selU_ = nullptr, *s_cntU_ = nullptr, *s_iflag_ = nullptr;
+    size_t s_sel_cap_ = 0, s_lcnt_cap_ = 0, s_selU_cap_ = 0, s_cntU_cap_ = 0, s_iflag_cap_ = 0;
+    void *h_res_ = nullptr; // pinned: results of insert_search_batch
+    size_t h_res_cap_ = 0;
     SearchHit *s_spill_ = nullptr;
     size_t s_spill_cap_ = 0;
     int *s_lk_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -156,8 +165,6 @@ private:
     HostGraphStage *hg_ = nullptr;
     void *h_stage_ = nullptr;
     size_t h_stage_cap_ = 0;
-    bool insert_search_pass(const SearchJob *jobs, int njobs, int k, int cand_cap, int max_edges0, int *out_sel, int sel_stride,
-                            int nlayers, int *out_cnt, int *out_flag);
     void *ev0_ = nullptr, *ev1_ = nullptr;
     void *stream_ = nullptr;
     bool profiling_ = false;

@@ -805,15 +805,17 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
 // SearchLayer + RelativeNeighborPruning (:189-190) with the next layer's entry = selected[0]
 // (:216).  One launch serves every layer of every item of a batch (the few multi-layer items
 // clear their visited bitset between layers).  Output per (job, layer): the selected ids in
-// selection order.  jobs[].search_layer = the item's first layer min(level, top).
+// selection order (layer 0 -> slot `job`; layer L >= 1 -> upper slot jobs[].aux + L - 1).
+// jobs[].search_layer = the item's first layer min(level, top).
 template <int METRIC>
 __global__ void __launch_bounds__(64)
 graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
-                           int *__restrict__ out_sel, int sel_stride, int nlayers, int *__restrict__ out_cnt,
-                           int *__restrict__ out_flag, unsigned long long *__restrict__ eval_counter, int nbcap)
+                           int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
+                           int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
+                           unsigned long long *__restrict__ eval_counter, int nbcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
@@ -841,9 +843,9 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         if (!ok) break;
         const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
         const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals);
-        const size_t slot = (size_t)job * nlayers + layer;
-        for (int i = lane; i < rc; i += 64) out_sel[slot * sel_stride + i] = L.acc[i];
-        if (lane == 0) out_cnt[slot] = rc;
+        int *osel = layer == 0 ? out_sel0 + (size_t)job * sel_stride : out_selU + (size_t)(jb.aux + layer - 1) * sel_stride;
+        for (int i = lane; i < rc; i += 64) osel[i] = L.acc[i];
+        if (lane == 0) { if (layer == 0) out_cnt0[job] = rc; else out_cntU[jb.aux + layer - 1] = rc; }
         const int next_entry = __builtin_amdgcn_readfirstlane(L.acc[0]); // :216 selected[0] -> bestPeer of the next layer (:179)
         jb.entry = next_entry;
         jb.entry_layer = layer - 1;
@@ -1012,11 +1014,12 @@ Device::~Device()
     if (d_queries_) (void)hipFree(d_queries_);
     if (d_q_sn_) (void)hipFree(d_q_sn_);
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
     if (h_stage_) (void)hipHostFree(h_stage_);
+    if (h_res_) (void)hipHostFree(h_res_);
     delete hg_;
 }
 
@@ -1316,67 +1319,89 @@ static bool jobs_valid(const SearchJob *jobs, int njobs, long long g_n, long lon
     return true;
 }
 
-bool Device::insert_search_pass(const SearchJob *jobs, int njobs, int k, int cand_cap, int max_edges0, int *out_sel, int sel_stride,
-                                int nlayers, int *out_cnt, int *out_flag)
+bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res)
 {
     if (njobs <= 0) return true;
+    if (!jobs || !res || k < 1 || n_upper < 0 || max_edges0 < 2) { set_dev_error("insert_search_batch: bad argument"); return false; }
+    if (g_n_ <= 0) { set_dev_error("insert_search_batch: no graph uploaded"); return false; }
+    for (int i = 0; i < njobs; ++i) {
+        const SearchJob &j = jobs[i];
+        if (j.qref >= 0) { set_dev_error("insert_search_batch: qref must name a stored row"); return false; }
+        if (j.search_layer > 0 && (j.aux < 0 || j.aux + j.search_layer > n_upper)) { set_dev_error("insert_search_batch: upper-layer slot out of range"); return false; }
+    }
+    if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("insert_search_batch: job outside the uploaded graph / rows"); return false; }
+    const int cand_cap = cand_lds_cap(k, dim_, true, nbcap());
+    const size_t lds = search_lds_bytes(k, cand_cap, dim_, true, nbcap());
+    if (lds > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
     if (!bind()) return false;
     hipStream_t st = S(stream_);
+    const int sel_stride = max_edges0;
     const long long vis_words = (g_n_ + 31) / 32;
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
     long long chunk = std::min<long long>(njobs, std::max<long long>(256, (8LL << 30) / (long long)std::max<size_t>(vis_bytes_per_job, 1)));
     if (!ensure_search_scratch(chunk, 0, vis_bytes_per_job)) return false;
-    if (!grow_dev(&s_sel_, &s_sel_cap_, (size_t)chunk * nlayers * sel_stride) || !grow_dev(&s_lcnt_, &s_lcnt_cap_, (size_t)chunk * nlayers)) return false;
+    const size_t nU = (size_t)std::max(n_upper, 1);
+    if (!grow_dev(&s_sel_, &s_sel_cap_, (size_t)njobs * sel_stride) || !grow_dev(&s_lcnt_, &s_lcnt_cap_, (size_t)njobs) ||
+        !grow_dev(&s_selU_, &s_selU_cap_, nU * sel_stride) || !grow_dev(&s_cntU_, &s_cntU_cap_, nU) ||
+        !grow_dev(&s_iflag_, &s_iflag_cap_, (size_t)njobs))
+        return false;
+    // pinned results: [sel0 | cnt0 | selU | cntU | flag | evals]
+    const size_t b_sel0 = 4u * (size_t)njobs * sel_stride, b_cnt0 = 4u * (size_t)njobs, b_selU = 4u * nU * sel_stride, b_cntU = 4u * nU, b_flag = 4u * (size_t)njobs;
+    const size_t need = b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 16;
+    if (need > h_res_cap_) {
+        if (h_res_) (void)hipHostFree(h_res_);
+        h_res_ = nullptr; h_res_cap_ = 0;
+        if (hipHostMalloc(&h_res_, need + need / 2, hipHostMallocDefault) != hipSuccess) { set_dev_error("insert_search_batch: pinned allocation failed"); return false; }
+        h_res_cap_ = need + need / 2;
+    }
+    char *hb = static_cast<char *>(h_res_);
+    int *h_sel0 = reinterpret_cast<int *>(hb), *h_cnt0 = reinterpret_cast<int *>(hb + b_sel0);
+    int *h_selU = reinterpret_cast<int *>(hb + b_sel0 + b_cnt0), *h_cntU = reinterpret_cast<int *>(hb + b_sel0 + b_cnt0 + b_selU);
+    int *h_flag = reinterpret_cast<int *>(hb + b_sel0 + b_cnt0 + b_selU + b_cntU);
+    unsigned long long *h_ev = reinterpret_cast<unsigned long long *>(hb + ((b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 7) & ~(size_t)7));
+    SearchJob *h_jobs = static_cast<SearchJob *>(pinned_stage(sizeof(SearchJob) * (size_t)chunk));
+    if (!h_jobs) return false;
     for (long long off = 0; off < njobs; off += chunk) {
         const int nj = (int)std::min<long long>(chunk, njobs - off);
-        HIP_OK(hipMemcpyAsync(s_jobs_, jobs + off, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
+        memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
+        HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemsetAsync(s_visited_, 0, vis_bytes_per_job * (size_t)nj, st));
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-        const size_t lds = search_lds_bytes(k, cand_cap, dim_, true, nbcap());
 #define LAUNCH(M)                                                                                                          \
     hipLaunchKernelGGL(graph_insert_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
-                       g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(), max_edges0, s_visited_, vis_words, s_sel_, sel_stride, \
-                       nlayers, s_lcnt_, s_flag_, s_evals_, nbcap())
+                       g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
+                       max_edges0, s_visited_, vis_words, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
+                       sel_stride, s_iflag_ + off, s_evals_, nbcap())
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
         else LAUNCH(M_UCOS);
 #undef LAUNCH
         HIP_OK(hipGetLastError());
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
-        unsigned long long ev = 0;
-        HIP_OK(hipMemcpyAsync(out_sel + (size_t)off * nlayers * sel_stride, s_sel_, sizeof(int) * (size_t)nj * nlayers * sel_stride, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(out_cnt + (size_t)off * nlayers, s_lcnt_, sizeof(int) * (size_t)nj * nlayers, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(out_flag + off, s_flag_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(&ev, s_evals_, sizeof(ev), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st)); // the job staging buffer is reused by the next chunk
         stats_.search_launches++;
-        stats_.search_evals += ev;
+        stats_.search_evals += *h_ev;
         if (timed) {
             float ms = 0.f;
             HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
             stats_.search_kernel_ms += ms;
             stats_.search_timed_launches++;
-            stats_.search_timed_evals += ev;
+            stats_.search_timed_evals += *h_ev;
         }
     }
-    return true;
-}
-
-bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int *out_sel, int sel_stride,
-                                 int nlayers, int *out_cnt, int *out_flag)
-{
-    if (njobs <= 0) return true;
-    if (!jobs || !out_sel || !out_cnt || !out_flag || k < 1 || sel_stride < max_edges0 || nlayers < 1) { set_dev_error("insert_search_batch: bad argument"); return false; }
-    for (int i = 0; i < njobs; ++i) if (jobs[i].search_layer >= nlayers) { set_dev_error("insert_search_batch: nlayers too small"); return false; }
-    if (g_n_ <= 0) { set_dev_error("insert_search_batch: no graph uploaded"); return false; }
-    for (int i = 0; i < njobs; ++i) if (jobs[i].qref >= 0) { set_dev_error("insert_search_batch: qref must name a stored row"); return false; }
-    if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("insert_search_batch: job outside the uploaded graph / rows"); return false; }
-    const int cap = cand_lds_cap(k, dim_, true, nbcap());
-    if (search_lds_bytes(k, cap, dim_, true, nbcap()) > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
-    if (!insert_search_pass(jobs, njobs, k, cap, max_edges0, out_sel, sel_stride, nlayers, out_cnt, out_flag)) return false;
-    for (int i = 0; i < njobs; ++i) stats_.search_overflows += (uint64_t)(out_flag[i] != 0);
+    HIP_OK(hipMemcpyAsync(h_sel0, s_sel_, b_sel0, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_cnt0, s_lcnt_, b_cnt0, hipMemcpyDeviceToHost, st));
+    if (n_upper > 0) {
+        HIP_OK(hipMemcpyAsync(h_selU, s_selU_, 4u * (size_t)n_upper * sel_stride, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(h_cntU, s_cntU_, 4u * (size_t)n_upper, hipMemcpyDeviceToHost, st));
+    }
+    HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (int i = 0; i < njobs; ++i) stats_.search_overflows += (uint64_t)(h_flag[i] != 0);
+    *res = InsertResults{h_sel0, h_cnt0, h_selU, h_cntU, h_flag, sel_stride};
     return true;
 }
 
@@ -1621,7 +1646,7 @@ bool Device::knn_search(const float *queries, int nq, int entry_point, int k_bea
     if (!set_queries(queries, nq)) return false;
     std::vector<SearchJob> jobs((size_t)nq);
     const int top = hg_->level[(size_t)entry_point];
-    for (int i = 0; i < nq; ++i) jobs[(size_t)i] = SearchJob{i, entry_point, top, 0};
+    for (int i = 0; i < nq; ++i) jobs[(size_t)i] = SearchJob{i, entry_point, top, 0, -1};
     return search_batch(jobs.data(), nq, k_beam, k_out, out_ids, out_d, out_flag);
 }
 

@@ -684,7 +684,11 @@ bool HnswIndex::search_half_lockstep(const std::vector<int> &bid, const std::vec
         j.efc = p_.max_candidates;
     }
     if (!engine_->run(src, (long long)items.size())) { err = get_dev_error(); return false; }
-    for (size_t t = 0; t < items.size(); ++t) sel[(size_t)items[t]] = std::move(src.jobs[t].selected);
+    if (sel.own.empty()) sel.own.resize((size_t)sel.n);
+    for (size_t t = 0; t < items.size(); ++t) {
+        sel.own[(size_t)items[t]] = std::move(src.jobs[t].selected);
+        sel.has_own[(size_t)items[t]] = 1;
+    }
     return true;
 }
 
@@ -697,42 +701,20 @@ bool HnswIndex::search_half_device(const std::vector<int> &bid, Selection &sel, 
     g_pt.batches++;
     const int n = (int)bid.size();
     const int top = graph_.top_layer(), ep = graph_.entry;
-    const int sel_stride = 2 * p_.max_edges;
-    std::vector<int> l0((size_t)n);
-    std::vector<char> redo((size_t)n, 0);
-    int maxl = 0;
-    for (int i = 0; i < n; ++i) {
-        const int lvl = graph_.level[(size_t)bid[(size_t)i]];
-        sel[(size_t)i].assign((size_t)lvl + 1, {});
-        l0[(size_t)i] = std::min(lvl, top); // GraphConnector.cs:176
-        maxl = std::max(maxl, l0[(size_t)i]);
-    }
-    // one launch: every item walks all its layers on the device; multi-layer items go first so
-    // that the longest traversals start with the launch
-    std::vector<int> order((size_t)n);
-    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return l0[(size_t)a] > l0[(size_t)b]; });
-    const int nlayers = maxl + 1;
+    // one launch: every item walks all its layers on the device (GraphConnector.cs:172-181)
     std::vector<SearchJob> jobs((size_t)n);
-    for (int t = 0; t < n; ++t) {
-        const int i = order[(size_t)t];
-        jobs[(size_t)t] = SearchJob{~bid[(size_t)i], ep, top, l0[(size_t)i]}; // FindEntryPoint from the top (:174), first layer :176
+    sel.upper_base.assign((size_t)n, -1);
+    int n_upper = 0;
+    for (int i = 0; i < n; ++i) {
+        const int id = bid[(size_t)i];
+        const int l0 = std::min(graph_.level[(size_t)id], top); // :176
+        if (l0 > 0) { sel.upper_base[(size_t)i] = n_upper; n_upper += l0; }
+        jobs[(size_t)i] = SearchJob{~id, ep, top, l0, sel.upper_base[(size_t)i]}; // FindEntryPoint from the top (:174)
     }
-    std::vector<int> out_sel((size_t)n * nlayers * sel_stride), out_cnt((size_t)n * nlayers), out_flag((size_t)n);
-    if (!dev_->insert_search_batch(jobs.data(), n, p_.max_candidates, 2 * p_.max_edges, out_sel.data(), sel_stride, nlayers,
-                                   out_cnt.data(), out_flag.data())) { err = get_dev_error(); return false; }
-    for (int t = 0; t < n; ++t) {
-        const int i = order[(size_t)t];
-        if (out_flag[(size_t)t]) { redo[(size_t)i] = 1; continue; }
-        for (int L = l0[(size_t)i]; L >= 0; --L) {
-            const size_t slot = (size_t)t * nlayers + L;
-            const int *ids = out_sel.data() + slot * sel_stride;
-            sel[(size_t)i][(size_t)L].assign(ids, ids + out_cnt[slot]);
-        }
-    }
+    if (!dev_->insert_search_batch(jobs.data(), n, p_.max_candidates, 2 * p_.max_edges, n_upper, &sel.dev)) { err = get_dev_error(); return false; }
     std::vector<int> again;
-    for (int i = 0; i < n; ++i) if (redo[(size_t)i]) again.push_back(i);
-    return search_half_lockstep(bid, again, sel, err);
+    for (int i = 0; i < n; ++i) if (sel.dev.flag[i]) again.push_back(i);
+    return search_half_lockstep(bid, again, sel, err); // items the device handed back
 }
 
 // ---- link half ----------------------------------------------------------------------------
@@ -744,7 +726,8 @@ struct LinkGroup {
 };
 // currNode.OutEdges[layer] = selected (:192) and the back-edge appends grouped per
 // (neighbour, layer), in item order.
-void collect_groups(Graph &g, const std::vector<int> &bid, const std::vector<std::vector<std::vector<int>>> &sel, std::vector<LinkGroup> &groups)
+template <class Sel>
+void collect_groups(Graph &g, const std::vector<int> &bid, const Sel &sel, std::vector<LinkGroup> &groups)
 {
     std::unordered_map<uint64_t, size_t> where;
     const int n = (int)bid.size();
@@ -753,11 +736,13 @@ void collect_groups(Graph &g, const std::vector<int> &bid, const std::vector<std
     for (int i = 0; i < n; ++i) {
         const int id = bid[(size_t)i];
         for (int layer = std::min(g.level[(size_t)id], top); layer >= 0; --layer) {
-            const std::vector<int> &s = sel[(size_t)i][(size_t)layer];
+            const int *sp; int sc;
+            sel.get(i, layer, sp, sc);
             int *l = g.list(id, layer);
-            l[0] = (int)s.size();
-            std::memcpy(l + 1, s.data(), sizeof(int) * s.size());
-            for (int nb : s) {
+            l[0] = sc;
+            std::memcpy(l + 1, sp, sizeof(int) * (size_t)sc);
+            for (int e = 0; e < sc; ++e) {
+                const int nb = sp[e];
                 const uint64_t key = ((uint64_t)(uint32_t)nb << 8) | (uint64_t)(uint32_t)layer;
                 auto it = where.find(key);
                 if (it == where.end()) {
@@ -808,15 +793,17 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
         for (int i = 0; i < n; ++i) {
             const int id = bid[(size_t)i];
             for (int layer = std::min(graph_.level[(size_t)id], top); layer >= 0; --layer) {
-                const std::vector<int> &s = sel[(size_t)i][(size_t)layer];
+                const int *sp; int sc;
+                sel.get(i, layer, sp, sc);
                 int *l = graph_.list(id, layer); // currNode.OutEdges[layer] = selected (:192), host copy
-                l[0] = (int)s.size();
-                std::memcpy(l + 1, s.data(), sizeof(int) * s.size());
+                l[0] = sc;
+                std::memcpy(l + 1, sp, sizeof(int) * (size_t)sc);
                 size_t r0 = rows.size();
                 rows.resize(r0 + (size_t)row_stride, 0);
-                rows[r0] = id; rows[r0 + 1] = layer; rows[r0 + 2] = (int)s.size();
-                std::memcpy(rows.data() + r0 + 3, s.data(), sizeof(int) * s.size());
-                for (int nb : s) {
+                rows[r0] = id; rows[r0 + 1] = layer; rows[r0 + 2] = sc;
+                std::memcpy(rows.data() + r0 + 3, sp, sizeof(int) * (size_t)sc);
+                for (int e = 0; e < sc; ++e) {
+                    const int nb = sp[e];
                     int gi;
                     if (layer == 0) {
                         gi = grp_of_node0_[(size_t)nb];
@@ -858,7 +845,9 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
 bool HnswIndex::insert_batch(const std::vector<int> &bid, std::string &err)
 {
     const int n = (int)bid.size();
-    Selection sel((size_t)n);
+    Selection sel;
+    sel.n = n;
+    sel.has_own.assign((size_t)n, 0);
     if (p_.device_traversal && dev_->traversal_fits(p_.max_candidates, true, p_.max_edges)) {
         if (!search_half_device(bid, sel, err)) return false;
         return link_half_device(bid, sel, err); // keeps the HBM mirror in step
@@ -973,7 +962,7 @@ int HnswIndex::knn_query_device(const float *, int count, int k, int *out_ids, f
     const int ef = std::max(p_.min_nn, k);
     std::vector<SearchJob> jobs((size_t)count);
     const int ep = graph_.entry, top = graph_.top_layer();
-    for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0};
+    for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0, -1};
     std::vector<int> flag((size_t)count);
     { Tick t(g_pt.query_dev);
     if (!dev_->search_batch(jobs.data(), count, ef, k, out_ids, out_dists, flag.data())) { err = get_dev_error(); return -1; } }

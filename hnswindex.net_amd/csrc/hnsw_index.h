@@ -63,7 +63,22 @@ private:
     bool ensure_dim(int dim, std::string &err);
     bool ensure_capacity(long long need, std::string &err);
     bool insert_batch(const std::vector<int> &bid, std::string &err);
-    using Selection = std::vector<std::vector<std::vector<int>>>; // [item][layer] -> selected neighbour ids
+    // Selected neighbour ids per (batch item, layer).  Device results are read in place from the
+    // context's pinned buffers (layer 0: slot = item; layer L >= 1: slot upper_base[item] + L - 1);
+    // items processed on the host (lock-step mode, hand-backs) carry their own lists.
+    struct Selection {
+        int n = 0;
+        Device::InsertResults dev{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+        std::vector<int> upper_base;
+        std::vector<char> has_own;
+        std::vector<std::vector<std::vector<int>>> own;
+        inline void get(int i, int layer, const int *&ids, int &cnt) const
+        {
+            if (has_own[(size_t)i]) { const std::vector<int> &v = own[(size_t)i][(size_t)layer]; ids = v.data(); cnt = (int)v.size(); return; }
+            if (layer == 0) { ids = dev.sel0 + (size_t)i * dev.sel_stride; cnt = dev.cnt0[i]; }
+            else { const size_t s = (size_t)(upper_base[(size_t)i] + layer - 1); ids = dev.selU + s * dev.sel_stride; cnt = dev.cntU[s]; }
+        }
+    };
     bool search_half_lockstep(const std::vector<int> &bid, const std::vector<int> &items, Selection &sel, std::string &err);
     bool search_half_device(const std::vector<int> &bid, Selection &sel, std::string &err);
     bool link_half_lockstep(const std::vector<int> &bid, const Selection &sel, std::string &err);
