@@ -258,27 +258,27 @@ struct HEnt {
     int id;
     unsigned key;
 };
-__device__ __forceinline__ HEnt uniform_ent(unsigned long long v)
+__device__ __forceinline__ HEnt uniform_ent(int2 v) // two 32-bit scalars (keeps the key compares on s_cmp_*_u32)
 {
     HEnt e;
-    e.id = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    e.key = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    e.id = __builtin_amdgcn_readfirstlane(v.x);
+    e.key = (unsigned)__builtin_amdgcn_readfirstlane(v.y);
     return e;
 }
-__device__ __forceinline__ unsigned long long pack_ent(HEnt e) { return (unsigned long long)(unsigned)e.id | ((unsigned long long)e.key << 32); }
+__device__ __forceinline__ int2 pack_ent(HEnt e) { return make_int2(e.id, (int)e.key); }
 
 // `top` lives entirely in LDS; `cand` keeps its first `cap` entries in LDS and spills the
 // (rarely reached) deep leaves to a private HBM area, so the LDS footprint -- and with it the
 // number of resident waves -- is set by the common case, not the worst one.
 struct LdsHeap {
     ND *b;
-    __device__ __forceinline__ HEnt get(int i) const { return uniform_ent(*reinterpret_cast<const unsigned long long *>(b + i)); }
-    __device__ __forceinline__ void set(int i, HEnt v) const { *reinterpret_cast<unsigned long long *>(b + i) = pack_ent(v); }
+    __device__ __forceinline__ HEnt get(int i) const { return uniform_ent(*reinterpret_cast<const int2 *>(b + i)); }
+    __device__ __forceinline__ void set(int i, HEnt v) const { *reinterpret_cast<int2 *>(b + i) = pack_ent(v); }
     // both children in one LDS round trip (entry i + 1 may be one past the heap: never used then)
     __device__ __forceinline__ void get2(int i, HEnt &x, HEnt &y) const
     {
-        const unsigned long long *p = reinterpret_cast<const unsigned long long *>(b + i);
-        const unsigned long long vx = p[0], vy = p[1];
+        const int2 *p = reinterpret_cast<const int2 *>(b + i);
+        const int2 vx = p[0], vy = p[1];
         x = uniform_ent(vx);
         y = uniform_ent(vy);
     }
@@ -289,18 +289,18 @@ struct SpillHeap {
     ND *g;
     __device__ __forceinline__ HEnt get(int i) const
     {
-        return uniform_ent(i < cap ? *reinterpret_cast<const unsigned long long *>(b + i) : *reinterpret_cast<const unsigned long long *>(g + (i - cap)));
+        return uniform_ent(i < cap ? *reinterpret_cast<const int2 *>(b + i) : *reinterpret_cast<const int2 *>(g + (i - cap)));
     }
     __device__ __forceinline__ void set(int i, HEnt v) const
     {
-        if (i < cap) *reinterpret_cast<unsigned long long *>(b + i) = pack_ent(v);
-        else *reinterpret_cast<unsigned long long *>(g + (i - cap)) = pack_ent(v);
+        if (i < cap) *reinterpret_cast<int2 *>(b + i) = pack_ent(v);
+        else *reinterpret_cast<int2 *>(g + (i - cap)) = pack_ent(v);
     }
     __device__ __forceinline__ void get2(int i, HEnt &x, HEnt &y) const
     {
         if (i + 1 < cap) {
-            const unsigned long long *p = reinterpret_cast<const unsigned long long *>(b + i);
-            const unsigned long long vx = p[0], vy = p[1];
+            const int2 *p = reinterpret_cast<const int2 *>(b + i);
+            const int2 vx = p[0], vy = p[1];
             x = uniform_ent(vx);
             y = uniform_ent(vy);
         } else {
