@@ -3,6 +3,7 @@
 # calibration on a known byte count in the same access pattern (tools/kbench).
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profiles; mkdir -p $O
+[ -x $R/tools/kbench ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off $R/tools/kbench.hip -o $R/tools/kbench
 cd /tmp && export TMPDIR=/tmp
 # 1) kernel trace + stats of the default bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
