@@ -1,0 +1,67 @@
+"""GPU tier: randomized shapes and TIE-HEAVY data against the oracle.  Small-integer coordinates
+produce many exactly equal distances and duplicate vectors, which is where heap tie order,
+the unstable introsort and the device's integer-key heaps could diverge from the host path."""
+import numpy as np
+import pytest
+
+import oracle
+from common import normalize_f32
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Index():
+    import hnswindex
+    assert hnswindex.net_amd.lib.hnswdev_device_count() > 0
+    return hnswindex.Index
+
+
+def _case(rng):
+    dim = int(rng.choice([3, 8, 12, 16, 31, 64]))
+    metric = str(rng.choice(["sq_euclid", "cosine", "ucosine"]))
+    M = int(rng.integers(2, 24))
+    efc = int(rng.integers(4, 90))
+    ef = int(rng.integers(1, 70))
+    k = int(rng.integers(1, 12))
+    n = int(rng.integers(300, 2500))
+    levels = int(rng.integers(2, 5))               # coordinate alphabet size: fewer => more ties
+    x = rng.integers(0, levels, (n, dim)).astype(np.float32)
+    x[rng.integers(0, n, n // 10)] = x[rng.integers(0, n, n // 10)]   # exact duplicates
+    if metric != "sq_euclid":
+        x += 1.0                                   # keep norms away from zero
+    if metric == "ucosine":
+        x = normalize_f32(x)
+    q = x[rng.integers(0, n, 120)].copy()
+    q[::3] += (rng.integers(0, 2, (q[::3].shape)) * 0.5).astype(np.float32)
+    if metric == "ucosine":
+        q = normalize_f32(q)
+    batch = int(rng.choice([1, 7, 64, 16384]))
+    return dict(dim=dim, metric=metric, M=M, efc=efc, ef=ef, k=k, n=n, x=x, q=q, batch=batch, seed=int(rng.integers(0, 1 << 30)))
+
+
+@pytest.mark.parametrize("case_seed", range(12))
+def test_tie_heavy_random_case(Index, case_seed):
+    c = _case(np.random.default_rng(1000 + case_seed))
+    ref = oracle.OracleIndex(c["dim"], c["metric"], max_edges=c["M"], max_candidates=c["efc"], min_nn=c["ef"],
+                             collection_size=64, random_seed=c["seed"])
+    if c["batch"] == 1:
+        ref.add(c["x"])
+    else:
+        ref.add_batched(c["x"], c["batch"])
+    want_ids, want_d = ref.knn_query(c["q"], c["k"])
+    for traversal in ("device", "host"):
+        ix = Index(c["dim"], c["metric"])
+        ix.set_collection_size(64); ix.set_max_edges(c["M"]); ix.set_max_candidates(c["efc"]); ix.set_min_nn(c["ef"])
+        ix.set_random_seed(c["seed"]); ix.set_insert_batch(c["batch"]); ix.set_device_traversal(traversal == "device")
+        ix.add(c["x"])
+        assert ix.graph_hash() == ref.graph_hash(), (traversal, {k: v for k, v in c.items() if k not in ("x", "q")})
+        ids, d = ix.knn_query(c["q"], c["k"])
+        assert (ids == want_ids).all() and d.tobytes() == want_d.tobytes(), traversal
+    # removal of a third of the items, then queries and a re-insert, still in step
+    rm = np.random.default_rng(case_seed).permutation(c["n"])[: c["n"] // 3].astype(np.int32)
+    ix.remove(rm); ref.remove(rm)
+    assert ix.graph_hash() == ref.graph_hash() and ix.ids().tolist() == ref.active_ids().tolist()
+    ids, d = ix.knn_query(c["q"], c["k"])
+    want_ids, want_d = ref.knn_query(c["q"], c["k"])
+    assert (ids == want_ids).all() and d.tobytes() == want_d.tobytes()
