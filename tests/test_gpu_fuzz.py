@@ -65,3 +65,20 @@ def test_tie_heavy_random_case(Index, case_seed):
     ids, d = ix.knn_query(c["q"], c["k"])
     want_ids, want_d = ref.knn_query(c["q"], c["k"])
     assert (ids == want_ids).all() and d.tobytes() == want_d.tobytes()
+
+
+@pytest.mark.parametrize("M,efc,ef,k,batch", [(1, 1, 1, 1, 16384), (1, 1, 1, 1, 1), (2, 1, 3, 2, 64), (63, 5, 2, 1, 16384), (3, 300, 200, 50, 256)])
+def test_extreme_parameters_match_oracle(Index, M, efc, ef, k, batch):
+    # bindings/__tests__/parameters_test.py:24-45 uses max_edges=1 and max_candidates=1
+    from common import uniform
+    x, q = uniform(1200, 24, 171), uniform(100, 24, 172)
+    ref = oracle.OracleIndex(24, max_edges=M, max_candidates=efc, min_nn=ef, collection_size=1200)
+    ref.add(x) if batch == 1 else ref.add_batched(x, batch)
+    want = ref.knn_query(q, k)
+    for traversal in ("device", "host"):
+        ix = Index(24); ix.set_collection_size(1200); ix.set_max_edges(M); ix.set_max_candidates(efc); ix.set_min_nn(ef)
+        ix.set_insert_batch(batch); ix.set_device_traversal(traversal == "device")
+        ix.add(x)
+        assert ix.graph_hash() == ref.graph_hash(), traversal
+        got = ix.knn_query(q, k)
+        assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes(), traversal
