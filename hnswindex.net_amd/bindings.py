@@ -95,6 +95,12 @@ lib.hnsw_mi355x_export_levels.restype = ct.c_int
 lib.hnsw_mi355x_export_levels.argtypes = [ct.c_void_p, _I, ct.c_int]
 lib.hnsw_mi355x_export_edges.restype = ct.c_int
 lib.hnsw_mi355x_export_edges.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int, ct.c_int]
+lib.hnsw_mi355x_dim.restype = ct.c_int
+lib.hnsw_mi355x_dim.argtypes = [ct.c_void_p]
+lib.hnsw_mi355x_serialize.restype = ct.c_int
+lib.hnsw_mi355x_serialize.argtypes = [ct.c_void_p, ct.c_char_p]
+lib.hnsw_mi355x_deserialize.restype = ct.c_void_p
+lib.hnsw_mi355x_deserialize.argtypes = [ct.c_char_p, ct.c_char_p]
 lib.hnsw_mi355x_graph_hash.restype = ct.c_uint64
 lib.hnsw_mi355x_graph_hash.argtypes = [ct.c_void_p]
 lib.hnsw_mi355x_get_stats.restype = ct.c_int
@@ -348,6 +354,25 @@ class Index:
         if n < 0:
             raise IndexError((i, layer))
         return buf[:n].copy()
+
+    # ---- HNSWIndex.Serialize / Deserialize (src/HNSWIndex/HNSWIndex.cs:210-229) ----
+    def serialize(self, path) -> None:
+        """Write the reference's protobuf-net snapshot of this index to `path`."""
+        if not self._initialized:
+            self._initialize()
+        self._check(lib.hnsw_mi355x_serialize(self._h, os.fsencode(path)))
+
+    @classmethod
+    def deserialize(cls, path, metric="sq_euclid") -> "Index":
+        """Reconstruct an index from a snapshot written by `serialize` or by the reference."""
+        h = lib.hnsw_mi355x_deserialize(metric.encode("utf-8"), os.fsencode(path))
+        if not h:
+            raise RuntimeError("deserialize failed: " + last_error())
+        ix = cls(0, metric)
+        ix._h = h
+        ix._initialized = True
+        ix.dim = int(lib.hnsw_mi355x_dim(h))
+        return ix
 
     def graph_hash(self) -> int:
         return int(lib.hnsw_mi355x_graph_hash(self._h))

@@ -2,6 +2,7 @@
 // (/root/reference/bindings/HNSWIndex.Native/HNSWIndexExports.cs:27-273), same names,
 // signatures, return codes and padding, over the MI355X-backed HnswIndex.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -10,6 +11,7 @@
 
 #include "../../include/hnsw_mi355x.h"
 #include "hnsw_index.h"
+#include "snapshot_io.h"
 
 using hnsw::HnswIndex;
 using hnsw::Params;
@@ -43,14 +45,18 @@ API int hnsw_get_last_error_utf8(void *buf, int buf_len) // :27-39
     return need;
 }
 
+static int parse_metric(const char *distance_metric) // :47-60
+{
+    if (!distance_metric) return -1;
+    if (!std::strcmp(distance_metric, "sq_euclid")) return HNSWDEV_SQ_EUCLID;
+    if (!std::strcmp(distance_metric, "cosine")) return HNSWDEV_COSINE;
+    if (!std::strcmp(distance_metric, "ucosine")) return HNSWDEV_UCOSINE;
+    return -1;
+}
+
 API void *hnsw_create(const char *distance_metric) // :41-65
 {
-    int metric = -1;
-    if (distance_metric) {
-        if (!std::strcmp(distance_metric, "sq_euclid")) metric = HNSWDEV_SQ_EUCLID;
-        else if (!std::strcmp(distance_metric, "cosine")) metric = HNSWDEV_COSINE;
-        else if (!std::strcmp(distance_metric, "ucosine")) metric = HNSWDEV_UCOSINE;
-    }
+    const int metric = parse_metric(distance_metric);
     if (metric < 0) {
         set_error(std::string("System.ArgumentException: Unsupported distance metric: ") + (distance_metric ? distance_metric : "(null)"));
         return nullptr;
@@ -191,6 +197,7 @@ API int hnsw_mi355x_knn_query_resident(void *h, int k, int *out_ids, float *out_
     if (static_cast<HnswIndex *>(h)->knn_query_resident(k, out_ids, out_dists, err) < 0) { set_error(err); return -1; }
     return 0;
 }
+API int hnsw_mi355x_dim(void *h) { return h ? static_cast<HnswIndex *>(h)->dim() : 0; }
 API int hnsw_mi355x_length(void *h) { return h ? static_cast<HnswIndex *>(h)->graph().length : 0; }
 API int hnsw_mi355x_active_ids(void *h, int *out, int cap)
 {
@@ -241,6 +248,36 @@ API int hnsw_mi355x_export_edges(void *h, int layer, int *counts, int *edges, in
     }
     return g.length;
 }
+// HNSWIndex.Serialize / Deserialize (src/HNSWIndex/HNSWIndex.cs:210-229); the reference's C ABI
+// does not export them, its C# API does.
+API int hnsw_mi355x_serialize(void *h, const char *path_utf8)
+{
+    if (!h) return 0;
+    std::string err;
+    if (static_cast<HnswIndex *>(h)->serialize(path_utf8, err) < 0) { set_error(err); return -1; }
+    return 0;
+}
+API void *hnsw_mi355x_deserialize(const char *distance_metric, const char *path_utf8)
+{
+    const int metric = parse_metric(distance_metric);
+    if (metric < 0) {
+        set_error(std::string("System.ArgumentException: Unsupported distance metric: ") + (distance_metric ? distance_metric : "(null)"));
+        return nullptr;
+    }
+    Params p;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        p = g_pending; // backend knobs only; the HNSW parameters come from the snapshot
+    }
+    std::string err;
+    HnswIndex *ix = HnswIndex::deserialize(metric, p, path_utf8, err);
+    if (!ix) { set_error(err); return nullptr; }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_pending = Params();
+    }
+    return ix;
+}
 API uint64_t hnsw_mi355x_graph_hash(void *h) { return h ? static_cast<HnswIndex *>(h)->graph_hash() : 0; }
 API int hnsw_mi355x_get_stats(void *h, hnswdev_stats *out)
 {
@@ -265,6 +302,35 @@ API int hnsw_mi355x_set_profiling(void *h, int enabled)
 
 // ---- host-logic test hooks (no device involved): the restated BCL pieces, so that the CPU
 // test tier can compare them with the oracle's independent restatement ----
+// Snapshot codec without a device: decode `in_path`, re-encode to `out_path`.
+// info = {length, dim, count, entry, capacity, max_edges, allow_removals, random_seed}
+API int hnswhost_test_snapshot_transcode(const char *in_path, const char *out_path, int *info, uint64_t *graph_hash)
+{
+    std::string err;
+    FILE *f = std::fopen(in_path, "rb");
+    if (!f) { set_error("cannot open input"); return -1; }
+    std::vector<uint8_t> buf;
+    std::fseek(f, 0, SEEK_END);
+    long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    buf.resize((size_t)std::max(0L, sz));
+    if (sz > 0 && std::fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); set_error("short read"); return -1; }
+    std::fclose(f);
+    hnsw::SnapshotParams sp;
+    hnsw::Graph g;
+    std::vector<float> rows;
+    int dim = 0;
+    long long cap = 0;
+    if (!hnsw::read_snapshot(buf.data(), buf.size(), sp, g, rows, dim, cap, err)) { set_error(err); return -1; }
+    if (info) {
+        info[0] = g.length; info[1] = dim; info[2] = g.count; info[3] = g.entry; info[4] = (int)cap;
+        info[5] = sp.max_edges; info[6] = sp.allow_removals ? 1 : 0; info[7] = sp.random_seed;
+    }
+    if (graph_hash) *graph_hash = hnsw::graph_hash_of(g);
+    if (out_path && !hnsw::write_snapshot(out_path, sp, g, rows.data(), dim, cap, err)) { set_error(err); return -1; }
+    return 0;
+}
+
 API void hnswhost_test_random_next(int seed, int n, int *out)
 {
     hnsw::DotnetRandom r(seed);

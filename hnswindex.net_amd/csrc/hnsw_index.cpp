@@ -12,6 +12,13 @@
 #include <thread>
 #include <unordered_map>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "snapshot_io.h"
+
 namespace hnsw {
 
 namespace {
@@ -1115,24 +1122,68 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
     return 0;
 }
 
-uint64_t HnswIndex::graph_hash() const
+// ---- Serialize / Deserialize ------------------------------------------------------------------
+int HnswIndex::serialize(const char *path, std::string &err)
 {
-    uint64_t x = 1469598103934665603ULL;
-    auto mix = [&](int v) {
-        uint32_t u = (uint32_t)v;
-        for (int b = 0; b < 4; ++b) { x ^= (u >> (8 * b)) & 0xff; x *= 1099511628211ULL; }
-    };
-    mix(graph_.entry);
-    for (int i = 0; i < graph_.length; ++i) {
-        if (graph_.removed[(size_t)i]) { mix(-2); continue; } // a vacated slot: its stale lists are unreachable
-        mix(graph_.level[(size_t)i]);
-        for (int l = 0; l <= graph_.level[(size_t)i]; ++l) {
-            const int *e = graph_.list(i, l);
-            mix(e[0]);
-            for (int j = 1; j <= e[0]; ++j) mix(e[j]);
-        }
-    }
-    return x;
+    if (!path) { err = "System.ArgumentNullException: filePath"; return -1; }
+    SnapshotParams sp;
+    sp.max_edges = p_.max_edges;
+    sp.distribution_rate = p_.distribution_rate;
+    sp.min_nn = p_.min_nn;
+    sp.max_candidates = p_.max_candidates;
+    sp.remove_max_candidates = p_.remove_max_candidates;
+    sp.collection_size = p_.collection_size;
+    sp.random_seed = p_.random_seed;
+    sp.allow_removals = p_.allow_removals;
+    std::vector<float> rows((size_t)graph_.length * (size_t)dim_);
+    if (graph_.length > 0 && !dev_->download_rows(0, graph_.length, rows.data())) { err = get_dev_error(); return -1; }
+    return write_snapshot(path, sp, graph_, rows.data(), dim_, capacity_, err) ? 0 : -1;
 }
+
+HnswIndex *HnswIndex::deserialize(int metric, const Params &backend, const char *path, std::string &err)
+{
+    if (!path) { err = "System.ArgumentNullException: filePath"; return nullptr; }
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { err = std::string("System.IO.FileNotFoundException: Could not find file '") + path + "'"; return nullptr; }
+    struct stat st;
+    if (::fstat(fd, &st) != 0) { ::close(fd); err = "System.IO.IOException: fstat"; return nullptr; }
+    const size_t len = (size_t)st.st_size;
+    void *map = len ? ::mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    ::close(fd);
+    if (len && map == MAP_FAILED) { err = "System.IO.IOException: mmap"; return nullptr; }
+    SnapshotParams sp;
+    Graph g;
+    std::vector<float> rows;
+    int dim = 0;
+    long long capacity = 0;
+    const bool ok = read_snapshot(static_cast<const uint8_t *>(map), len, sp, g, rows, dim, capacity, err);
+    if (len) ::munmap(map, len);
+    if (!ok) return nullptr;
+    Params p = backend;
+    p.max_edges = sp.max_edges;
+    p.distribution_rate = sp.distribution_rate;
+    p.min_nn = sp.min_nn;
+    p.max_candidates = sp.max_candidates;
+    p.remove_max_candidates = sp.remove_max_candidates;
+    p.collection_size = sp.collection_size;
+    p.random_seed = sp.random_seed;
+    p.allow_removals = sp.allow_removals;
+    // GraphData's snapshot constructor (GraphData.cs:58-74): the RNG restarts from RandomSeed
+    // (create() does that), Capacity / Length / EntryPointId are taken from the snapshot
+    HnswIndex *ix = create(metric, p, err);
+    if (!ix) return nullptr;
+    ix->capacity_ = std::max<long long>(1, capacity);
+    if (g.length > 0) {
+        if (!ix->ensure_dim(dim, err)) { delete ix; return nullptr; }
+        ix->graph_ = std::move(g);
+        if (!ix->dev_->upload_rows(0, ix->graph_.length, rows.data())) { err = get_dev_error(); delete ix; return nullptr; }
+    } else {
+        ix->graph_ = std::move(g);
+    }
+    ix->graph_dirty_ = true;
+    return ix;
+}
+
+uint64_t HnswIndex::graph_hash() const { return graph_hash_of(graph_); }
 
 } // namespace hnsw

@@ -52,7 +52,14 @@ public:
     // hnsw_remove (HNSWIndex.Remove, src/HNSWIndex/HNSWIndex.cs:83-102), ids in order.
     int remove(const int *ids, int count, std::string &err);
 
+    // HNSWIndex.Serialize / Deserialize (src/HNSWIndex/HNSWIndex.cs:210-229): the reference's
+    // protobuf-net snapshot (csrc/snapshot_io.h).  `backend` supplies the device knobs only;
+    // the HNSW parameters come from the file.
+    int serialize(const char *path, std::string &err);
+    static HnswIndex *deserialize(int metric, const Params &backend, const char *path, std::string &err);
+
     int count() const { return graph_.count; }
+    int dim() const { return dim_; }
     const Graph &graph() const { return graph_; }
     Device *device() { return dev_.get(); }
     uint64_t graph_hash() const;

@@ -351,4 +351,26 @@ struct Graph {
     inline int top_layer() const { return level[entry]; } // GraphData.GetTopLayer :195-198
 };
 
+// Order-sensitive digest of the graph (entry point, levels, every list in EdgeList order); the
+// test oracle computes the same value for whole-graph parity checks.
+inline uint64_t graph_hash_of(const Graph &g)
+{
+    uint64_t x = 1469598103934665603ULL;
+    auto mix = [&](int v) {
+        uint32_t u = (uint32_t)v;
+        for (int b = 0; b < 4; ++b) { x ^= (u >> (8 * b)) & 0xff; x *= 1099511628211ULL; }
+    };
+    mix(g.entry);
+    for (int i = 0; i < g.length; ++i) {
+        if (g.removed[(size_t)i]) { mix(-2); continue; } // a vacated slot: its stale lists are unreachable
+        mix(g.level[(size_t)i]);
+        for (int l = 0; l <= g.level[(size_t)i]; ++l) {
+            const int *e = g.list(i, l);
+            mix(e[0]);
+            for (int j = 1; j <= e[0]; ++j) mix(e[j]);
+        }
+    }
+    return x;
+}
+
 } // namespace hnsw

@@ -115,10 +115,22 @@ int hnsw_mi355x_length(void *handle);  /* slots ever allocated (ids are < length
 /* HNSWIndex.Ids(): the live ids in ActiveSet order; returns Count. */
 int hnsw_mi355x_active_ids(void *handle, int *out, int cap);
 int hnsw_mi355x_entry_point(void *handle);
+/* Row length fixed by the first add (or by the loaded snapshot); 0 before that. */
+int hnsw_mi355x_dim(void *handle);
 int hnsw_mi355x_node_max_layer(void *handle, int id);
 /* Copies up to cap out-edge ids of (id, layer); returns the edge count or -1. */
 int hnsw_mi355x_get_out_edges(void *handle, int id, int layer, int *out, int cap);
 uint64_t hnsw_mi355x_graph_hash(void *handle);
+
+/* HNSWIndex.Serialize(filePath) / HNSWIndex.Deserialize(distFnc, filePath)
+ * (src/HNSWIndex/HNSWIndex.cs:210-229): the reference's protobuf-net snapshot of
+ * HNSWIndexSnapshot<float[],float> (HNSWIndexSnapshot.cs:12-16, GraphDataSnapshot.cs:13-35,
+ * Node.cs:9-36, HNSWParameters.cs:12-55).  The reference's C ABI does not export these; its C#
+ * API has them.  serialize: 0 / -1.  deserialize: a handle for hnsw_* calls, or 0 with the
+ * message in hnsw_get_last_error_utf8; HNSW parameters come from the file, the pending
+ * hnsw_mi355x_set_* backend knobs are consumed as by hnsw_create. */
+int hnsw_mi355x_serialize(void *handle, const char *path_utf8);
+void *hnsw_mi355x_deserialize(const char *distance_metric_utf8, const char *path_utf8);
 /* Bulk forms: levels of nodes [0, min(count, cap)); returns count. */
 int hnsw_mi355x_export_levels(void *handle, int *out, int cap);
 /* counts[id] = out-degree of (id, layer), -1 where the node has no such layer;
