@@ -42,7 +42,8 @@ class Stats(ct.Structure):
     _fields_ = [("launches", ct.c_uint64), ("evals", ct.c_uint64), ("timed_launches", ct.c_uint64),
                 ("timed_evals", ct.c_uint64), ("kernel_ms", ct.c_double), ("row_bytes", ct.c_uint64),
                 ("search_launches", ct.c_uint64), ("search_evals", ct.c_uint64), ("search_timed_launches", ct.c_uint64),
-                ("search_timed_evals", ct.c_uint64), ("search_kernel_ms", ct.c_double), ("search_overflows", ct.c_uint64)]
+                ("search_timed_evals", ct.c_uint64), ("search_kernel_ms", ct.c_double), ("search_overflows", ct.c_uint64),
+                ("search_repeats", ct.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -35,7 +35,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
     LIB.parent.mkdir(parents=True, exist_ok=True)
-    cmd = [hipcc(), *FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(LIB), "-lpthread"]
+    extra = os.environ.get("HNSW_MI355X_EXTRA_FLAGS", "").split()  # kernel experiments (-D...)
+    cmd = [hipcc(), *FLAGS, *extra, *[str(CSRC / s) for s in SOURCES], "-o", str(LIB), "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -369,8 +369,35 @@ __device__ __forceinline__ void measure_pass(const float *__restrict__ rows, con
         acc[p] = 0.0f;
     }
     const int nblk = dim >> 3;
+    int k = 0;
+    // All row loads of a 16-block (128-float) chunk are issued before any arithmetic, so a chunk
+    // costs ONE memory round trip for its 8 * NP rows: the lane partials must be summed in k
+    // order, the loads need not be issued in it.  (A plain unrolled loop waits per unroll group --
+    // four dependent round trips per 512-B row pass, most of an expansion's latency.)
+    for (; k + 16 <= nblk; k += 16) {
+        float x[NP][16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) x[p][kk] = a[p][8 * (k + kk) + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float y = qs[8 * (k + kk) + j];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (METRIC == M_SQ) {
+                    const float d = x[p][kk] - y;
+                    acc[p] = __builtin_fmaf(d, d, acc[p]);
+                } else {
+                    const float pr = x[p][kk] * y;
+                    acc[p] = acc[p] + pr;
+                }
+            }
+        }
+    }
 #pragma unroll 4
-    for (int k = 0; k < nblk; ++k) {
+    for (; k < nblk; ++k) {
         float y = qs[8 * k + j];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -461,6 +488,268 @@ struct GraphView {
         return layer == 0 ? adj0 + (size_t)id * stride0 : pool + upper[id] + (size_t)(layer - 1) * strideU;
     }
 };
+
+#ifdef EXP_PHASE_CLOCKS // experiment build: shader-clock cycles per traversal phase, summed over waves
+__device__ unsigned long long g_phase[12];
+#define PH_DECL() long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_t = __builtin_readcyclecounter()
+#define PH(i) do { long long ph_n = __builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; } while (0)
+#define PH_COUNT(i, v) ph_acc[i] += (v)
+#define PH_FLUSH() do { if (lane == 0) for (int ph_i = 0; ph_i < 8; ++ph_i) atomicAdd(&g_phase[ph_i], (unsigned long long)ph_acc[ph_i]); } while (0)
+#else
+#define PH_DECL() do {} while (0)
+#define PH(i) do {} while (0)
+#define PH_COUNT(i, v) do {} while (0)
+#define PH_FLUSH() do {} while (0)
+#endif
+
+// FindEntryPoint / FindEntryAtLayer (GraphNavigator.cs:27-82): greedy descent from jb.entry at
+// jb.entry_layer down to (not including) jb.search_layer.  Leaves the entry of the search layer
+// in `best` and its distance in `cur` (both wave-uniform).
+template <int METRIC>
+__device__ __forceinline__ void descend(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
+                                        const GraphView &G, const SearchJob jb, const SearchLds &L, int lane, int &best, float &cur,
+                                        unsigned long long &evals)
+{
+    int *nbuf = L.nbuf;
+    float *dbuf = L.dbuf;
+    const float *qs = L.qs;
+    best = jb.entry;
+    __syncthreads();
+    if (lane == 0) nbuf[0] = best;
+    __syncthreads();
+    measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, 1, lane);
+    __syncthreads();
+    cur = dbuf[0]; // :57
+    evals += 1;
+    for (int layer = jb.entry_layer; layer > jb.search_layer; --layer) {
+        bool changed = true;
+        while (changed) { // :60
+            changed = false;
+            const int *l = G.list(best, layer);
+            const int n = l[0];
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) nbuf[i] = l[1 + i]; // :65 span taken once per pass
+            __syncthreads();
+            if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane);
+            __syncthreads();
+            evals += (unsigned long long)n;
+            for (int i = 0; i < n; ++i) { // :67-78
+                float d = dbuf[i];
+                if (d < cur) { cur = d; best = nbuf[i]; changed = true; }
+            }
+        }
+    }
+    best = __builtin_amdgcn_readfirstlane(best);
+    cur = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cur)));
+}
+
+// ---- SearchLayer on ONE sorted list in registers ---------------------------------------------
+// The reference keeps two heaps (GraphNavigator.cs:126-127): topCandidates (the k closest seen,
+// farthest at the root) and candidates (everything accepted, closest at the root).  An accepted
+// element is pushed to both; it leaves topCandidates only when k closer ones exist, and from
+// then on its distance exceeds farthestResultDist for good, so popping it from `candidates` can
+// only end the loop (:147-150).  Hence the live part of `candidates` is exactly the not yet
+// expanded members of topCandidates, and when no two coexisting entries have equal distances
+// the whole state is one ascending list of <= k entries with an "expanded" mark:
+//   pop closest candidate  = first unmarked entry            (ballot + ctz)
+//   push / trim to k       = ranked insertion, last one drops (compare + popcount + lane shift)
+//   farthestResultDist     = entry k - 1
+// which is straight-line wave-wide code instead of scalar sift loops in LDS (2/3 of the traversal
+// time at C2, all of it scalar-issue bound).  With equal distances the reference's results depend
+// on the heaps' array layout (pop order among equals, OrderBy / ToArray order), which a sorted
+// list does not reproduce: every insertion checks for an equal key among the entries it joins
+// and raises `tie`; the caller then repeats the job with the exact two-heap traversal below.
+// Position p lives in lane p & 63 of register set p >> 6; id bit 31 = expanded.
+__device__ __forceinline__ int dpp_wave_shr1(int carry_in, int v)
+{
+    return __builtin_amdgcn_update_dpp(carry_in, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); // lane 0 keeps carry_in
+}
+template <int NS>
+struct SortedTop {
+    unsigned key[NS];
+    int id[NS];
+    __device__ __forceinline__ HEnt at(int p) const // uniform p
+    {
+        HEnt e{__builtin_amdgcn_readlane(id[0], p & 63), (unsigned)__builtin_amdgcn_readlane((int)key[0], p & 63)};
+#pragma unroll
+        for (int t = 1; t < NS; ++t) {
+            const int wi = __builtin_amdgcn_readlane(id[t], p & 63);
+            const unsigned wk = (unsigned)__builtin_amdgcn_readlane((int)key[t], p & 63);
+            if ((p >> 6) == t) { e.id = wi; e.key = wk; }
+        }
+        return e;
+    }
+    __device__ __forceinline__ unsigned key_at(int p) const
+    {
+        unsigned v = (unsigned)__builtin_amdgcn_readlane((int)key[0], p & 63);
+#pragma unroll
+        for (int t = 1; t < NS; ++t) {
+            const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)key[t], p & 63);
+            if ((p >> 6) == t) v = w;
+        }
+        return v;
+    }
+    // first entry not yet expanded, or -1
+    __device__ __forceinline__ int first_open(int count, int lane) const
+    {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (64 * t >= count) break;
+            const unsigned long long m = __ballot(lane + 64 * t < count && id[t] >= 0);
+            if (m) return 64 * t + (int)__builtin_ctzll(m);
+        }
+        return -1;
+    }
+    __device__ __forceinline__ void mark(int p, int lane)
+    {
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            if ((p >> 6) == t && lane == (p & 63)) id[t] |= (int)0x80000000;
+    }
+    // ranked insertion of (xk, xid); beyond k entries the last one drops
+    __device__ __forceinline__ void insert(unsigned xk, int xid, int &count, int k, int lane, bool &tie)
+    {
+        int r = 0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (64 * t >= count) break;
+            const bool valid = lane + 64 * t < count;
+            r += (int)__popcll(__ballot(valid && key[t] < xk));
+            tie |= valid && key[t] == xk;
+        }
+#pragma unroll
+        for (int t = NS - 1; t >= 0; --t) {
+            if (64 * t > count || 64 * (t + 1) <= r) continue; // nothing at or after r in this set
+            int ck = 0, ci = 0;
+            if (t > 0) { ck = __builtin_amdgcn_readlane((int)key[t - 1], 63); ci = __builtin_amdgcn_readlane(id[t - 1], 63); }
+            const int sk = dpp_wave_shr1(ck, (int)key[t]);
+            const int si = dpp_wave_shr1(ci, id[t]);
+            const int p = lane + 64 * t;
+            key[t] = p == r ? xk : p > r ? (unsigned)sk : key[t];
+            id[t] = p == r ? xid : p > r ? si : id[t];
+        }
+        if (count < k) ++count;
+    }
+};
+
+// Returns false on a NaN / -0 distance (exact host re-run); `tie` asks for the exact two-heap
+// traversal.  Result: L.top[0..top_n) ascending by distance.  The query must be staged in L.qs.
+template <int METRIC, int NS>
+__device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
+                                                const GraphView &G, const SearchJob jb, int k, unsigned *vis, const SearchLds &L,
+                                                int lane, int &top_n_out, bool &tie_out, unsigned long long &evals)
+{
+    int *nbuf = L.nbuf;
+    float *dbuf = L.dbuf;
+    const float *qs = L.qs;
+    PH_DECL();
+    int best;
+    float cur;
+    descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals);
+    // ---- SearchLayer (GraphNavigator.cs:123-189) ----
+    const int layer = jb.search_layer;
+    SortedTop<NS> T;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) { T.key[t] = 0u; T.id[t] = 0; }
+    int top_n = 0;
+    bool unsafe = key_unsafe(cur); // NaN / -0 (see f2key)
+    bool tie = false;
+    T.insert(f2key(cur), best, top_n, k, lane, tie);                 // :134, :138
+    if (lane == 0) atomicOr(&vis[best >> 5], 1u << (best & 31));     // :140
+    unsigned far_key = f2key(cur);                                   // farthestResultDist :135
+    int pre_id = -1, pre_a = 0, pre_b = 0; // speculative prefetch of the next expansion's list (see traverse)
+    const int lstride = layer == 0 ? G.stride0 : G.strideU;
+    PH(0);
+    while (!unsafe) {
+        const int pos = T.first_open(top_n, lane); // :146 closest candidate; none left <=> :147-150 / empty
+        if (pos < 0) break;
+        const HEnt c = T.at(pos);
+        T.mark(pos, lane);
+        PH(1);
+        int n, nb_a = 0, nb_b = 0;
+        if (c.id == pre_id) {
+            n = __builtin_amdgcn_readlane(pre_a, 0);
+            nb_a = __shfl(pre_a, (lane + 1) & 63, 64);
+            const int w64 = __builtin_amdgcn_readlane(pre_b, 0);
+            if (lane == 63) nb_a = w64;
+            nb_b = __shfl(pre_b, (lane + 1) & 63, 64);
+        } else {
+            const int *l = G.list(c.id, layer);
+            n = __builtin_amdgcn_readfirstlane(l[0]);
+            if (lane < n) nb_a = l[1 + lane];
+            if (lane + 64 < n) nb_b = l[65 + lane];
+        }
+        PH_COUNT(6, c.id == pre_id);
+        PH_COUNT(7, 1);
+        int m = 0;
+        __syncthreads();
+        PH(2);
+        for (int base = 0; base < n; base += 64) { // :158-161 keep only unvisited, in list order
+            const int i = base + lane;
+            bool fresh = false;
+            const int nb = base == 0 ? nb_a : nb_b;
+            if (i < n) {
+                const unsigned bit = 1u << (nb & 31);
+                const unsigned old = atomicOr(&vis[nb >> 5], bit); // :181 (lists hold no duplicates)
+                fresh = (old & bit) == 0;
+            }
+            const unsigned long long mask = __ballot(fresh);
+            const int posn = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (fresh) nbuf[m + posn] = nb;
+            m += __popcll(mask);
+        }
+        PH(3);
+        pre_id = -1;
+        {
+            const int nxt = T.first_open(top_n, lane);
+            if (nxt >= 0) {
+                pre_id = T.at(nxt).id;
+                const int *pl = G.list(pre_id, layer);
+                pre_a = lane < lstride ? pl[lane] : 0;
+                pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
+            }
+        }
+        __syncthreads();
+        if (m == 0) continue;
+        measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
+        __syncthreads();
+        PH(4);
+        evals += (unsigned long long)m;
+        // the push loop (:165-178) in adjacency order; farthest never grows once the list is full,
+        // so only the lanes passing the test now can pass it later: they are replayed one by one
+        for (int base = 0; base < m && !unsafe; base += 64) {
+            const int i = base + lane;
+            const float my_d = (i < m) ? dbuf[i] : 0.0f;
+            const int my_id = (i < m) ? nbuf[i] : 0;
+            const unsigned my_key = f2key(my_d);
+            if (__ballot(i < m && key_unsafe(my_d))) { unsafe = true; break; }
+            unsigned long long maybe = __ballot(i < m && (top_n < k || my_key < far_key));
+            while (maybe) {
+                const int src = __builtin_ctzll(maybe);
+                maybe &= maybe - 1;
+                const unsigned dk = (unsigned)__builtin_amdgcn_readlane((int)my_key, src);
+                if (top_n < k || dk < far_key) { // :165
+                    T.insert(dk, __builtin_amdgcn_readlane(my_id, src), top_n, k, lane, tie); // :168-174
+                    if (top_n == k) far_key = T.key_at(k - 1);                                // :176-177
+                }
+            }
+        }
+        PH(5);
+    }
+    PH_FLUSH();
+    // ToArray() for the callers: with distinct distances any order-insensitive consumer (OrderBy,
+    // Span.Sort) sees the same thing; ascending order is also what they would produce
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int p = lane + 64 * t;
+        if (p < top_n) { L.top[p].id = T.id[t] & 0x7fffffff; L.top[p].dist = key2f(T.key[t]); }
+    }
+    __syncthreads();
+    top_n_out = top_n;
+    tie_out = __ballot(tie) != 0ull;
+    return !unsafe;
+}
 
 // Descent + beam search of one job; result = L.top[0..top_n) in heap order.  Returns false on
 // candidate-heap overflow.  The query must already be staged in L.qs.
@@ -687,7 +976,7 @@ __device__ inline void dev_dotnet_sort(ND *arr, int n, int *stk)
 template <int METRIC>
 __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                                                          ND *cands, int n, int max_edges, const SearchLds &L, int lane,
-                                                         unsigned long long &evals)
+                                                         unsigned long long &evals, bool presorted = false)
 {
     int *acc = L.acc;
     __syncthreads();
@@ -696,7 +985,7 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
         __syncthreads();
         return n;
     }
-    dev_dotnet_sort(cands, n, L.stk); // :22
+    if (!presorted) dev_dotnet_sort(cands, n, L.stk); // :22 (a sorted-list traversal hands them over in order)
     __syncthreads();
     int rc = 0;
     for (int i = 0; i < n && rc < max_edges; ++i) { // :23
@@ -727,22 +1016,25 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
     return rc;
 }
 
-template <int METRIC>
+// NS > 0: sorted-list traversal with NS register sets (k <= 64 * NS); out_flag 2 = equal distances
+// met, repeat with NS = 0 (the exact two-heap traversal).  job_map (optional): blockIdx -> job for
+// such a repeat launch; scratch (visited, spill) is indexed by blockIdx, results by job.
+template <int METRIC, int NS>
 __global__ void __launch_bounds__(64)
 graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
-                    const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill, int spill_cap,
-                    unsigned *__restrict__ visited, long long vis_words, int k_out, int *__restrict__ out_ids,
+                    const SearchJob *__restrict__ jobs, const int *__restrict__ job_map, int k, int cand_cap, ND *__restrict__ spill,
+                    int spill_cap, unsigned *__restrict__ visited, long long vis_words, int k_out, int *__restrict__ out_ids,
                     float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
                     unsigned long long *__restrict__ eval_counter, int nbcap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
-    const int job = blockIdx.x;
+    const int job = job_map ? job_map[blockIdx.x] : (int)blockIdx.x;
     const SearchJob jb = jobs[job];
-    unsigned *vis = visited + (size_t)job * (size_t)vis_words;
+    unsigned *vis = visited + (size_t)blockIdx.x * (size_t)vis_words;
     const GraphView G{adj0, stride0, upper, pool, strideU};
 
     const float *q;
@@ -757,7 +1049,24 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
     unsigned long long evals = 0;
     int top_n = 0;
-    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)job * spill_cap, spill_cap, vis, L, lane, top_n, evals);
+    if constexpr (NS > 0) {
+        bool tie = false;
+        const bool ok = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, vis, L, lane, top_n, tie, evals);
+        // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
+        // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
+        for (int r = lane; r < k_out; r += 64) {
+            const bool have = r < top_n;
+            out_ids[(size_t)job * k_out + r] = have ? L.top[r].id : -1;
+            out_d[(size_t)job * k_out + r] = have ? L.top[r].dist : __uint_as_float(0x7fc00000u);
+        }
+        if (lane == 0) {
+            out_cnt[job] = ok ? top_n : 0;
+            out_flag[job] = ok ? (tie ? 2 : 0) : 1;
+            if (!(ok && tie)) atomicAdd(eval_counter, evals); // a repeated job is counted by its repeat
+        }
+        return;
+    }
+    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)blockIdx.x * spill_cap, spill_cap, vis, L, lane, top_n, evals);
     // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(c => c.Dist) is a STABLE sort over the heap
     // array (ToArray(), BinaryHeap.cs:41-44) and only the first k_out survive -- so select the
     // k_out smallest (float.CompareTo order: NaN first, -0 == +0) with ties broken by array index:
@@ -807,11 +1116,12 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
 // clear their visited bitset between layers).  Output per (job, layer): the selected ids in
 // selection order (layer 0 -> slot `job`; layer L >= 1 -> upper slot jobs[].aux + L - 1).
 // jobs[].search_layer = the item's first layer min(level, top).
-template <int METRIC>
+template <int METRIC, int NS>
 __global__ void __launch_bounds__(64)
 graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
-                           const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
+                           const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs,
+                           const int *__restrict__ job_map, int k,
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
                            int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
@@ -820,9 +1130,9 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
-    const int job = blockIdx.x;
+    const int job = job_map ? job_map[blockIdx.x] : (int)blockIdx.x;
     SearchJob jb = jobs[job];
-    unsigned *vis = visited + (size_t)job * (size_t)vis_words;
+    unsigned *vis = visited + (size_t)blockIdx.x * (size_t)vis_words;
     const GraphView G{adj0, stride0, upper, pool, strideU};
     const int item = ~jb.qref;
     const float *q = rows + (size_t)item * dim;
@@ -830,7 +1140,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
     if (METRIC == M_COS) sb = row_sn[item];
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
     unsigned long long evals = 0;
-    bool ok = true;
+    bool ok = true, repeat = false;
     const int first_layer = jb.search_layer;
     for (int layer = first_layer; layer >= 0 && ok; --layer) {
         if (layer != first_layer) { // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
@@ -839,10 +1149,19 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
             __syncthreads();
         }
         int top_n = 0;
-        ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)job * spill_cap, spill_cap, vis, L, lane, top_n, evals);
-        if (!ok) break;
         const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
-        const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals);
+        if constexpr (NS > 0) {
+            bool tie = false;
+            ok = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, vis, L, lane, top_n, tie, evals);
+            if (!ok) break;
+            // equal distances, or fewer candidates than MaxEdges (the heuristic then returns them in
+            // HEAP order, Heuristic.cs:13-18): the exact traversal repeats this item
+            if (tie || top_n < max_edges) { repeat = true; break; }
+        } else {
+            ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)blockIdx.x * spill_cap, spill_cap, vis, L, lane, top_n, evals);
+            if (!ok) break;
+        }
+        const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, NS > 0);
         int *osel = layer == 0 ? out_sel0 + (size_t)job * sel_stride : out_selU + (size_t)(jb.aux + layer - 1) * sel_stride;
         for (int i = lane; i < rc; i += 64) osel[i] = L.acc[i];
         if (lane == 0) { if (layer == 0) out_cnt0[job] = rc; else out_cntU[jb.aux + layer - 1] = rc; }
@@ -853,8 +1172,8 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         __syncthreads();
     }
     if (lane == 0) {
-        out_flag[job] = ok ? 0 : 1;
-        atomicAdd(eval_counter, evals);
+        out_flag[job] = repeat ? 2 : ok ? 0 : 1;
+        if (!repeat) atomicAdd(eval_counter, evals);
     }
 }
 
@@ -1013,8 +1332,20 @@ Device::~Device()
     if (d_row_sn_) (void)hipFree(d_row_sn_);
     if (d_queries_) (void)hipFree(d_queries_);
     if (d_q_sn_) (void)hipFree(d_q_sn_);
+#ifdef EXP_PHASE_CLOCKS
+    {
+        unsigned long long h[12] = {0};
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) == hipSuccess) {
+            double tot = 0;
+            for (int i = 0; i < 6; ++i) tot += (double)h[i];
+            fprintf(stderr, "[phase clocks] descent %.1f%% pop %.1f%% list %.1f%% visited %.1f%% rows %.1f%% push %.1f%% | expansions %llu, prefetch hits %llu (%.1f%%), cycles/expansion %.0f\n",
+                    100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, h[7], h[6],
+                    100.0 * h[6] / (double)std::max(1ull, h[7]), tot / (double)std::max(1ull, h[7]));
+        }
+    }
+#endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobmap_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -1216,6 +1547,11 @@ void Device::reset_stats()
     uint64_t rb = stats_.row_bytes;
     stats_ = hnswdev_stats{};
     stats_.row_bytes = rb;
+#ifdef EXP_PHASE_CLOCKS
+    unsigned long long z[12] = {0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z);
+#endif
 }
 
 
@@ -1260,6 +1596,15 @@ bool Device::set_graph(const int *adj0, long long n, int stride0, const int *lev
 // near 500 entries at ef = 128), the rest spills to HBM (SpillHeap).  A smaller LDS footprint means
 // more resident waves to hide memory latency: 7.6 -> 6.1 ms per 10k-query launch going from 1024
 // to 512 entries.  Beyond LDS + spill capacity the traversal is flagged for the lock-step path.
+// Register sets of the sorted-list traversal (SortedTop<NS>: k <= 64 * NS); 0 = two-heap traversal
+// only.  HNSW_MI355X_SORTED_TOP=0 forces the latter (the tests run both).
+static int sorted_top_sets(int k)
+{
+    const char *e = std::getenv("HNSW_MI355X_SORTED_TOP");
+    if (e && std::atoi(e) == 0) return 0;
+    return k <= 64 ? 1 : k <= 128 ? 2 : k <= 256 ? 4 : k <= 512 ? 8 : 0;
+}
+
 static int cand_lds_cap(int k, int dim, bool heur, int nbcap)
 {
     int cap = std::min(std::max(4 * k, 256), 4096);
@@ -1296,10 +1641,12 @@ bool Device::ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_
         if (s_jobs_) HIP_OK(hipFree(s_jobs_));
         if (s_cnt_) HIP_OK(hipFree(s_cnt_));
         if (s_flag_) HIP_OK(hipFree(s_flag_));
+        if (s_jobmap_) HIP_OK(hipFree(s_jobmap_));
         s_jobs_cap_ = (size_t)chunk;
         HIP_OK(hipMalloc(&s_jobs_, sizeof(SearchJob) * s_jobs_cap_));
         HIP_OK(hipMalloc(&s_cnt_, sizeof(int) * s_jobs_cap_));
         HIP_OK(hipMalloc(&s_flag_, sizeof(int) * s_jobs_cap_));
+        HIP_OK(hipMalloc(&s_jobmap_, sizeof(int) * s_jobs_cap_));
     }
     if (k > 0 && !grow_dev(&s_hits_, &s_hits_cap_, (size_t)chunk * k)) return false;
     if (!grow_dev(&s_spill_, &s_spill_cap_, (size_t)chunk * kSpillCap + 8)) return false; // +8: get2 may read one entry past a heap
@@ -1333,6 +1680,8 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     const int cand_cap = cand_lds_cap(k, dim_, true, nbcap());
     const size_t lds = search_lds_bytes(k, cand_cap, dim_, true, nbcap());
     if (lds > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
+    const int ns = sorted_top_sets(k);
+    const size_t lds_sorted = search_lds_bytes(k, 0, dim_, true, nbcap());
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     const int sel_stride = max_edges0;
@@ -1369,16 +1718,43 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-#define LAUNCH(M)                                                                                                          \
-    hipLaunchKernelGGL(graph_insert_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
-                       g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
+#define LAUNCH2(M, NS_, GRID, LDS, MAP, CAP)                                                                               \
+    hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_>), dim3(GRID), dim3(64), LDS, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
+                       g_upper_, g_pool_, g_strideU_, s_jobs_, MAP, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
                        sel_stride, s_iflag_ + off, s_evals_, nbcap())
-        if (metric_ == M_SQ) LAUNCH(M_SQ);
-        else if (metric_ == M_COS) LAUNCH(M_COS);
-        else LAUNCH(M_UCOS);
-#undef LAUNCH
+#define LAUNCH(NS_, GRID, LDS, MAP, CAP)                                                                                   \
+    do {                                                                                                                   \
+        if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, MAP, CAP);                                                      \
+        else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, GRID, LDS, MAP, CAP);                                               \
+        else LAUNCH2(M_UCOS, NS_, GRID, LDS, MAP, CAP);                                                                    \
+    } while (0)
+        const int *no_map = nullptr;
+        switch (ns) {
+        case 1: LAUNCH(1, nj, lds_sorted, no_map, 0); break;
+        case 2: LAUNCH(2, nj, lds_sorted, no_map, 0); break;
+        case 4: LAUNCH(4, nj, lds_sorted, no_map, 0); break;
+        case 8: LAUNCH(8, nj, lds_sorted, no_map, 0); break;
+        default: LAUNCH(0, nj, lds, no_map, cand_cap); break;
+        }
         HIP_OK(hipGetLastError());
+        if (ns > 0) { // items that met equal distances or a short candidate list: exact two-heap traversal
+            HIP_OK(hipMemcpyAsync(h_flag + off, s_iflag_ + off, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            int n2 = 0;
+            int *h_map = reinterpret_cast<int *>(h_jobs); // staged jobs are on the device by now
+            static_assert(sizeof(SearchJob) >= sizeof(int), "job map fits the job staging buffer");
+            for (int i = 0; i < nj; ++i) if (h_flag[off + i] == 2) h_map[n2++] = i;
+            if (n2 > 0) {
+                HIP_OK(hipMemcpyAsync(s_jobmap_, h_map, sizeof(int) * (size_t)n2, hipMemcpyHostToDevice, st));
+                HIP_OK(hipMemsetAsync(s_visited_, 0, vis_bytes_per_job * (size_t)n2, st));
+                LAUNCH(0, n2, lds, s_jobmap_, cand_cap);
+                HIP_OK(hipGetLastError());
+                stats_.search_repeats += (uint64_t)n2;
+            }
+        }
+#undef LAUNCH
+#undef LAUNCH2
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st)); // the job staging buffer is reused by the next chunk
@@ -1529,6 +1905,8 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     const int cand_cap = cand_lds_cap(k, dim_, false, nbcap());
     const size_t lds = search_lds_bytes(k, cand_cap, dim_, false, nbcap());
     if (lds > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
+    const int ns = sorted_top_sets(k);
+    const size_t lds_sorted = search_lds_bytes(k, 0, dim_, false, nbcap());
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     const long long vis_words = (g_n_ + 31) / 32;
@@ -1555,15 +1933,41 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-#define LAUNCH(M)                                                                                                          \
-    hipLaunchKernelGGL(graph_search_kernel<M>, dim3(nj), dim3(64), lds, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_,     \
-                       g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, cand_cap, reinterpret_cast<ND *>(s_spill_), \
+#define LAUNCH2(M, NS_, GRID, LDS, MAP, CAP)                                                                               \
+    hipLaunchKernelGGL((graph_search_kernel<M, NS_>), dim3(GRID), dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
+                       g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, MAP, k, CAP, reinterpret_cast<ND *>(s_spill_), \
                        spill_cap_for_tests(), s_visited_, vis_words, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap())
-        if (metric_ == M_SQ) LAUNCH(M_SQ);
-        else if (metric_ == M_COS) LAUNCH(M_COS);
-        else LAUNCH(M_UCOS);
-#undef LAUNCH
+#define LAUNCH(NS_, GRID, LDS, MAP, CAP)                                                                                   \
+    do {                                                                                                                   \
+        if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, MAP, CAP);                                                      \
+        else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, GRID, LDS, MAP, CAP);                                               \
+        else LAUNCH2(M_UCOS, NS_, GRID, LDS, MAP, CAP);                                                                    \
+    } while (0)
+        const int *no_map = nullptr;
+        switch (ns) {
+        case 1: LAUNCH(1, nj, lds_sorted, no_map, 0); break;
+        case 2: LAUNCH(2, nj, lds_sorted, no_map, 0); break;
+        case 4: LAUNCH(4, nj, lds_sorted, no_map, 0); break;
+        case 8: LAUNCH(8, nj, lds_sorted, no_map, 0); break;
+        default: LAUNCH(0, nj, lds, no_map, cand_cap); break;
+        }
         HIP_OK(hipGetLastError());
+        if (ns > 0) { // jobs that met equal distances: once more, with the exact two-heap traversal
+            HIP_OK(hipMemcpyAsync(h_flag, s_flag_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            int n2 = 0;
+            int *h_map = reinterpret_cast<int *>(h_d); // not yet in use
+            for (int i = 0; i < nj; ++i) if (h_flag[i] == 2) h_map[n2++] = i;
+            if (n2 > 0) {
+                HIP_OK(hipMemcpyAsync(s_jobmap_, h_map, sizeof(int) * (size_t)n2, hipMemcpyHostToDevice, st));
+                HIP_OK(hipMemsetAsync(s_visited_, 0, vis_bytes_per_job * (size_t)n2, st));
+                LAUNCH(0, n2, lds, s_jobmap_, cand_cap);
+                HIP_OK(hipGetLastError());
+                stats_.search_repeats += (uint64_t)n2;
+            }
+        }
+#undef LAUNCH
+#undef LAUNCH2
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         HIP_OK(hipMemcpyAsync(h_ids, d_ids, 4u * (size_t)nj * k_out, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(h_d, d_d, 4u * (size_t)nj * k_out, hipMemcpyDeviceToHost, st));

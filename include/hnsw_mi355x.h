@@ -165,6 +165,7 @@ typedef struct hnswdev_stats {
     uint64_t search_timed_evals;
     double search_kernel_ms;      /* HIP-event durations of the timed search launches */
     uint64_t search_overflows;    /* traversals handed back to the lock-step path */
+    uint64_t search_repeats;      /* traversals repeated on the device with the exact two-heap variant (equal distances) */
 } hnswdev_stats;
 
 /* All return 0 on success, < 0 on error (message via hnswdev_last_error). */

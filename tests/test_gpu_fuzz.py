@@ -82,3 +82,44 @@ def test_extreme_parameters_match_oracle(Index, M, efc, ef, k, batch):
         assert ix.graph_hash() == ref.graph_hash(), traversal
         got = ix.knn_query(q, k)
         assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes(), traversal
+
+
+def _build(Index, x, M, efc, ef, batch):
+    ix = Index(x.shape[1])
+    ix.set_collection_size(x.shape[0]); ix.set_max_edges(M); ix.set_max_candidates(efc); ix.set_min_nn(ef)
+    ix.set_insert_batch(batch)
+    ix.add(x)
+    return ix
+
+
+@pytest.mark.parametrize("sorted_top", ["1", "0"])
+def test_sorted_list_and_two_heap_traversals_agree_with_the_oracle(Index, monkeypatch, sorted_top):
+    # the device traversal has a fast variant (one sorted list in registers, exact when no two
+    # coexisting candidates are equidistant) and the exact two-heap variant it falls back to
+    from common import uniform
+    monkeypatch.setenv("HNSW_MI355X_SORTED_TOP", sorted_top)
+    for (M, efc, ef, k) in [(8, 60, 40, 10), (16, 200, 128, 10), (12, 400, 300, 20), (6, 30, 600, 5)]:
+        x, q = uniform(3000, 32, 77), uniform(300, 32, 78)
+        ref = oracle.OracleIndex(32, max_edges=M, max_candidates=efc, min_nn=ef, collection_size=3000)
+        ref.add_batched(x, 16384)
+        ix = _build(Index, x, M, efc, ef, 16384)
+        assert ix.graph_hash() == ref.graph_hash()
+        want, got = ref.knn_query(q, k), ix.knn_query(q, k)
+        assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
+        assert ix.stats()["search_overflows"] == 0
+        if sorted_top == "0":
+            assert ix.stats()["search_repeats"] == 0
+
+
+def test_equal_distances_are_repeated_with_the_exact_traversal(Index):
+    # integer grid: most candidates tie; the sorted-list variant must notice every time
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 3, (4000, 10)).astype(np.float32)
+    q = rng.integers(0, 3, (500, 10)).astype(np.float32)
+    ref = oracle.OracleIndex(10, max_edges=10, max_candidates=50, min_nn=40, collection_size=4000)
+    ref.add_batched(x, 16384)
+    ix = _build(Index, x, 10, 50, 40, 16384)
+    assert ix.graph_hash() == ref.graph_hash()
+    want, got = ref.knn_query(q, 8), ix.knn_query(q, 8)
+    assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
+    assert ix.stats()["search_repeats"] > 400
