@@ -148,7 +148,7 @@ private:
     size_t s_visited_bytes_ = 0;
     SearchJob *s_jobs_ = nullptr;
     SearchHit *s_hits_ = nullptr;
-    int *s_cnt_ = nullptr, *s_flag_ = nullptr, *s_jobmap_ = nullptr;
+    int *s_cnt_ = nullptr, *s_flag_ = nullptr;
     unsigned long long *s_evals_ = nullptr;
     size_t s_jobs_cap_ = 0, s_hits_cap_ = 0;
     int *s_sel_ = nullptr, *s_lcnt_ = nullptr, *s_selU_ = nullptr, *s_cntU_ = nullptr, *s_iflag_ = nullptr;

@@ -555,11 +555,18 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
 //   push / trim to k       = ranked insertion, last one drops (compare + popcount + lane shift)
 //   farthestResultDist     = entry k - 1
 // which is straight-line wave-wide code instead of scalar sift loops in LDS (2/3 of the traversal
-// time at C2, all of it scalar-issue bound).  With equal distances the reference's results depend
-// on the heaps' array layout (pop order among equals, OrderBy / ToArray order), which a sorted
-// list does not reproduce: every insertion checks for an equal key among the entries it joins
-// and raises `tie`; the caller then repeats the job with the exact two-heap traversal below.
-// Position p lives in lane p & 63 of register set p >> 6; id bit 31 = expanded.
+// time at C2, all of it scalar-issue bound).  Equal distances: a heap removes "the" extreme
+// element, so as long as the extreme is unique the SETS in both heaps evolve identically whatever
+// the array layout.  The layout shows only when (i) the farthest result is evicted while another
+// entry has the same distance, (ii) the closest candidate is popped while another open candidate
+// has the same distance, or (iii) equal distances sit next to each other in what the caller
+// consumes in order (OrderBy + Take(k), Span.Sort).  (ii) and (iii) raise `tie` and the caller
+// repeats the job with the exact two-heap traversal below.  After (i) the survivor (the reference
+// may hold its twin instead -- same distance, other id, possibly still a candidate there) is only
+// marked DOUBTFUL: the search goes on, and `tie` is raised if a doubtful entry is popped or is still
+// in the list at the end; usually the next few insertions push it out and nothing depended on it.
+// Equal distances elsewhere in the list are harmless.  Position p lives in lane p & 63 of register
+// set p >> 6; id bit 31 = expanded, bit 30 = doubtful (node ids stay below 2^30).
 __device__ __forceinline__ int dpp_wave_shr1(int carry_in, int v)
 {
     return __builtin_amdgcn_update_dpp(carry_in, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); // lane 0 keeps carry_in
@@ -600,22 +607,33 @@ struct SortedTop {
         }
         return -1;
     }
-    __device__ __forceinline__ void mark(int p, int lane)
+    __device__ __forceinline__ void mark(int p, int lane, int bit = (int)0x80000000)
     {
 #pragma unroll
         for (int t = 0; t < NS; ++t)
-            if ((p >> 6) == t && lane == (p & 63)) id[t] |= (int)0x80000000;
+            if ((p >> 6) == t && lane == (p & 63)) id[t] |= bit;
     }
-    // ranked insertion of (xk, xid); beyond k entries the last one drops
-    __device__ __forceinline__ void insert(unsigned xk, int xid, int &count, int k, int lane, bool &tie)
+    __device__ __forceinline__ void mark_key(unsigned k0, int count, int lane, int bit) // every entry of that key
+    {
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            if (lane + 64 * t < count && key[t] == k0) id[t] |= bit;
+    }
+    __device__ __forceinline__ bool any_flagged(int count, int lane, int bit) const // uniform result
+    {
+        bool f = false;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) f |= lane + 64 * t < count && (id[t] & bit) != 0;
+        return __ballot(f) != 0ull;
+    }
+    // ranked insertion of (xk, xid), before any entries of equal key; beyond k entries the last one drops
+    __device__ __forceinline__ void insert(unsigned xk, int xid, int &count, int k, int lane)
     {
         int r = 0;
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             if (64 * t >= count) break;
-            const bool valid = lane + 64 * t < count;
-            r += (int)__popcll(__ballot(valid && key[t] < xk));
-            tie |= valid && key[t] == xk;
+            r += (int)__popcll(__ballot(lane + 64 * t < count && key[t] < xk));
         }
 #pragma unroll
         for (int t = NS - 1; t >= 0; --t) {
@@ -630,14 +648,29 @@ struct SortedTop {
         }
         if (count < k) ++count;
     }
+    // any p in [1, upto) with key[p] == key[p - 1]?  (uniform result)
+    __device__ __forceinline__ bool adjacent_equal(int upto, int lane) const
+    {
+        bool eq = false;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (64 * t >= upto) break;
+            int ck = 0;
+            if (t > 0) ck = __builtin_amdgcn_readlane((int)key[t - 1], 63);
+            const unsigned prev = (unsigned)dpp_wave_shr1(ck, (int)key[t]);
+            const int p = lane + 64 * t;
+            eq |= p >= 1 && p < upto && key[t] == prev;
+        }
+        return __ballot(eq) != 0ull;
+    }
 };
 
 // Returns false on a NaN / -0 distance (exact host re-run); `tie` asks for the exact two-heap
 // traversal.  Result: L.top[0..top_n) ascending by distance.  The query must be staged in L.qs.
 template <int METRIC, int NS>
 __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
-                                                const GraphView &G, const SearchJob jb, int k, unsigned *vis, const SearchLds &L,
-                                                int lane, int &top_n_out, bool &tie_out, unsigned long long &evals)
+                                                const GraphView &G, const SearchJob jb, int k, int ordered_prefix, unsigned *vis,
+                                                const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals)
 {
     int *nbuf = L.nbuf;
     float *dbuf = L.dbuf;
@@ -654,16 +687,18 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     int top_n = 0;
     bool unsafe = key_unsafe(cur); // NaN / -0 (see f2key)
     bool tie = false;
-    T.insert(f2key(cur), best, top_n, k, lane, tie);                 // :134, :138
+    T.insert(f2key(cur), best, top_n, k, lane);                      // :134, :138
     if (lane == 0) atomicOr(&vis[best >> 5], 1u << (best & 31));     // :140
     unsigned far_key = f2key(cur);                                   // farthestResultDist :135
     int pre_id = -1, pre_a = 0, pre_b = 0; // speculative prefetch of the next expansion's list (see traverse)
     const int lstride = layer == 0 ? G.stride0 : G.strideU;
     PH(0);
-    while (!unsafe) {
+    constexpr int kDoubt = 0x40000000, kIdMask = 0x3fffffff;
+    while (!unsafe && !tie) {
         const int pos = T.first_open(top_n, lane); // :146 closest candidate; none left <=> :147-150 / empty
         if (pos < 0) break;
         const HEnt c = T.at(pos);
+        if (c.id & kDoubt) { tie = true; break; } // the reference may be expanding its twin instead
         T.mark(pos, lane);
         PH(1);
         int n, nb_a = 0, nb_b = 0;
@@ -703,7 +738,9 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         {
             const int nxt = T.first_open(top_n, lane);
             if (nxt >= 0) {
-                pre_id = T.at(nxt).id;
+                const HEnt e = T.at(nxt);
+                if (e.key == c.key) tie = true; // (ii): which of the two the reference pops first is a matter of heap layout
+                pre_id = e.id & kIdMask;
                 const int *pl = G.list(pre_id, layer);
                 pre_a = lane < lstride ? pl[lane] : 0;
                 pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
@@ -729,8 +766,13 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 maybe &= maybe - 1;
                 const unsigned dk = (unsigned)__builtin_amdgcn_readlane((int)my_key, src);
                 if (top_n < k || dk < far_key) { // :165
-                    T.insert(dk, __builtin_amdgcn_readlane(my_id, src), top_n, k, lane, tie); // :168-174
-                    if (top_n == k) far_key = T.key_at(k - 1);                                // :176-177
+                    const bool evicts = top_n == k;
+                    T.insert(dk, __builtin_amdgcn_readlane(my_id, src), top_n, k, lane); // :168-174
+                    if (top_n == k) {
+                        const unsigned nf = T.key_at(k - 1);                             // :176-177
+                        if (evicts && nf == far_key) T.mark_key(nf, top_n, lane, kDoubt); // (i): one of several equally far results was dropped
+                        far_key = nf;
+                    }
                 }
             }
         }
@@ -743,11 +785,13 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
         const int p = lane + 64 * t;
-        if (p < top_n) { L.top[p].id = T.id[t] & 0x7fffffff; L.top[p].dist = key2f(T.key[t]); }
+        if (p < top_n) { L.top[p].id = T.id[t] & kIdMask; L.top[p].dist = key2f(T.key[t]); }
     }
     __syncthreads();
     top_n_out = top_n;
-    tie_out = __ballot(tie) != 0ull;
+    if (T.adjacent_equal(min(top_n, ordered_prefix), lane)) tie = true; // (iii)
+    if (T.any_flagged(top_n, lane, kDoubt)) tie = true;                  // (i) left unresolved
+    tie_out = tie;
     return !unsafe;
 }
 
@@ -1016,15 +1060,15 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
     return rc;
 }
 
-// NS > 0: sorted-list traversal with NS register sets (k <= 64 * NS); out_flag 2 = equal distances
-// met, repeat with NS = 0 (the exact two-heap traversal).  job_map (optional): blockIdx -> job for
-// such a repeat launch; scratch (visited, spill) is indexed by blockIdx, results by job.
+// NS > 0: sorted-list traversal with NS register sets (k <= 64 * NS); a wave that meets equal
+// distances where the heap layout shows starts over with the exact two-heap traversal (out_flag 2,
+// informational).  NS = 0: two-heap traversal only.
 template <int METRIC, int NS>
 __global__ void __launch_bounds__(64)
 graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
-                    const SearchJob *__restrict__ jobs, const int *__restrict__ job_map, int k, int cand_cap, ND *__restrict__ spill,
+                    const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
                     int spill_cap, unsigned *__restrict__ visited, long long vis_words, int k_out, int *__restrict__ out_ids,
                     float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
                     unsigned long long *__restrict__ eval_counter, int nbcap)
@@ -1032,7 +1076,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
-    const int job = job_map ? job_map[blockIdx.x] : (int)blockIdx.x;
+    const int job = blockIdx.x;
     const SearchJob jb = jobs[job];
     unsigned *vis = visited + (size_t)blockIdx.x * (size_t)vis_words;
     const GraphView G{adj0, stride0, upper, pool, strideU};
@@ -1049,22 +1093,33 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
     unsigned long long evals = 0;
     int top_n = 0;
+    bool repeated = false;
     if constexpr (NS > 0) {
         bool tie = false;
-        const bool ok = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, vis, L, lane, top_n, tie, evals);
-        // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
-        // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
-        for (int r = lane; r < k_out; r += 64) {
-            const bool have = r < top_n;
-            out_ids[(size_t)job * k_out + r] = have ? L.top[r].id : -1;
-            out_d[(size_t)job * k_out + r] = have ? L.top[r].dist : __uint_as_float(0x7fc00000u);
+        // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
+        const bool ok1 = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, vis, L, lane, top_n, tie, evals);
+        if (!(ok1 && tie)) {
+            // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
+            // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
+            for (int r = lane; r < k_out; r += 64) {
+                const bool have = r < top_n;
+                out_ids[(size_t)job * k_out + r] = have ? L.top[r].id : -1;
+                out_d[(size_t)job * k_out + r] = have ? L.top[r].dist : __uint_as_float(0x7fc00000u);
+            }
+            if (lane == 0) {
+                out_cnt[job] = ok1 ? top_n : 0;
+                out_flag[job] = ok1 ? 0 : 1;
+                atomicAdd(eval_counter, evals);
+            }
+            return;
         }
-        if (lane == 0) {
-            out_cnt[job] = ok ? top_n : 0;
-            out_flag[job] = ok ? (tie ? 2 : 0) : 1;
-            if (!(ok && tie)) atomicAdd(eval_counter, evals); // a repeated job is counted by its repeat
-        }
-        return;
+        // equal distances where the heap layout shows: this wave starts over with the exact traversal
+        __syncthreads();
+        for (long long w = lane; w < vis_words; w += 64) vis[w] = 0u;
+        __syncthreads();
+        evals = 0;
+        top_n = 0;
+        repeated = true;
     }
     const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)blockIdx.x * spill_cap, spill_cap, vis, L, lane, top_n, evals);
     // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(c => c.Dist) is a STABLE sort over the heap
@@ -1104,7 +1159,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     }
     if (lane == 0) {
         out_cnt[job] = ok ? top_n : 0;
-        out_flag[job] = ok ? 0 : 1;
+        out_flag[job] = ok ? (repeated ? 2 : 0) : 1; // 2: informational (answered by the exact traversal)
         atomicAdd(eval_counter, evals);
     }
 }
@@ -1120,8 +1175,7 @@ template <int METRIC, int NS>
 __global__ void __launch_bounds__(64)
 graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
-                           const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs,
-                           const int *__restrict__ job_map, int k,
+                           const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
                            int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
@@ -1130,7 +1184,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
-    const int job = job_map ? job_map[blockIdx.x] : (int)blockIdx.x;
+    const int job = blockIdx.x;
     SearchJob jb = jobs[job];
     unsigned *vis = visited + (size_t)blockIdx.x * (size_t)vis_words;
     const GraphView G{adj0, stride0, upper, pool, strideU};
@@ -1150,18 +1204,29 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         }
         int top_n = 0;
         const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
+        bool exact = NS == 0;
         if constexpr (NS > 0) {
             bool tie = false;
-            ok = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, vis, L, lane, top_n, tie, evals);
+            const unsigned long long ev0 = evals;
+            ok = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k, vis, L, lane, top_n, tie, evals); // Span.Sort consumes all
             if (!ok) break;
-            // equal distances, or fewer candidates than MaxEdges (the heuristic then returns them in
-            // HEAP order, Heuristic.cs:13-18): the exact traversal repeats this item
-            if (tie || top_n < max_edges) { repeat = true; break; }
-        } else {
+            // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
+            // then returns them in HEAP order, Heuristic.cs:13-18): this layer again, exact traversal
+            if (tie || top_n < max_edges) {
+                exact = true;
+                repeat = true;
+                evals = ev0;
+                top_n = 0;
+                __syncthreads();
+                for (long long w = lane; w < vis_words; w += 64) vis[w] = 0u;
+                __syncthreads();
+            }
+        }
+        if (exact) {
             ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)blockIdx.x * spill_cap, spill_cap, vis, L, lane, top_n, evals);
             if (!ok) break;
         }
-        const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, NS > 0);
+        const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact);
         int *osel = layer == 0 ? out_sel0 + (size_t)job * sel_stride : out_selU + (size_t)(jb.aux + layer - 1) * sel_stride;
         for (int i = lane; i < rc; i += 64) osel[i] = L.acc[i];
         if (lane == 0) { if (layer == 0) out_cnt0[job] = rc; else out_cntU[jb.aux + layer - 1] = rc; }
@@ -1172,8 +1237,8 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         __syncthreads();
     }
     if (lane == 0) {
-        out_flag[job] = repeat ? 2 : ok ? 0 : 1;
-        if (!repeat) atomicAdd(eval_counter, evals);
+        out_flag[job] = ok ? (repeat ? 2 : 0) : 1; // 2: informational (a layer was answered by the exact traversal)
+        atomicAdd(eval_counter, evals);
     }
 }
 
@@ -1345,7 +1410,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobmap_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -1604,6 +1669,7 @@ static int sorted_top_sets(int k)
     if (e && std::atoi(e) == 0) return 0;
     return k <= 64 ? 1 : k <= 128 ? 2 : k <= 256 ? 4 : k <= 512 ? 8 : 0;
 }
+constexpr long long kSortedTopMaxNodes = 1LL << 30; // the sorted list keeps two mark bits in the id word
 
 static int cand_lds_cap(int k, int dim, bool heur, int nbcap)
 {
@@ -1641,12 +1707,10 @@ bool Device::ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_
         if (s_jobs_) HIP_OK(hipFree(s_jobs_));
         if (s_cnt_) HIP_OK(hipFree(s_cnt_));
         if (s_flag_) HIP_OK(hipFree(s_flag_));
-        if (s_jobmap_) HIP_OK(hipFree(s_jobmap_));
         s_jobs_cap_ = (size_t)chunk;
         HIP_OK(hipMalloc(&s_jobs_, sizeof(SearchJob) * s_jobs_cap_));
         HIP_OK(hipMalloc(&s_cnt_, sizeof(int) * s_jobs_cap_));
         HIP_OK(hipMalloc(&s_flag_, sizeof(int) * s_jobs_cap_));
-        HIP_OK(hipMalloc(&s_jobmap_, sizeof(int) * s_jobs_cap_));
     }
     if (k > 0 && !grow_dev(&s_hits_, &s_hits_cap_, (size_t)chunk * k)) return false;
     if (!grow_dev(&s_spill_, &s_spill_cap_, (size_t)chunk * kSpillCap + 8)) return false; // +8: get2 may read one entry past a heap
@@ -1680,8 +1744,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     const int cand_cap = cand_lds_cap(k, dim_, true, nbcap());
     const size_t lds = search_lds_bytes(k, cand_cap, dim_, true, nbcap());
     if (lds > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
-    const int ns = sorted_top_sets(k);
-    const size_t lds_sorted = search_lds_bytes(k, 0, dim_, true, nbcap());
+    const int ns = g_n_ < kSortedTopMaxNodes ? sorted_top_sets(k) : 0;
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     const int sel_stride = max_edges0;
@@ -1718,41 +1781,25 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-#define LAUNCH2(M, NS_, GRID, LDS, MAP, CAP)                                                                               \
+#define LAUNCH2(M, NS_, GRID, LDS, CAP)                                                                               \
     hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_>), dim3(GRID), dim3(64), LDS, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
-                       g_upper_, g_pool_, g_strideU_, s_jobs_, MAP, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
+                       g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
                        sel_stride, s_iflag_ + off, s_evals_, nbcap())
-#define LAUNCH(NS_, GRID, LDS, MAP, CAP)                                                                                   \
+#define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
     do {                                                                                                                   \
-        if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, MAP, CAP);                                                      \
-        else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, GRID, LDS, MAP, CAP);                                               \
-        else LAUNCH2(M_UCOS, NS_, GRID, LDS, MAP, CAP);                                                                    \
+        if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, CAP);                                                      \
+        else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, GRID, LDS, CAP);                                               \
+        else LAUNCH2(M_UCOS, NS_, GRID, LDS, CAP);                                                                    \
     } while (0)
-        const int *no_map = nullptr;
         switch (ns) {
-        case 1: LAUNCH(1, nj, lds_sorted, no_map, 0); break;
-        case 2: LAUNCH(2, nj, lds_sorted, no_map, 0); break;
-        case 4: LAUNCH(4, nj, lds_sorted, no_map, 0); break;
-        case 8: LAUNCH(8, nj, lds_sorted, no_map, 0); break;
-        default: LAUNCH(0, nj, lds, no_map, cand_cap); break;
+        case 1: LAUNCH(1, nj, lds, cand_cap); break;
+        case 2: LAUNCH(2, nj, lds, cand_cap); break;
+        case 4: LAUNCH(4, nj, lds, cand_cap); break;
+        case 8: LAUNCH(8, nj, lds, cand_cap); break;
+        default: LAUNCH(0, nj, lds, cand_cap); break;
         }
         HIP_OK(hipGetLastError());
-        if (ns > 0) { // items that met equal distances or a short candidate list: exact two-heap traversal
-            HIP_OK(hipMemcpyAsync(h_flag + off, s_iflag_ + off, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
-            HIP_OK(hipStreamSynchronize(st));
-            int n2 = 0;
-            int *h_map = reinterpret_cast<int *>(h_jobs); // staged jobs are on the device by now
-            static_assert(sizeof(SearchJob) >= sizeof(int), "job map fits the job staging buffer");
-            for (int i = 0; i < nj; ++i) if (h_flag[off + i] == 2) h_map[n2++] = i;
-            if (n2 > 0) {
-                HIP_OK(hipMemcpyAsync(s_jobmap_, h_map, sizeof(int) * (size_t)n2, hipMemcpyHostToDevice, st));
-                HIP_OK(hipMemsetAsync(s_visited_, 0, vis_bytes_per_job * (size_t)n2, st));
-                LAUNCH(0, n2, lds, s_jobmap_, cand_cap);
-                HIP_OK(hipGetLastError());
-                stats_.search_repeats += (uint64_t)n2;
-            }
-        }
 #undef LAUNCH
 #undef LAUNCH2
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
@@ -1776,7 +1823,10 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     }
     HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    for (int i = 0; i < njobs; ++i) stats_.search_overflows += (uint64_t)(h_flag[i] != 0);
+    for (int i = 0; i < njobs; ++i) {
+        if (h_flag[i] == 2) { stats_.search_repeats++; h_flag[i] = 0; }
+        stats_.search_overflows += (uint64_t)(h_flag[i] != 0);
+    }
     *res = InsertResults{h_sel0, h_cnt0, h_selU, h_cntU, h_flag, sel_stride};
     return true;
 }
@@ -1905,8 +1955,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     const int cand_cap = cand_lds_cap(k, dim_, false, nbcap());
     const size_t lds = search_lds_bytes(k, cand_cap, dim_, false, nbcap());
     if (lds > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
-    const int ns = sorted_top_sets(k);
-    const size_t lds_sorted = search_lds_bytes(k, 0, dim_, false, nbcap());
+    const int ns = g_n_ < kSortedTopMaxNodes ? sorted_top_sets(k) : 0;
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     const long long vis_words = (g_n_ + 31) / 32;
@@ -1933,39 +1982,24 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-#define LAUNCH2(M, NS_, GRID, LDS, MAP, CAP)                                                                               \
+#define LAUNCH2(M, NS_, GRID, LDS, CAP)                                                                               \
     hipLaunchKernelGGL((graph_search_kernel<M, NS_>), dim3(GRID), dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
-                       g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, MAP, k, CAP, reinterpret_cast<ND *>(s_spill_), \
+                       g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
                        spill_cap_for_tests(), s_visited_, vis_words, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap())
-#define LAUNCH(NS_, GRID, LDS, MAP, CAP)                                                                                   \
+#define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
     do {                                                                                                                   \
-        if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, MAP, CAP);                                                      \
-        else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, GRID, LDS, MAP, CAP);                                               \
-        else LAUNCH2(M_UCOS, NS_, GRID, LDS, MAP, CAP);                                                                    \
+        if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, CAP);                                                      \
+        else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, GRID, LDS, CAP);                                               \
+        else LAUNCH2(M_UCOS, NS_, GRID, LDS, CAP);                                                                    \
     } while (0)
-        const int *no_map = nullptr;
         switch (ns) {
-        case 1: LAUNCH(1, nj, lds_sorted, no_map, 0); break;
-        case 2: LAUNCH(2, nj, lds_sorted, no_map, 0); break;
-        case 4: LAUNCH(4, nj, lds_sorted, no_map, 0); break;
-        case 8: LAUNCH(8, nj, lds_sorted, no_map, 0); break;
-        default: LAUNCH(0, nj, lds, no_map, cand_cap); break;
+        case 1: LAUNCH(1, nj, lds, cand_cap); break;
+        case 2: LAUNCH(2, nj, lds, cand_cap); break;
+        case 4: LAUNCH(4, nj, lds, cand_cap); break;
+        case 8: LAUNCH(8, nj, lds, cand_cap); break;
+        default: LAUNCH(0, nj, lds, cand_cap); break;
         }
         HIP_OK(hipGetLastError());
-        if (ns > 0) { // jobs that met equal distances: once more, with the exact two-heap traversal
-            HIP_OK(hipMemcpyAsync(h_flag, s_flag_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
-            HIP_OK(hipStreamSynchronize(st));
-            int n2 = 0;
-            int *h_map = reinterpret_cast<int *>(h_d); // not yet in use
-            for (int i = 0; i < nj; ++i) if (h_flag[i] == 2) h_map[n2++] = i;
-            if (n2 > 0) {
-                HIP_OK(hipMemcpyAsync(s_jobmap_, h_map, sizeof(int) * (size_t)n2, hipMemcpyHostToDevice, st));
-                HIP_OK(hipMemsetAsync(s_visited_, 0, vis_bytes_per_job * (size_t)n2, st));
-                LAUNCH(0, n2, lds, s_jobmap_, cand_cap);
-                HIP_OK(hipGetLastError());
-                stats_.search_repeats += (uint64_t)n2;
-            }
-        }
 #undef LAUNCH
 #undef LAUNCH2
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
@@ -1976,6 +2010,9 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         HIP_OK(hipStreamSynchronize(st));
         memcpy(out_ids + (size_t)off * k_out, h_ids, 4u * (size_t)nj * k_out);
         memcpy(out_d + (size_t)off * k_out, h_d, 4u * (size_t)nj * k_out);
+        for (int i = 0; i < nj; ++i) {
+            if (h_flag[i] == 2) { stats_.search_repeats++; h_flag[i] = 0; }
+        }
         memcpy(out_flag + off, h_flag, sizeof(int) * (size_t)nj);
         const unsigned long long ev = *h_ev;
         stats_.search_launches++;

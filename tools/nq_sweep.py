@@ -26,4 +26,4 @@ for nq in [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (10
     s = ix.stats()
     kms = s["search_kernel_ms"] / max(1, s["search_timed_launches"])
     gbs = s["search_timed_evals"] * dim * 4 / (s["search_kernel_ms"] * 1e-3) / 1e9
-    print(f"nq={nq:7d}  {nq / dt:10.0f} q/s  kernel {kms:7.3f} ms  {gbs:7.1f} GB/s  frac {gbs / 8000:.3f}", flush=True)
+    print(f"nq={nq:7d}  {nq / dt:10.0f} q/s  kernel {kms:7.3f} ms  {gbs:7.1f} GB/s  frac {gbs / 8000:.3f}  repeats {s['search_repeats']}", flush=True)
