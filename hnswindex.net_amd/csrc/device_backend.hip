@@ -491,6 +491,8 @@ struct GraphView {
 
 #ifdef EXP_PHASE_CLOCKS // experiment build: shader-clock cycles per traversal phase, summed over waves
 __device__ unsigned long long g_phase[12];
+__device__ unsigned long long g_phase_link[12];
+#define PH_FLUSH_LINK() do { if (lane == 0) for (int ph_i = 0; ph_i < 8; ++ph_i) atomicAdd(&g_phase_link[ph_i], (unsigned long long)ph_acc[ph_i]); } while (0)
 #define PH_DECL() long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_t = __builtin_readcyclecounter()
 #define PH(i) do { long long ph_n = __builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; } while (0)
 #define PH_COUNT(i, v) ph_acc[i] += (v)
@@ -500,6 +502,7 @@ __device__ unsigned long long g_phase[12];
 #define PH(i) do {} while (0)
 #define PH_COUNT(i, v) do {} while (0)
 #define PH_FLUSH() do {} while (0)
+#define PH_FLUSH_LINK() do {} while (0)
 #endif
 
 // FindEntryPoint / FindEntryAtLayer (GraphNavigator.cs:27-82): greedy descent from jb.entry at
@@ -1281,21 +1284,37 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
     for (int i = lane; i < cnt; i += 64) L.nbuf[i] = l[1 + i];
     __syncthreads();
     unsigned long long evals = 0;
+    PH_DECL();
+    PH(0);
     for (int t = g_off[g]; t < g_off[g + 1]; ++t) {
         if (lane == 0) L.nbuf[cnt] = g_items[t]; // :207
         cnt++;
         __syncthreads();
+        PH_COUNT(6, 1);
         if (cnt > max_edges) { // :209
+            PH_COUNT(7, 1);
             measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, L.nbuf, L.dbuf, cnt, lane); // Distance(cand, node.Id) :233
             __syncthreads();
+            PH(1);
             evals += (unsigned long long)cnt;
             for (int i = lane; i < cnt; i += 64) L.top[i] = ND{L.nbuf[i], L.dbuf[i]};
+#ifdef EXP_PHASE_CLOCKS
+            __syncthreads();
+            dev_dotnet_sort(L.top, cnt, L.stk);
+            __syncthreads();
+            PH(2);
+            const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, cnt, max_edges, L, lane, evals, true);
+            PH(3);
+#else
             const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, cnt, max_edges, L, lane, evals);
+#endif
             for (int i = lane; i < rc; i += 64) L.nbuf[i] = L.acc[i]; // node.OutEdges[layer] = newOut :236
             cnt = rc;
             __syncthreads();
         }
     }
+    PH(4);
+    PH_FLUSH_LINK();
     if (lane == 0) { l[0] = cnt; out_lists[(size_t)g * list_stride] = cnt; }
     for (int i = lane; i < cnt; i += 64) { l[1 + i] = L.nbuf[i]; out_lists[(size_t)g * list_stride + 1 + i] = L.nbuf[i]; }
     if (lane == 0) atomicAdd(eval_counter, evals);
@@ -1403,6 +1422,12 @@ Device::~Device()
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) == hipSuccess) {
             double tot = 0;
             for (int i = 0; i < 6; ++i) tot += (double)h[i];
+            unsigned long long hl[12] = {0};
+            (void)hipMemcpyFromSymbol(hl, HIP_SYMBOL(g_phase_link), sizeof hl);
+            double tl = 0;
+            for (int i = 0; i < 5; ++i) tl += (double)hl[i];
+            fprintf(stderr, "[phase clocks, link] stage %.1f%% measure %.1f%% sort %.1f%% heuristic %.1f%% rest %.1f%% | appends %llu, prunes %llu, cycles/prune %.0f\n",
+                    100 * hl[0] / tl, 100 * hl[1] / tl, 100 * hl[2] / tl, 100 * hl[3] / tl, 100 * hl[4] / tl, hl[6], hl[7], tl / (double)std::max(1ull, hl[7]));
             fprintf(stderr, "[phase clocks] descent %.1f%% pop %.1f%% list %.1f%% visited %.1f%% rows %.1f%% push %.1f%% | expansions %llu, prefetch hits %llu (%.1f%%), cycles/expansion %.0f\n",
                     100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, h[7], h[6],
                     100.0 * h[6] / (double)std::max(1ull, h[7]), tot / (double)std::max(1ull, h[7]));

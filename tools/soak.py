@@ -1,0 +1,36 @@
+"""Parity soak at sizes between the unit tests and the full-size test: float-resolution ties are
+common enough there (a few per thousand traversals) to exercise the sorted-list traversal's tie
+rules against the oracle.  Usage: python tools/soak.py [n] [dim] [nq]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import hnswindex  # noqa: E402
+import oracle  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60_000
+dim = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+nq = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
+fails = 0
+for seed, (M, efc, ef, k) in enumerate([(16, 200, 128, 10), (8, 100, 64, 5), (24, 300, 256, 20)]):
+    rng = np.random.default_rng(900 + seed)
+    x = rng.random((n, dim), dtype=np.float32)
+    q = rng.random((nq, dim), dtype=np.float32)
+    ix = hnswindex.Index(dim)
+    ix.set_collection_size(n); ix.set_max_edges(M); ix.set_max_candidates(efc); ix.set_min_nn(ef)
+    t = time.time(); ix.add(x); tb = time.time() - t
+    ref = oracle.OracleIndex(dim, max_edges=M, max_candidates=efc, min_nn=ef, collection_size=n)
+    t = time.time(); ref.add_batched(x, 16384); tr = time.time() - t
+    same_graph = ix.graph_hash() == ref.graph_hash()
+    s0 = ix.stats()
+    got = ix.knn_query(q, k)
+    s1 = ix.stats()
+    want = ref.knn_query(q, k, threads=16)
+    same_q = bool((got[0] == want[0]).all()) and got[1].tobytes() == want[1].tobytes()
+    print(f"M={M} efC={efc} ef={ef} k={k}: graph {'same' if same_graph else 'DIFFERENT'} (gpu {tb:.1f}s, oracle {tr:.1f}s, "
+          f"build repeats {s0['search_repeats']}), queries {'same' if same_q else 'DIFFERENT'} "
+          f"(repeats {s1['search_repeats'] - s0['search_repeats']}, hand-backs {s1['search_overflows']})", flush=True)
+    fails += (not same_graph) + (not same_q)
+sys.exit(1 if fails else 0)
