@@ -35,7 +35,8 @@ def parse():
     p.add_argument("--n", "--index-size", dest="n", type=int, default=1_000_000, help="indexed vectors (BASELINE C2: 1M)")
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--metric", default="sq_euclid")
-    p.add_argument("--nq", type=int, default=10_000, help="queries per GPU per step")
+    p.add_argument("--nq", type=int, default=65_536, help="queries per GPU per step (one batched knn_query call)")
+    p.add_argument("--small-batch", type=int, default=10_000, help="also time batches of this many queries (N=1 only; 0 = skip)")
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--max-edges", type=int, default=16)
     p.add_argument("--ef-construction", type=int, default=200)
@@ -163,6 +164,16 @@ def main():
         step_pcie()
     barrier()
     dt_pcie = (time.perf_counter() - t0) / 2
+    small = None
+    if world == 1 and 0 < a.small_batch < a.nq:  # the same step on a smaller batch: launch fill / tail effects
+        ix.set_resident_queries(q_all[:a.small_batch])
+        ix.knn_query_resident(a.k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ix.knn_query_resident(a.k)
+        torch.cuda.synchronize()
+        small = a.small_batch * 10 / (time.perf_counter() - t0)
     ix.set_resident_queries(q_all[lo:hi])
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -264,7 +275,8 @@ def main():
         "build_evals": build_stats["evals"] + build_stats["search_evals"],
         "build_launches": build_stats["launches"] + build_stats["search_launches"],
         "evals_per_query": round((st["search_evals"] + st["evals"]) / (a.nq * a.steps), 1),
-        "traversal": a.traversal, "search_overflows": st["search_overflows"],
+        "traversal": a.traversal, "search_overflows": st["search_overflows"], "search_repeats": st["search_repeats"],
+        "small_batch": None if small is None else {"queries_per_batch": a.small_batch, "queries_per_sec": round(small, 1)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

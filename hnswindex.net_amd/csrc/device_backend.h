@@ -146,6 +146,8 @@ private:
     // search scratch
     unsigned *s_visited_ = nullptr;
     size_t s_visited_bytes_ = 0;
+    int *s_jobctr_ = nullptr; // persistent launches: next job
+    int num_cu_ = 256;
     SearchJob *s_jobs_ = nullptr;
     SearchHit *s_hits_ = nullptr;
     int *s_cnt_ = nullptr, *s_flag_ = nullptr;
@@ -159,7 +161,7 @@ private:
     size_t s_spill_cap_ = 0;
     int *s_lk_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t s_lk_cap_[5] = {0, 0, 0, 0, 0};
-    bool ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_job);
+    bool ensure_search_scratch(long long chunk, long long slots, int k, size_t vis_bytes_per_job);
     void *pinned_stage(size_t bytes);
     struct HostGraphStage;
     HostGraphStage *hg_ = nullptr;

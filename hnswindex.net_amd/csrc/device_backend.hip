@@ -1066,22 +1066,30 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
 // NS > 0: sorted-list traversal with NS register sets (k <= 64 * NS); a wave that meets equal
 // distances where the heap layout shows starts over with the exact two-heap traversal (out_flag 2,
 // informational).  NS = 0: two-heap traversal only.
+// The wave's visited bitset back to all zero (vis_words is a multiple of 4, the arena 16-byte aligned).
+__device__ __forceinline__ void clear_visited(unsigned *vis, long long vis_words, int lane)
+{
+    __syncthreads();
+    uint4 *v4 = reinterpret_cast<uint4 *>(vis);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (long long w = lane; w < (vis_words >> 2); w += 64) v4[w] = z;
+    __syncthreads();
+}
+
+// One job on this wave.  `vis` / `spill`: the wave's own scratch (vis all zero on entry; the caller
+// clears it afterwards).
 template <int METRIC, int NS>
-__global__ void __launch_bounds__(64)
-graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
+__device__ __forceinline__ void search_job(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
                     const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
-                    int spill_cap, unsigned *__restrict__ visited, long long vis_words, int k_out, int *__restrict__ out_ids,
+                    int spill_cap, unsigned *__restrict__ vis, long long vis_words, int k_out, int *__restrict__ out_ids,
                     float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
-                    unsigned long long *__restrict__ eval_counter, int nbcap)
+                    unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
-    const int job = blockIdx.x;
     const SearchJob jb = jobs[job];
-    unsigned *vis = visited + (size_t)blockIdx.x * (size_t)vis_words;
     const GraphView G{adj0, stride0, upper, pool, strideU};
 
     const float *q;
@@ -1117,14 +1125,12 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
             return;
         }
         // equal distances where the heap layout shows: this wave starts over with the exact traversal
-        __syncthreads();
-        for (long long w = lane; w < vis_words; w += 64) vis[w] = 0u;
-        __syncthreads();
+        clear_visited(vis, vis_words, lane);
         evals = 0;
         top_n = 0;
         repeated = true;
     }
-    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)blockIdx.x * spill_cap, spill_cap, vis, L, lane, top_n, evals);
+    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, vis, L, lane, top_n, evals);
     // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(c => c.Dist) is a STABLE sort over the heap
     // array (ToArray(), BinaryHeap.cs:41-44) and only the first k_out survive -- so select the
     // k_out smallest (float.CompareTo order: NaN first, -0 == +0) with ties broken by array index:
@@ -1167,6 +1173,35 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     }
 }
 
+// Persistent launch: one wave per block, as many blocks as stay resident; each takes jobs from a
+// shared counter until none are left.  A wave owns one visited bitset and one spill area for the
+// whole launch and leaves the bitset clean after every job, so the scratch is sized by the
+// resident waves (not by the batch) and nothing is memset between launches.
+template <int METRIC, int NS>
+__global__ void __launch_bounds__(64)
+graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
+                    const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
+                    const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
+                    const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
+                    int spill_cap, unsigned *__restrict__ visited, long long vis_words, int k_out, int *__restrict__ out_ids,
+                    float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
+                    unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    unsigned *vis = visited + (size_t)blockIdx.x * (size_t)vis_words;
+    ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
+    for (;;) {
+        int job = 0;
+        if (lane == 0) job = atomicAdd(job_counter, 1);
+        job = __builtin_amdgcn_readfirstlane(job);
+        if (job >= njobs) break;
+        search_job<METRIC, NS>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
+                               vis, vis_words, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job);
+        clear_visited(vis, vis_words, lane);
+    }
+}
+
 // Insert, search half, fused: for one new item, GraphConnector.AddNewConnections' whole loop
 // (GraphConnector.cs:172-181): FindEntryPoint, then for every layer of the item ConnectAtLayer's
 // SearchLayer + RelativeNeighborPruning (:189-190) with the next layer's entry = selected[0]
@@ -1175,21 +1210,17 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
 // selection order (layer 0 -> slot `job`; layer L >= 1 -> upper slot jobs[].aux + L - 1).
 // jobs[].search_layer = the item's first layer min(level, top).
 template <int METRIC, int NS>
-__global__ void __launch_bounds__(64)
-graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+__device__ __forceinline__ void insert_job(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
-                           int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
+                           int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ vis, long long vis_words,
                            int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
-                           unsigned long long *__restrict__ eval_counter, int nbcap)
+                           unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
-    const int job = blockIdx.x;
     SearchJob jb = jobs[job];
-    unsigned *vis = visited + (size_t)blockIdx.x * (size_t)vis_words;
     const GraphView G{adj0, stride0, upper, pool, strideU};
     const int item = ~jb.qref;
     const float *q = rows + (size_t)item * dim;
@@ -1200,11 +1231,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
     bool ok = true, repeat = false;
     const int first_layer = jb.search_layer;
     for (int layer = first_layer; layer >= 0 && ok; --layer) {
-        if (layer != first_layer) { // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
-            __syncthreads();
-            for (long long w = lane; w < vis_words; w += 64) vis[w] = 0u;
-            __syncthreads();
-        }
+        if (layer != first_layer) clear_visited(vis, vis_words, lane); // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
         int top_n = 0;
         const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
         bool exact = NS == 0;
@@ -1220,13 +1247,11 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
                 repeat = true;
                 evals = ev0;
                 top_n = 0;
-                __syncthreads();
-                for (long long w = lane; w < vis_words; w += 64) vis[w] = 0u;
-                __syncthreads();
+                clear_visited(vis, vis_words, lane);
             }
         }
         if (exact) {
-            ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill + (size_t)blockIdx.x * spill_cap, spill_cap, vis, L, lane, top_n, evals);
+            ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, vis, L, lane, top_n, evals);
             if (!ok) break;
         }
         const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact);
@@ -1242,6 +1267,31 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
     if (lane == 0) {
         out_flag[job] = ok ? (repeat ? 2 : 0) : 1; // 2: informational (a layer was answered by the exact traversal)
         atomicAdd(eval_counter, evals);
+    }
+}
+
+template <int METRIC, int NS>
+__global__ void __launch_bounds__(64)
+graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                           const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
+                           const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
+                           int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
+                           int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
+                           int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
+                           unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    unsigned *vis = visited + (size_t)blockIdx.x * (size_t)vis_words;
+    ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
+    for (;;) { // persistent, see graph_search_kernel
+        int job = 0;
+        if (lane == 0) job = atomicAdd(job_counter, 1);
+        job = __builtin_amdgcn_readfirstlane(job);
+        if (job >= njobs) break;
+        insert_job<METRIC, NS>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, vis,
+                               vis_words, out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job);
+        clear_visited(vis, vis_words, lane);
     }
 }
 
@@ -1404,6 +1454,10 @@ Device *Device::create(int device, int dim, int metric, long long capacity)
     hipStream_t st;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_dev_error("hipStreamCreate failed"); return fail(); }
     d->stream_ = st;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) d->num_cu_ = cus;
+    }
     if (!d->reserve(capacity > 0 ? capacity : 1)) return fail();
     return d;
 }
@@ -1435,7 +1489,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -1696,6 +1750,16 @@ static int sorted_top_sets(int k)
 }
 constexpr long long kSortedTopMaxNodes = 1LL << 30; // the sorted list keeps two mark bits in the id word
 
+// Blocks (= waves) of a persistent traversal launch: what stays resident on the chip.
+template <class K>
+static int resident_blocks(K kernel, size_t lds, int num_cu)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+    return per_cu * std::max(1, num_cu);
+}
+constexpr int kMaxSlots = 256 * 32; // scratch is sized for this many resident waves (8 per SIMD, 256 CUs)
+
 static int cand_lds_cap(int k, int dim, bool heur, int nbcap)
 {
     int cap = std::min(std::max(4 * k, 256), 4096);
@@ -1720,14 +1784,19 @@ static bool grow_dev(T **p, size_t *cap, size_t need)
     return true;
 }
 
-bool Device::ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_job)
+// chunk: jobs per launch (job / result buffers); slots: waves of a persistent launch (visited
+// bitsets, spill areas).  The visited arena is all zero between launches: zeroed when allocated,
+// and every wave clears its bitset after each job.
+bool Device::ensure_search_scratch(long long chunk, long long slots, int k, size_t vis_bytes_per_job)
 {
-    if (vis_bytes_per_job * (size_t)chunk > s_visited_bytes_) {
+    if (vis_bytes_per_job * (size_t)slots > s_visited_bytes_) {
         if (s_visited_) HIP_OK(hipFree(s_visited_));
         s_visited_ = nullptr;
-        s_visited_bytes_ = vis_bytes_per_job * (size_t)chunk;
+        s_visited_bytes_ = vis_bytes_per_job * (size_t)slots;
         HIP_OK(hipMalloc(&s_visited_, s_visited_bytes_));
+        HIP_OK(hipMemsetAsync(s_visited_, 0, s_visited_bytes_, S(stream_)));
     }
+    if (!s_jobctr_) HIP_OK(hipMalloc(&s_jobctr_, sizeof(int)));
     if ((size_t)chunk > s_jobs_cap_) {
         if (s_jobs_) HIP_OK(hipFree(s_jobs_));
         if (s_cnt_) HIP_OK(hipFree(s_cnt_));
@@ -1738,7 +1807,7 @@ bool Device::ensure_search_scratch(long long chunk, int k, size_t vis_bytes_per_
         HIP_OK(hipMalloc(&s_flag_, sizeof(int) * s_jobs_cap_));
     }
     if (k > 0 && !grow_dev(&s_hits_, &s_hits_cap_, (size_t)chunk * k)) return false;
-    if (!grow_dev(&s_spill_, &s_spill_cap_, (size_t)chunk * kSpillCap + 8)) return false; // +8: get2 may read one entry past a heap
+    if (!grow_dev(&s_spill_, &s_spill_cap_, (size_t)slots * kSpillCap + 8)) return false; // +8: get2 may read one entry past a heap
     if (!s_evals_) HIP_OK(hipMalloc(&s_evals_, sizeof(unsigned long long)));
     if (!ev0_) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); ev0_ = a; ev1_ = b; }
     return true;
@@ -1773,10 +1842,10 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     const int sel_stride = max_edges0;
-    const long long vis_words = (g_n_ + 31) / 32;
+    const long long vis_words = ((g_n_ + 31) / 32 + 3) & ~3LL;
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
-    long long chunk = std::min<long long>(njobs, std::max<long long>(256, (8LL << 30) / (long long)std::max<size_t>(vis_bytes_per_job, 1)));
-    if (!ensure_search_scratch(chunk, 0, vis_bytes_per_job)) return false;
+    const long long chunk = std::min<long long>(njobs, 1 << 20);
+    if (!ensure_search_scratch(chunk, kMaxSlots, 0, vis_bytes_per_job)) return false;
     const size_t nU = (size_t)std::max(n_upper, 1);
     if (!grow_dev(&s_sel_, &s_sel_cap_, (size_t)njobs * sel_stride) || !grow_dev(&s_lcnt_, &s_lcnt_cap_, (size_t)njobs) ||
         !grow_dev(&s_selU_, &s_selU_cap_, nU * sel_stride) || !grow_dev(&s_cntU_, &s_cntU_cap_, nU) ||
@@ -1802,15 +1871,17 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         const int nj = (int)std::min<long long>(chunk, njobs - off);
         memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
         HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemsetAsync(s_visited_, 0, vis_bytes_per_job * (size_t)nj, st));
+        HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int), st));
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-#define LAUNCH2(M, NS_, GRID, LDS, CAP)                                                                               \
-    hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_>), dim3(GRID), dim3(64), LDS, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
+#define LAUNCH2(M, NS_, GRID, LDS, CAP) \
+    hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_>), \
+                       dim3(std::min<int>(GRID, std::min(kMaxSlots, resident_blocks(graph_insert_search_kernel<M, NS_>, LDS, num_cu_)))), \
+                       dim3(64), LDS, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
-                       sel_stride, s_iflag_ + off, s_evals_, nbcap())
+                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_)
 #define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
     do {                                                                                                                   \
         if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, CAP);                                                      \
@@ -1906,7 +1977,7 @@ bool Device::link_batch(const int *rows, int nrows, int row_stride, const int *g
     if (list_stride < max_edges0 + 1 || max_edges0 + 1 > nbcap()) { set_dev_error("link_batch: list stride too small"); return false; }
     if (!bind()) return false;
     hipStream_t st = S(stream_);
-    if (!ensure_search_scratch(1, 0, 4)) return false;
+    if (!ensure_search_scratch(1, 1, 0, 16)) return false;
     const size_t need[5] = {(size_t)nrows * row_stride, (size_t)ngroups * 2, (size_t)ngroups + 1, (size_t)std::max(total, 1), (size_t)ngroups * list_stride};
     for (int i = 0; i < 5; ++i) if (!grow_dev(&s_lk_[i], &s_lk_cap_[i], std::max<size_t>(need[i], 1))) return false;
     if (nrows > 0) {
@@ -1983,11 +2054,10 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     const int ns = g_n_ < kSortedTopMaxNodes ? sorted_top_sets(k) : 0;
     if (!bind()) return false;
     hipStream_t st = S(stream_);
-    const long long vis_words = (g_n_ + 31) / 32;
+    const long long vis_words = ((g_n_ + 31) / 32 + 3) & ~3LL;
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
-    // jobs per launch bounded by an 8 GiB visited arena
-    long long chunk = std::min<long long>(njobs, std::max<long long>(256, (8LL << 30) / (long long)std::max<size_t>(vis_bytes_per_job, 1)));
-    if (!ensure_search_scratch(chunk, k_out, vis_bytes_per_job)) return false;
+    const long long chunk = std::min<long long>(njobs, 1 << 20);
+    if (!ensure_search_scratch(chunk, kMaxSlots, k_out, vis_bytes_per_job)) return false;
     // pinned layout: [evals (16 B) | jobs | ids | dists | flags]
     const size_t b_jobs = sizeof(SearchJob) * (size_t)chunk, b_res = 4u * (size_t)chunk * k_out;
     char *hs = static_cast<char *>(pinned_stage(16 + b_jobs + 2 * b_res + 4u * (size_t)chunk));
@@ -2003,14 +2073,16 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         const int nj = (int)std::min<long long>(chunk, njobs - off);
         memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
         HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemsetAsync(s_visited_, 0, vis_bytes_per_job * (size_t)nj, st));
+        HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int), st));
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-#define LAUNCH2(M, NS_, GRID, LDS, CAP)                                                                               \
-    hipLaunchKernelGGL((graph_search_kernel<M, NS_>), dim3(GRID), dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
+#define LAUNCH2(M, NS_, GRID, LDS, CAP) \
+    hipLaunchKernelGGL((graph_search_kernel<M, NS_>), \
+                       dim3(std::min<int>(GRID, std::min(kMaxSlots, resident_blocks(graph_search_kernel<M, NS_>, LDS, num_cu_)))), \
+                       dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap())
+                       spill_cap_for_tests(), s_visited_, vis_words, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_)
 #define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
     do {                                                                                                                   \
         if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, CAP);                                                      \

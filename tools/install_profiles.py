@@ -20,9 +20,14 @@ for f in ("bench_under_rocprof", "bench_pmc_fetch", "bench_pmc_write"):
 plain = ROOT / "gpurun_out" / "bench_1m_final.log"
 if plain.exists():
     (dst / f"{r}_bench_1m_plain.json").write_text("".join(l for l in open(plain) if l.startswith('{"metric"')))
-K = "void hnsw::graph_search_kernel<0>"
-fetch = json.load(open(dst / f"{r}_pmc_fetch_size.json"))["counters"][K]["FETCH_SIZE"]["avg_per_dispatch"]
-write = json.load(open(dst / f"{r}_pmc_write_size.json"))["counters"][K]["WRITE_SIZE"]["avg_per_dispatch"]
+def counter(path, name):
+    cs = json.load(open(path))["counters"]
+    key = [k for k in cs if "graph_search_kernel<0" in k][0]  # sq_euclid instantiation (any register-set count)
+    return cs[key][name]["avg_per_dispatch"]
+
+
+fetch = counter(dst / f"{r}_pmc_fetch_size.json", "FETCH_SIZE")
+write = counter(dst / f"{r}_pmc_write_size.json", "WRITE_SIZE")
 cal = json.load(open(dst / f"{r}_pmc_calibration_kbench.json"))["counters"]["v1"]["FETCH_SIZE"]["avg_per_dispatch"]
 m = re.search(r"single ([0-9.]+) us \(([0-9.]+) GB/s\)", [l for l in open(dst / f"{r}_pmc_calibration_kbench.log") if l.startswith("v1")][0])
 known = float(m.group(2)) * 1e9 * float(m.group(1)) * 1e-6
@@ -30,7 +35,8 @@ factor = known / (cal * 1024)
 b = json.load(open(dst / f"{r}_bench_pmc_fetch.json"))
 alg = b["roofline"]["evals_per_launch"] * b["roofline"]["bytes_per_eval"]
 out = {"round": int(r[1:]), "kernel": "graph_search_kernel<sq_euclid>",
-       "workload": {"n": 1000000, "dim": 128, "nq": 10000, "ef_search": 128, "k": 10, "max_edges": 16},
+       "workload": {"n": b["config"]["n"], "dim": b["config"]["dim"], "nq": b["config"]["queries_per_gpu_per_step"],
+                    "ef_search": b["config"]["ef_search"], "k": b["config"]["k"], "max_edges": b["config"]["max_edges"]},
        "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
        "fetch_calibration": {"method": "tools/kbench (same 8-lane strided-dword row gather), 32768 slots x ~21 distinct random 512-B rows of a 2 GB matrix",
                              "known_bytes_per_launch": known, "FETCH_SIZE_KB_per_launch": cal, "factor": factor},
