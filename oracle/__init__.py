@@ -181,7 +181,10 @@ class OracleIndex:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_free(self._h)
+            try:
+                lib().orc_free(self._h)
+            except TypeError:  # interpreter shutdown: module globals already cleared
+                pass
             self._h = None
 
     def add(self, vecs):
