@@ -147,6 +147,9 @@ private:
     unsigned *s_visited_ = nullptr;
     size_t s_visited_bytes_ = 0;
     int *s_jobctr_ = nullptr; // persistent launches: next job
+    int *s_vislog_ = nullptr; // per-wave logs of visited ids (large graphs)
+    size_t s_vislog_cap_ = 0;
+    bool visited_log(size_t vis_bytes_per_job, int **out);
     int num_cu_ = 256;
     SearchJob *s_jobs_ = nullptr;
     SearchHit *s_hits_ = nullptr;

@@ -489,6 +489,45 @@ struct GraphView {
     }
 };
 
+// A wave's visited set (VisitedListPool.cs:10-67 restated for one in-flight traversal): a bitset
+// over node ids in HBM, all zero between jobs.  Clearing streams over the whole bitset; for large
+// graphs (bitset > 512 KB, i.e. > 4M nodes) the ids that were set are logged instead and only their
+// words are cleared -- at 10M nodes the 1.25-MB stream per traversal cost as much as the row reads.
+struct VisitedSet {
+    unsigned *bits;
+    long long words; // multiple of 4; the arena is 16-byte aligned
+    int *log;        // nullptr: no log
+    int log_cap;
+    int n;           // logged ids, or -1 once the log overflowed (then clear() streams)
+    __device__ __forceinline__ void note(const int *ids, int m, int lane) // ids: wave-visible array (LDS)
+    {
+        if (log == nullptr || n < 0) return;
+        if (n + m > log_cap) { n = -1; return; }
+        for (int i = lane; i < m; i += 64) log[n + i] = ids[i];
+        n += m;
+    }
+    __device__ __forceinline__ void note_one(int id, int lane)
+    {
+        if (log == nullptr || n < 0) return;
+        if (n + 1 > log_cap) { n = -1; return; }
+        if (lane == 0) log[n] = id;
+        n += 1;
+    }
+    __device__ __forceinline__ void clear(int lane)
+    {
+        __syncthreads();
+        if (log != nullptr && n >= 0) {
+            for (int i = lane; i < n; i += 64) bits[log[i] >> 5] = 0u;
+        } else {
+            uint4 *v4 = reinterpret_cast<uint4 *>(bits);
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            for (long long w = lane; w < (words >> 2); w += 64) v4[w] = z;
+        }
+        n = 0;
+        __syncthreads();
+    }
+};
+
 #ifdef EXP_PHASE_CLOCKS // experiment build: shader-clock cycles per traversal phase, summed over waves
 __device__ unsigned long long g_phase[12];
 __device__ unsigned long long g_phase_link[12];
@@ -672,7 +711,7 @@ struct SortedTop {
 // traversal.  Result: L.top[0..top_n) ascending by distance.  The query must be staged in L.qs.
 template <int METRIC, int NS>
 __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
-                                                const GraphView &G, const SearchJob jb, int k, int ordered_prefix, unsigned *vis,
+                                                const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet &V,
                                                 const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals)
 {
     int *nbuf = L.nbuf;
@@ -691,7 +730,8 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     bool unsafe = key_unsafe(cur); // NaN / -0 (see f2key)
     bool tie = false;
     T.insert(f2key(cur), best, top_n, k, lane);                      // :134, :138
-    if (lane == 0) atomicOr(&vis[best >> 5], 1u << (best & 31));     // :140
+    if (lane == 0) atomicOr(&V.bits[best >> 5], 1u << (best & 31));     // :140
+    V.note_one(best, lane);
     unsigned far_key = f2key(cur);                                   // farthestResultDist :135
     int pre_id = -1, pre_a = 0, pre_b = 0; // speculative prefetch of the next expansion's list (see traverse)
     const int lstride = layer == 0 ? G.stride0 : G.strideU;
@@ -728,7 +768,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             const int nb = base == 0 ? nb_a : nb_b;
             if (i < n) {
                 const unsigned bit = 1u << (nb & 31);
-                const unsigned old = atomicOr(&vis[nb >> 5], bit); // :181 (lists hold no duplicates)
+                const unsigned old = atomicOr(&V.bits[nb >> 5], bit); // :181 (lists hold no duplicates)
                 fresh = (old & bit) == 0;
             }
             const unsigned long long mask = __ballot(fresh);
@@ -751,6 +791,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         }
         __syncthreads();
         if (m == 0) continue;
+        V.note(nbuf, m, lane);
         measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
         __syncthreads();
         PH(4);
@@ -803,7 +844,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
 template <int METRIC>
 __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                          const GraphView &G, const SearchJob jb, int k, int cand_cap, ND *spill, int spill_cap,
-                                         unsigned *vis, const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals)
+                                         VisitedSet &V, const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals)
 {
     const LdsHeap top{L.top};
     const SpillHeap cand{L.cand, cand_cap, spill};
@@ -849,7 +890,8 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
         HEnt e{best, f2key(cur)};
         heap_push<false>(top, top_n, e); // :134
         heap_push<true>(cand, cand_n, e); // :138
-        if (lane == 0) atomicOr(&vis[best >> 5], 1u << (best & 31)); // :140
+        if (lane == 0) atomicOr(&V.bits[best >> 5], 1u << (best & 31)); // :140
+        V.note_one(best, lane);
     }
     unsigned far_key = f2key(cur); // farthestResultDist :135
     // Speculative prefetch of the NEXT expansion's out-edge list: while the current candidate
@@ -882,7 +924,7 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
             const int nb = base == 0 ? nb_a : nb_b;
             if (i < n) {
                 const unsigned bit = 1u << (nb & 31);
-                const unsigned old = atomicOr(&vis[nb >> 5], bit); // :181 (lists hold no duplicates)
+                const unsigned old = atomicOr(&V.bits[nb >> 5], bit); // :181 (lists hold no duplicates)
                 fresh = (old & bit) == 0;
             }
             const unsigned long long mask = __ballot(fresh);
@@ -899,6 +941,7 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
         }
         __syncthreads();
         if (m == 0) continue;
+        V.note(nbuf, m, lane);
         measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
         __syncthreads();
         evals += (unsigned long long)m;
@@ -1066,16 +1109,6 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
 // NS > 0: sorted-list traversal with NS register sets (k <= 64 * NS); a wave that meets equal
 // distances where the heap layout shows starts over with the exact two-heap traversal (out_flag 2,
 // informational).  NS = 0: two-heap traversal only.
-// The wave's visited bitset back to all zero (vis_words is a multiple of 4, the arena 16-byte aligned).
-__device__ __forceinline__ void clear_visited(unsigned *vis, long long vis_words, int lane)
-{
-    __syncthreads();
-    uint4 *v4 = reinterpret_cast<uint4 *>(vis);
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    for (long long w = lane; w < (vis_words >> 2); w += 64) v4[w] = z;
-    __syncthreads();
-}
-
 // One job on this wave.  `vis` / `spill`: the wave's own scratch (vis all zero on entry; the caller
 // clears it afterwards).
 template <int METRIC, int NS>
@@ -1083,7 +1116,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
                     const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
-                    int spill_cap, unsigned *__restrict__ vis, long long vis_words, int k_out, int *__restrict__ out_ids,
+                    int spill_cap, VisitedSet &V, int k_out, int *__restrict__ out_ids,
                     float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
                     unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job)
 {
@@ -1108,7 +1141,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
     if constexpr (NS > 0) {
         bool tie = false;
         // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
-        const bool ok1 = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, vis, L, lane, top_n, tie, evals);
+        const bool ok1 = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals);
         if (!(ok1 && tie)) {
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
             // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
@@ -1125,12 +1158,12 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
             return;
         }
         // equal distances where the heap layout shows: this wave starts over with the exact traversal
-        clear_visited(vis, vis_words, lane);
+        V.clear(lane);
         evals = 0;
         top_n = 0;
         repeated = true;
     }
-    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, vis, L, lane, top_n, evals);
+    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
     // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(c => c.Dist) is a STABLE sort over the heap
     // array (ToArray(), BinaryHeap.cs:41-44) and only the first k_out survive -- so select the
     // k_out smallest (float.CompareTo order: NaN first, -0 == +0) with ties broken by array index:
@@ -1183,13 +1216,14 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
                     const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
-                    int spill_cap, unsigned *__restrict__ visited, long long vis_words, int k_out, int *__restrict__ out_ids,
-                    float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
+                    int spill_cap, unsigned *__restrict__ visited, long long vis_words, int *__restrict__ vis_log, int vis_log_cap, int k_out,
+                    int *__restrict__ out_ids, float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
                     unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    unsigned *vis = visited + (size_t)blockIdx.x * (size_t)vis_words;
+    VisitedSet V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
+                 vis_log ? vis_log + (size_t)blockIdx.x * (size_t)vis_log_cap : nullptr, vis_log_cap, 0};
     ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
     for (;;) {
         int job = 0;
@@ -1197,8 +1231,8 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
         job = __builtin_amdgcn_readfirstlane(job);
         if (job >= njobs) break;
         search_job<METRIC, NS>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
-                               vis, vis_words, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job);
-        clear_visited(vis, vis_words, lane);
+                               V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job);
+        V.clear(lane);
     }
 }
 
@@ -1213,7 +1247,7 @@ template <int METRIC, int NS>
 __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
-                           int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ vis, long long vis_words,
+                           int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, VisitedSet &V,
                            int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
                            unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job)
@@ -1231,14 +1265,14 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     bool ok = true, repeat = false;
     const int first_layer = jb.search_layer;
     for (int layer = first_layer; layer >= 0 && ok; --layer) {
-        if (layer != first_layer) clear_visited(vis, vis_words, lane); // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
+        if (layer != first_layer) V.clear(lane); // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
         int top_n = 0;
         const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
         bool exact = NS == 0;
         if constexpr (NS > 0) {
             bool tie = false;
             const unsigned long long ev0 = evals;
-            ok = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k, vis, L, lane, top_n, tie, evals); // Span.Sort consumes all
+            ok = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals); // Span.Sort consumes all
             if (!ok) break;
             // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
             // then returns them in HEAP order, Heuristic.cs:13-18): this layer again, exact traversal
@@ -1247,11 +1281,11 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                 repeat = true;
                 evals = ev0;
                 top_n = 0;
-                clear_visited(vis, vis_words, lane);
+                V.clear(lane);
             }
         }
         if (exact) {
-            ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, vis, L, lane, top_n, evals);
+            ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
             if (!ok) break;
         }
         const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact);
@@ -1276,22 +1310,23 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
-                           int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
+                           int *__restrict__ vis_log, int vis_log_cap, int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
                            unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    unsigned *vis = visited + (size_t)blockIdx.x * (size_t)vis_words;
+    VisitedSet V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
+                 vis_log ? vis_log + (size_t)blockIdx.x * (size_t)vis_log_cap : nullptr, vis_log_cap, 0};
     ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
     for (;;) { // persistent, see graph_search_kernel
         int job = 0;
         if (lane == 0) job = atomicAdd(job_counter, 1);
         job = __builtin_amdgcn_readfirstlane(job);
         if (job >= njobs) break;
-        insert_job<METRIC, NS>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, vis,
-                               vis_words, out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job);
-        clear_visited(vis, vis_words, lane);
+        insert_job<METRIC, NS>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
+                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job);
+        V.clear(lane);
     }
 }
 
@@ -1489,7 +1524,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vislog_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -1758,7 +1793,8 @@ static int resident_blocks(K kernel, size_t lds, int num_cu)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
     return per_cu * std::max(1, num_cu);
 }
-constexpr int kMaxSlots = 256 * 32; // scratch is sized for this many resident waves (8 per SIMD, 256 CUs)
+constexpr int kMaxSlots = 256 * 32;
+constexpr int kVisLogCap = 16384; // ids a traversal may log before it falls back to streaming the bitset clear // scratch is sized for this many resident waves (8 per SIMD, 256 CUs)
 
 static int cand_lds_cap(int k, int dim, bool heur, int nbcap)
 {
@@ -1787,6 +1823,24 @@ static bool grow_dev(T **p, size_t *cap, size_t need)
 // chunk: jobs per launch (job / result buffers); slots: waves of a persistent launch (visited
 // bitsets, spill areas).  The visited arena is all zero between launches: zeroed when allocated,
 // and every wave clears its bitset after each job.
+static int vis_log_cap_for_tests()
+{
+    if (const char *e = std::getenv("HNSW_MI355X_VIS_LOG_CAP")) return std::max(1, std::min(kVisLogCap, std::atoi(e)));
+    return kVisLogCap;
+}
+
+// The per-wave visited-id logs (VisitedSet), only for graphs whose bitset is large.
+bool Device::visited_log(size_t vis_bytes_per_job, int **out)
+{
+    *out = nullptr;
+    const char *e = std::getenv("HNSW_MI355X_VIS_LOG"); // tests: 1 forces the log, 0 forbids it
+    const bool want = e ? std::atoi(e) != 0 : vis_bytes_per_job > (512u << 10);
+    if (!want) return true;
+    if (!grow_dev(&s_vislog_, &s_vislog_cap_, (size_t)kMaxSlots * kVisLogCap)) return false;
+    *out = s_vislog_;
+    return true;
+}
+
 bool Device::ensure_search_scratch(long long chunk, long long slots, int k, size_t vis_bytes_per_job)
 {
     if (vis_bytes_per_job * (size_t)slots > s_visited_bytes_) {
@@ -1846,6 +1900,8 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
     const long long chunk = std::min<long long>(njobs, 1 << 20);
     if (!ensure_search_scratch(chunk, kMaxSlots, 0, vis_bytes_per_job)) return false;
+    int *vis_log = nullptr;
+    if (!visited_log(vis_bytes_per_job, &vis_log)) return false;
     const size_t nU = (size_t)std::max(n_upper, 1);
     if (!grow_dev(&s_sel_, &s_sel_cap_, (size_t)njobs * sel_stride) || !grow_dev(&s_lcnt_, &s_lcnt_cap_, (size_t)njobs) ||
         !grow_dev(&s_selU_, &s_selU_cap_, nU * sel_stride) || !grow_dev(&s_cntU_, &s_cntU_cap_, nU) ||
@@ -1880,7 +1936,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
                        dim3(std::min<int>(GRID, std::min(kMaxSlots, resident_blocks(graph_insert_search_kernel<M, NS_>, LDS, num_cu_)))), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
-                       max_edges0, s_visited_, vis_words, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
+                       max_edges0, s_visited_, vis_words, vis_log, vis_log_cap_for_tests(), s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
                        sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_)
 #define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
     do {                                                                                                                   \
@@ -2058,6 +2114,8 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
     const long long chunk = std::min<long long>(njobs, 1 << 20);
     if (!ensure_search_scratch(chunk, kMaxSlots, k_out, vis_bytes_per_job)) return false;
+    int *vis_log = nullptr;
+    if (!visited_log(vis_bytes_per_job, &vis_log)) return false;
     // pinned layout: [evals (16 B) | jobs | ids | dists | flags]
     const size_t b_jobs = sizeof(SearchJob) * (size_t)chunk, b_res = 4u * (size_t)chunk * k_out;
     char *hs = static_cast<char *>(pinned_stage(16 + b_jobs + 2 * b_res + 4u * (size_t)chunk));
@@ -2082,7 +2140,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
                        dim3(std::min<int>(GRID, std::min(kMaxSlots, resident_blocks(graph_search_kernel<M, NS_>, LDS, num_cu_)))), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_)
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_log, vis_log_cap_for_tests(), k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_)
 #define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
     do {                                                                                                                   \
         if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, CAP);                                                      \

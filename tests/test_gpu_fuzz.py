@@ -123,3 +123,37 @@ def test_equal_distances_are_repeated_with_the_exact_traversal(Index):
     want, got = ref.knn_query(q, 8), ix.knn_query(q, 8)
     assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
     assert ix.stats()["search_repeats"] > 400
+
+
+def test_many_jobs_per_resident_wave(Index):
+    # persistent launches: far more traversals than resident waves, so every wave reuses its visited
+    # bitset (cleared in the kernel) many times; also Add in one call with a batch cap above the slots
+    from common import uniform
+    x, q = uniform(6000, 16, 301), uniform(120_000, 16, 302)
+    ref = oracle.OracleIndex(16, max_edges=8, max_candidates=40, min_nn=24, collection_size=6000)
+    ref.add_batched(x, 16384)
+    ix = _build(Index, x, 8, 40, 24, 16384)
+    assert ix.graph_hash() == ref.graph_hash()
+    got = ix.knn_query(q, 6)
+    want = ref.knn_query(q, 6, threads=8)
+    assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
+    again = ix.knn_query(q[:5000], 6)   # the scratch was left clean
+    assert (again[0] == want[0][:5000]).all()
+
+
+@pytest.mark.parametrize("log_cap", ["16384", "300"])
+@pytest.mark.parametrize("sorted_top", ["1", "0"])
+def test_visited_id_log_clearing(Index, monkeypatch, sorted_top, log_cap):
+    # large graphs clear their visited bitsets through a log of the ids they set (forced here on a
+    # small graph); a log that overflows falls back to streaming the bitset
+    from common import uniform
+    monkeypatch.setenv("HNSW_MI355X_VIS_LOG", "1")
+    monkeypatch.setenv("HNSW_MI355X_VIS_LOG_CAP", log_cap)
+    monkeypatch.setenv("HNSW_MI355X_SORTED_TOP", sorted_top)
+    x, q = uniform(5000, 24, 401), uniform(40_000, 24, 402)
+    ref = oracle.OracleIndex(24, max_edges=8, max_candidates=50, min_nn=30, collection_size=5000)
+    ref.add_batched(x, 16384)
+    ix = _build(Index, x, 8, 50, 30, 16384)
+    assert ix.graph_hash() == ref.graph_hash()
+    got, want = ix.knn_query(q, 5), ref.knn_query(q, 5, threads=8)
+    assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
