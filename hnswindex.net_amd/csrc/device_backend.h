@@ -113,6 +113,14 @@ public:
     //  out_lists: ngroups x list_stride ints [cnt, ids...]: the final adjacency list of every group.
     bool link_batch(const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
                     const int *g_items, int ngroups, int max_edges0, int *out_lists, int list_stride);
+    // The same in two halves, so that the host can prepare the next sub-batch while this one runs:
+    // begin copies the inputs to one of two pinned staging sets and enqueues copy-in, kernels and
+    // copy-out on the stream; finish waits for that set and returns its lists (valid until the set
+    // is used again).  Sub-batches are applied in the order they were begun.
+    bool link_batch_begin(int set, const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
+                          const int *g_items, int ngroups, int max_edges0, int list_stride);
+    bool link_batch_finish(int set, const int **out_lists);
+
     // C-ABI conveniences (synchronous; validate ids on the host before launching).
     bool dist_query_batch(const float *queries, int nq, const int *offsets, const int *ids, float *out);
     bool dist_pair_batch(const int *a, const int *b, int n, float *out);
@@ -171,6 +179,14 @@ private:
     void *h_stage_ = nullptr;
     size_t h_stage_cap_ = 0;
     void *ev0_ = nullptr, *ev1_ = nullptr;
+    struct LinkSet { // pinned staging of one in-flight link sub-batch
+        int *h_in = nullptr, *h_out = nullptr;
+        size_t in_cap = 0, out_cap = 0;
+        unsigned long long *h_ev = nullptr;
+        void *ev_start = nullptr, *ev_stop = nullptr, *ev_done = nullptr;
+        bool busy = false, timed = false;
+        int ngroups = 0;
+    } lset_[2];
     void *stream_ = nullptr;
     bool profiling_ = false;
     hnswdev_stats stats_{};

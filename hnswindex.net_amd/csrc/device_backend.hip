@@ -1530,6 +1530,12 @@ Device::~Device()
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
     if (h_stage_) (void)hipHostFree(h_stage_);
     if (h_res_) (void)hipHostFree(h_res_);
+    for (LinkSet &ls : lset_) {
+        if (ls.h_in) (void)hipHostFree(ls.h_in);
+        if (ls.h_out) (void)hipHostFree(ls.h_out);
+        if (ls.h_ev) (void)hipHostFree(ls.h_ev);
+        for (void *e : {ls.ev_start, ls.ev_stop, ls.ev_done}) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    }
     delete hg_;
 }
 
@@ -2012,10 +2018,23 @@ bool Device::graph_append_nodes(long long first, long long n, const int *level, 
 bool Device::link_batch(const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
                         const int *g_items, int ngroups, int max_edges0, int *out_lists, int list_stride)
 {
-    if (nrows < 0 || ngroups < 0 || (nrows > 0 && !rows) || (ngroups > 0 && (!g_node || !g_layer || !g_off || !g_items || !out_lists))) {
+    if (ngroups > 0 && !out_lists) { set_dev_error("link_batch: bad argument"); return false; }
+    const int *res = nullptr;
+    if (!link_batch_begin(0, rows, nrows, row_stride, g_node, g_layer, g_off, g_items, ngroups, max_edges0, list_stride)) return false;
+    if (!link_batch_finish(0, &res)) return false;
+    if (ngroups > 0) memcpy(out_lists, res, sizeof(int) * (size_t)ngroups * list_stride);
+    return true;
+}
+
+bool Device::link_batch_begin(int set, const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
+                              const int *g_items, int ngroups, int max_edges0, int list_stride)
+{
+    if (set < 0 || set > 1 || nrows < 0 || ngroups < 0 || (nrows > 0 && !rows) || (ngroups > 0 && (!g_node || !g_layer || !g_off || !g_items))) {
         set_dev_error("link_batch: bad argument");
         return false;
     }
+    LinkSet &ls = lset_[set];
+    if (ls.busy) { set_dev_error("link_batch: staging set still in flight"); return false; }
     if (g_n_ <= 0) { set_dev_error("link_batch: no graph uploaded"); return false; }
     // host-side validation: a bad id must be an error return, never a GPU fault
     for (int r = 0; r < nrows; ++r) {
@@ -2035,20 +2054,57 @@ bool Device::link_batch(const int *rows, int nrows, int row_stride, const int *g
     hipStream_t st = S(stream_);
     if (!ensure_search_scratch(1, 1, 0, 16)) return false;
     const size_t need[5] = {(size_t)nrows * row_stride, (size_t)ngroups * 2, (size_t)ngroups + 1, (size_t)std::max(total, 1), (size_t)ngroups * list_stride};
-    for (int i = 0; i < 5; ++i) if (!grow_dev(&s_lk_[i], &s_lk_cap_[i], std::max<size_t>(need[i], 1))) return false;
+    // device buffers are shared by both sets: the stream orders one sub-batch after the other.
+    // Growing one frees the old allocation, which must not be in use any more.
+    for (int i = 0; i < 5; ++i) {
+        if (std::max<size_t>(need[i], 1) > s_lk_cap_[i]) {
+            HIP_OK(hipStreamSynchronize(st));
+            if (!grow_dev(&s_lk_[i], &s_lk_cap_[i], std::max<size_t>(need[i], 1) * 2)) return false;
+        }
+    }
+    // pinned staging of this set: [rows | node | layer | off | items], results, evaluation count
+    const size_t in_ints = need[0] + need[1] + need[2] + need[3];
+    if (in_ints > ls.in_cap) {
+        if (ls.h_in) (void)hipHostFree(ls.h_in);
+        ls.h_in = nullptr; ls.in_cap = 0;
+        if (hipHostMalloc((void **)&ls.h_in, sizeof(int) * in_ints * 2, hipHostMallocDefault) != hipSuccess) { set_dev_error("link_batch: pinned allocation failed"); return false; }
+        ls.in_cap = in_ints * 2;
+    }
+    if (std::max<size_t>(need[4], 1) > ls.out_cap) {
+        if (ls.h_out) (void)hipHostFree(ls.h_out);
+        ls.h_out = nullptr; ls.out_cap = 0;
+        if (hipHostMalloc((void **)&ls.h_out, sizeof(int) * std::max<size_t>(need[4], 1) * 2, hipHostMallocDefault) != hipSuccess) { set_dev_error("link_batch: pinned allocation failed"); return false; }
+        ls.out_cap = std::max<size_t>(need[4], 1) * 2;
+    }
+    if (!ls.h_ev && hipHostMalloc((void **)&ls.h_ev, 16, hipHostMallocDefault) != hipSuccess) { set_dev_error("link_batch: pinned allocation failed"); return false; }
+    if (!ls.ev_done) {
+        hipEvent_t a, b, c;
+        HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); HIP_OK(hipEventCreate(&c));
+        ls.ev_start = a; ls.ev_stop = b; ls.ev_done = c;
+    }
+    int *h_rows = ls.h_in, *h_node = h_rows + need[0], *h_off = h_node + need[1], *h_items = h_off + need[2];
+    if (nrows > 0) memcpy(h_rows, rows, sizeof(int) * need[0]);
+    if (ngroups > 0) {
+        memcpy(h_node, g_node, sizeof(int) * (size_t)ngroups);
+        memcpy(h_node + ngroups, g_layer, sizeof(int) * (size_t)ngroups);
+        memcpy(h_off, g_off, sizeof(int) * ((size_t)ngroups + 1));
+        memcpy(h_items, g_items, sizeof(int) * (size_t)total);
+    }
+    *ls.h_ev = 0;
+    ls.ngroups = ngroups;
+    ls.timed = false;
     if (nrows > 0) {
-        HIP_OK(hipMemcpyAsync(s_lk_[0], rows, sizeof(int) * need[0], hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(s_lk_[0], h_rows, sizeof(int) * need[0], hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(graph_write_rows_kernel, dim3(nrows), dim3(64), 0, st, g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_lk_[0], row_stride);
         HIP_OK(hipGetLastError());
     }
     if (ngroups > 0) {
-        HIP_OK(hipMemcpyAsync(s_lk_[1], g_node, sizeof(int) * (size_t)ngroups, hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(s_lk_[1] + ngroups, g_layer, sizeof(int) * (size_t)ngroups, hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(s_lk_[2], g_off, sizeof(int) * ((size_t)ngroups + 1), hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemcpyAsync(s_lk_[3], g_items, sizeof(int) * (size_t)total, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(s_lk_[1], h_node, sizeof(int) * (size_t)ngroups * 2, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(s_lk_[2], h_off, sizeof(int) * ((size_t)ngroups + 1), hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(s_lk_[3], h_items, sizeof(int) * (size_t)total, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
-        const bool timed = profiling_;
-        if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
+        ls.timed = profiling_;
+        if (ls.timed) HIP_OK(hipEventRecord((hipEvent_t)ls.ev_start, st));
         const int k_cap = nbcap();
         const size_t lds = search_lds_bytes(k_cap, 0, dim_, true, nbcap());
 #define LAUNCH(M)                                                                                                          \
@@ -2060,22 +2116,33 @@ bool Device::link_batch(const int *rows, int nrows, int row_stride, const int *g
         else LAUNCH(M_UCOS);
 #undef LAUNCH
         HIP_OK(hipGetLastError());
-        if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
-        unsigned long long ev = 0;
-        HIP_OK(hipMemcpyAsync(out_lists, s_lk_[4], sizeof(int) * (size_t)ngroups * list_stride, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(&ev, s_evals_, sizeof(ev), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
+        if (ls.timed) HIP_OK(hipEventRecord((hipEvent_t)ls.ev_stop, st));
+        HIP_OK(hipMemcpyAsync(ls.h_out, s_lk_[4], sizeof(int) * (size_t)ngroups * list_stride, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(ls.h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    }
+    HIP_OK(hipEventRecord((hipEvent_t)ls.ev_done, st));
+    ls.busy = true;
+    return true;
+}
+
+bool Device::link_batch_finish(int set, const int **out_lists)
+{
+    if (set < 0 || set > 1 || !lset_[set].busy) { set_dev_error("link_batch_finish: nothing in flight"); return false; }
+    LinkSet &ls = lset_[set];
+    if (!bind()) return false;
+    HIP_OK(hipEventSynchronize((hipEvent_t)ls.ev_done));
+    ls.busy = false;
+    if (out_lists) *out_lists = ls.h_out;
+    if (ls.ngroups > 0) {
         stats_.search_launches++;
-        stats_.search_evals += ev;
-        if (timed) {
+        stats_.search_evals += *ls.h_ev;
+        if (ls.timed) {
             float ms = 0.f;
-            HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
+            HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ls.ev_start, (hipEvent_t)ls.ev_stop));
             stats_.search_kernel_ms += ms;
             stats_.search_timed_launches++;
-            stats_.search_timed_evals += ev;
+            stats_.search_timed_evals += *ls.h_ev;
         }
-    } else {
-        HIP_OK(hipStreamSynchronize(st));
     }
     return true;
 }

@@ -584,6 +584,7 @@ constexpr int kBatchGrowthDiv = 16; // a snapshot batch never exceeds 1/16 of th
 // Optional phase timing (HNSW_MI355X_TRACE=1): printed when the index is destroyed.
 struct PhaseTimers {
     double sync_graph = 0, search_half = 0, collect = 0, link_host = 0, link_dev = 0, post = 0, query_dev = 0, set_queries = 0;
+    double add_nodes = 0, add_upload = 0, add_total = 0;
     long rounds = 0, batches = 0, prune_jobs = 0;
     bool on = std::getenv("HNSW_MI355X_TRACE") != nullptr;
 };
@@ -638,6 +639,7 @@ HnswIndex *HnswIndex::create(int metric, const Params &p, std::string &err)
 HnswIndex::~HnswIndex()
 {
     if (g_pt.on)
+        fprintf(stderr, "[hnsw trace] add: total=%.3fs nodes=%.3fs upload=%.3fs\n", g_pt.add_total, g_pt.add_nodes, g_pt.add_upload),
         fprintf(stderr, "[hnsw trace] batches=%ld sync_graph=%.3fs search_half=%.3fs collect=%.3fs link_host=%.3fs link_dev=%.3fs (rounds=%ld prune_jobs=%ld) | query: set_queries=%.3fs dev=%.3fs post=%.3fs\n",
                 g_pt.batches, g_pt.sync_graph, g_pt.search_half, g_pt.collect, g_pt.link_host, g_pt.link_dev, g_pt.rounds, g_pt.prune_jobs, g_pt.set_queries, g_pt.query_dev, g_pt.post);
     engine_.reset(); // before the device it allocates from
@@ -789,63 +791,93 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
     const int n = (int)bid.size();
     const int M2 = 2 * p_.max_edges, row_stride = 3 + M2, list_stride = graph_.stride0;
     const int top = graph_.top_layer();
-    std::vector<int> rows, g_node, g_layer, g_cnt;
-    std::vector<std::pair<int, int>> seq; // (group, item id) in append order
-    std::unordered_map<uint64_t, int> upper_groups;
-    {
-        Tick t(g_pt.collect);
-        if ((int)grp_of_node0_.size() < graph_.length) grp_of_node0_.resize((size_t)graph_.length, -1);
-        rows.reserve((size_t)n * row_stride);
-        seq.reserve((size_t)n * M2);
-        for (int i = 0; i < n; ++i) {
-            const int id = bid[(size_t)i];
-            for (int layer = std::min(graph_.level[(size_t)id], top); layer >= 0; --layer) {
-                const int *sp; int sc;
-                sel.get(i, layer, sp, sc);
-                int *l = graph_.list(id, layer); // currNode.OutEdges[layer] = selected (:192), host copy
-                l[0] = sc;
-                std::memcpy(l + 1, sp, sizeof(int) * (size_t)sc);
-                size_t r0 = rows.size();
-                rows.resize(r0 + (size_t)row_stride, 0);
-                rows[r0] = id; rows[r0 + 1] = layer; rows[r0 + 2] = sc;
-                std::memcpy(rows.data() + r0 + 3, sp, sizeof(int) * (size_t)sc);
-                for (int e = 0; e < sc; ++e) {
-                    const int nb = sp[e];
-                    int gi;
-                    if (layer == 0) {
-                        gi = grp_of_node0_[(size_t)nb];
-                        if (gi < 0) { gi = (int)g_node.size(); grp_of_node0_[(size_t)nb] = gi; g_node.push_back(nb); g_layer.push_back(0); g_cnt.push_back(0); }
-                    } else {
-                        const uint64_t key = ((uint64_t)(uint32_t)nb << 8) | (uint64_t)(uint32_t)layer;
-                        auto it = upper_groups.find(key);
-                        if (it == upper_groups.end()) { gi = (int)g_node.size(); upper_groups.emplace(key, gi); g_node.push_back(nb); g_layer.push_back(layer); g_cnt.push_back(0); }
-                        else gi = it->second;
+    // The batch is linked in up to four sub-batches of consecutive items.  Appending the items of one
+    // adjacency list sub-batch after sub-batch is the same sequence as appending them all in item
+    // order, so the outcome is unchanged -- but while the GPU links one sub-batch the host groups
+    // the next and files the previous one's lists.
+    const int S = n >= 2048 ? 4 : 1;
+    struct Pending { bool on = false; std::vector<int> node, layer; } pend[2];
+    auto finish = [&](int set) -> bool {
+        if (!pend[set].on) return true;
+        const int *out_lists = nullptr;
+        { Tick t(g_pt.link_dev); if (!dev_->link_batch_finish(set, &out_lists)) { err = get_dev_error(); return false; } }
+        Tick t(g_pt.link_host);
+        const std::vector<int> &gn = pend[set].node, &gl = pend[set].layer;
+        parallel_for((int)gn.size(), threads_, [&](int g) { // node.OutEdges[layer] as left by the appends / prunes
+            const int *o = out_lists + (size_t)g * list_stride;
+            int *l = graph_.list(gn[(size_t)g], gl[(size_t)g]);
+            std::memcpy(l, o, sizeof(int) * (size_t)(o[0] + 1));
+        });
+        pend[set].on = false;
+        return true;
+    };
+    // per-batch work arrays live in the index (their capacity settles after the first full batch)
+    std::vector<int> &rows = lk_rows_, &g_node = lk_node_, &g_layer = lk_layer_, &g_cnt = lk_cnt_;
+    std::vector<int> &g_off = lk_off_, &g_items = lk_items_, &fill = lk_fill_;
+    std::vector<std::pair<int, int>> &seq = lk_seq_; // (group, item id) in append order
+    if ((int)grp_of_node0_.size() < graph_.length) grp_of_node0_.resize((size_t)graph_.length, -1);
+    for (int s = 0; s < S; ++s) {
+        const int set = s & 1;
+        if (!finish(set)) return false; // sub-batch s - 2: its staging set is needed again
+        const int i0 = (int)((long long)n * s / S), i1 = (int)((long long)n * (s + 1) / S);
+        {
+            Tick t(g_pt.collect);
+            rows.clear(); g_node.clear(); g_layer.clear(); g_cnt.clear(); seq.clear();
+            std::unordered_map<uint64_t, int> upper_groups;
+            rows.reserve((size_t)(i1 - i0) * row_stride);
+            seq.reserve((size_t)(i1 - i0) * M2);
+            for (int i = i0; i < i1; ++i) {
+                const int id = bid[(size_t)i];
+                for (int layer = std::min(graph_.level[(size_t)id], top); layer >= 0; --layer) {
+                    const int *sp; int sc;
+                    sel.get(i, layer, sp, sc);
+                    int *l = graph_.list(id, layer); // currNode.OutEdges[layer] = selected (:192), host copy
+                    l[0] = sc;
+                    std::memcpy(l + 1, sp, sizeof(int) * (size_t)sc);
+                    size_t r0 = rows.size();
+                    rows.resize(r0 + (size_t)row_stride); // the tail beyond sc ids is never read (link_batch validates [0, sc))
+                    rows[r0] = id; rows[r0 + 1] = layer; rows[r0 + 2] = sc;
+                    std::memcpy(rows.data() + r0 + 3, sp, sizeof(int) * (size_t)sc);
+                    for (int e = 0; e < sc; ++e) {
+                        const int nb = sp[e];
+                        int gi;
+                        if (layer == 0) {
+                            gi = grp_of_node0_[(size_t)nb];
+                            if (gi < 0) { gi = (int)g_node.size(); grp_of_node0_[(size_t)nb] = gi; g_node.push_back(nb); g_layer.push_back(0); g_cnt.push_back(0); }
+                        } else {
+                            const uint64_t key = ((uint64_t)(uint32_t)nb << 8) | (uint64_t)(uint32_t)layer;
+                            auto it = upper_groups.find(key);
+                            if (it == upper_groups.end()) { gi = (int)g_node.size(); upper_groups.emplace(key, gi); g_node.push_back(nb); g_layer.push_back(layer); g_cnt.push_back(0); }
+                            else gi = it->second;
+                        }
+                        g_cnt[(size_t)gi]++;
+                        seq.emplace_back(gi, id);
                     }
-                    g_cnt[(size_t)gi]++;
-                    seq.emplace_back(gi, id);
                 }
             }
+            for (size_t g = 0; g < g_node.size(); ++g) if (g_layer[g] == 0) grp_of_node0_[(size_t)g_node[g]] = -1;
+            const int G = (int)g_node.size();
+            g_off.resize((size_t)G + 1);
+            g_items.resize(seq.size());
+            fill.assign((size_t)G, 0);
+            g_off[0] = 0;
+            for (int g = 0; g < G; ++g) g_off[(size_t)g + 1] = g_off[(size_t)g] + g_cnt[(size_t)g];
+            for (const auto &pr : seq) g_items[(size_t)(g_off[(size_t)pr.first] + fill[(size_t)pr.first]++)] = pr.second;
         }
-        for (size_t g = 0; g < g_node.size(); ++g) if (g_layer[g] == 0) grp_of_node0_[(size_t)g_node[g]] = -1;
+        {
+            Tick t(g_pt.link_dev);
+            g_pt.rounds++;
+            if (!dev_->link_batch_begin(set, rows.data(), (int)(rows.size() / (size_t)row_stride), row_stride, g_node.data(), g_layer.data(),
+                                        g_off.data(), g_items.data(), (int)g_node.size(), M2, list_stride)) { err = get_dev_error(); return false; }
+        }
+        pend[set].node = g_node;
+        pend[set].layer = g_layer;
+        pend[set].on = true;
     }
-    const int G = (int)g_node.size();
-    std::vector<int> g_off((size_t)G + 1, 0), g_items(seq.size()), fill((size_t)G, 0);
-    for (int g = 0; g < G; ++g) g_off[(size_t)g + 1] = g_off[(size_t)g] + g_cnt[(size_t)g];
-    for (const auto &pr : seq) g_items[(size_t)(g_off[(size_t)pr.first] + fill[(size_t)pr.first]++)] = pr.second;
-    std::vector<int> out_lists((size_t)G * list_stride);
-    {
-        Tick t(g_pt.link_dev);
-        g_pt.rounds++;
-        if (!dev_->link_batch(rows.data(), (int)(rows.size() / (size_t)row_stride), row_stride, g_node.data(), g_layer.data(), g_off.data(),
-                              g_items.data(), G, M2, out_lists.data(), list_stride)) { err = get_dev_error(); return false; }
-    }
-    Tick t(g_pt.link_host);
-    parallel_for(G, threads_, [&](int g) { // node.OutEdges[layer] as left by the appends / prunes
-        const int *o = out_lists.data() + (size_t)g * list_stride;
-        int *l = graph_.list(g_node[(size_t)g], g_layer[(size_t)g]);
-        std::memcpy(l, o, sizeof(int) * (size_t)(o[0] + 1));
-    });
-    return true;
+    // in the order they were begun
+    const int first = S >= 2 ? (S & 1) : 0;
+    if (!finish(first)) return false;
+    return finish(first ^ 1);
 }
 
 // One snapshot batch: the nodes `bid` (in insertion order) have no edges yet.
@@ -869,6 +901,8 @@ bool HnswIndex::insert_batch(const std::vector<int> &bid, std::string &err)
 int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::string &err)
 {
     if (!ensure_dim(dim, err)) return -1;
+    Tick t_total(g_pt.add_total);
+    double t_nodes0 = g_pt.on ? now_s() : 0;
     // GraphData.AddItem (src/HNSWIndex/GraphData.cs:79-118): one RNG draw per item, in order;
     // vacated slots are reused first when removals are allowed (:85-91)
     std::vector<int> ids((size_t)count), fresh; // fresh: the new nodes, in insertion order
@@ -884,6 +918,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
         fresh.push_back(ids[(size_t)i]);
     }
     if (!ensure_capacity(graph_.length, err)) return -1;
+    if (g_pt.on) { g_pt.add_nodes += now_s() - t_nodes0; t_nodes0 = now_s(); }
     if (any_reused) graph_dirty_ = true; // existing rows of the HBM mirror changed: full re-upload
     // rows -> HBM (id == row index)
     if (!any_reused && (int)fresh.size() == count) {
@@ -892,6 +927,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
         for (int i = 0; i < count; ++i)
             if (ids[(size_t)i] >= 0 && !dev_->upload_rows(ids[(size_t)i], 1, vectors + (size_t)i * dim)) { err = get_dev_error(); return -1; }
     }
+    if (g_pt.on) g_pt.add_upload += now_s() - t_nodes0;
     // GraphConnector.ConnectNewNode (:24-47), batched
     const int m = (int)fresh.size();
     const int bmax = std::max(1, p_.insert_batch);

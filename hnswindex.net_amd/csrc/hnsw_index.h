@@ -111,6 +111,8 @@ private:
     bool graph_dirty_ = true;       // HBM mirror needs a full re-upload
     long long dev_pool_len_ = 0;    // pool ints already mirrored
     std::vector<int> grp_of_node0_; // link half: group index per layer-0 neighbour (-1 = none)
+    std::vector<int> lk_rows_, lk_node_, lk_layer_, lk_cnt_, lk_off_, lk_items_, lk_fill_, lk_out_; // link half: per-batch work arrays
+    std::vector<std::pair<int, int>> lk_seq_;
 };
 
 } // namespace hnsw
