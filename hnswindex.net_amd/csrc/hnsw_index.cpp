@@ -795,7 +795,8 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
     // adjacency list sub-batch after sub-batch is the same sequence as appending them all in item
     // order, so the outcome is unchanged -- but while the GPU links one sub-batch the host groups
     // the next and files the previous one's lists.
-    const int S = n >= 2048 ? 4 : 1;
+    static const int split = [] { const char *e = std::getenv("HNSW_MI355X_LINK_SPLIT"); return e ? std::max(1, std::atoi(e)) : 4; }();
+    const int S = n >= 2048 ? split : 1;
     struct Pending { bool on = false; std::vector<int> node, layer; } pend[2];
     auto finish = [&](int set) -> bool {
         if (!pend[set].on) return true;
