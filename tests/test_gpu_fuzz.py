@@ -157,3 +157,15 @@ def test_visited_id_log_clearing(Index, monkeypatch, sorted_top, log_cap):
     assert ix.graph_hash() == ref.graph_hash()
     got, want = ix.knn_query(q, 5), ref.knn_query(q, 5, threads=8)
     assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
+
+
+def test_large_batches_link_in_pipelined_sub_batches(Index):
+    # snapshot batches of >= 2048 items are linked in four sub-batches (host grouping overlapped with
+    # the link kernel); the result must equal linking the whole batch in item order
+    from common import uniform
+    x = uniform(60_000, 16, 501)
+    ref = oracle.OracleIndex(16, max_edges=8, max_candidates=40, min_nn=10, collection_size=60_000)
+    ref.add_batched(x, 16384)
+    ix = _build(Index, x, 8, 40, 10, 16384)
+    assert ix.graph_hash() == ref.graph_hash()
+    assert (ix.levels() == ref.levels()).all() and ix.entry_point == ref.entry_point
