@@ -449,6 +449,7 @@ struct SearchLds {
     ND *cand;   // cand_cap
     float *qs;  // dim (padded to 4)
     float *qs2; // dim (padded to 4): second vector (heuristic / prune)
+    float *qs3; // dim (padded to 4): the heuristic's next candidate, staged while the current one is tested
     int *nbuf;  // nbcap
     float *dbuf; // nbcap
     int *acc;   // nbcap: accepted ids of the heuristic
@@ -459,7 +460,7 @@ struct SearchLds {
 __host__ __device__ inline size_t search_lds_bytes(int k, int cand_cap, int dim, bool heur, int nbcap)
 {
     size_t b = sizeof(ND) * (size_t)(k + 1 + cand_cap) + sizeof(float) * (size_t)((dim + 3) & ~3) + 2u * 4u * (size_t)nbcap;
-    if (heur) b += sizeof(float) * (size_t)((dim + 3) & ~3) + 4u * (size_t)nbcap + 4u * 3u * 40u;
+    if (heur) b += 2u * sizeof(float) * (size_t)((dim + 3) & ~3) + 4u * (size_t)nbcap + 4u * 3u * 40u;
     return b;
 }
 __device__ __forceinline__ SearchLds carve_lds(unsigned char *smem, int k, int cand_cap, int dim, int nbcap)
@@ -472,7 +473,8 @@ __device__ __forceinline__ SearchLds carve_lds(unsigned char *smem, int k, int c
     L.dbuf = reinterpret_cast<float *>(L.nbuf + nbcap);
     // heuristic-only regions (present when the launch sized LDS with heur = true)
     L.qs2 = L.dbuf + nbcap;
-    L.acc = reinterpret_cast<int *>(L.qs2 + ((dim + 3) & ~3));
+    L.qs3 = L.qs2 + ((dim + 3) & ~3);
+    L.acc = reinterpret_cast<int *>(L.qs3 + ((dim + 3) & ~3));
     L.stk = L.acc + nbcap;
     return L;
 }
@@ -1078,29 +1080,55 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
     if (!presorted) dev_dotnet_sort(cands, n, L.stk); // :22 (a sorted-list traversal hands them over in order)
     __syncthreads();
     int rc = 0;
+    // The row of candidate i + 1 is fetched while candidate i is being tested (registers, then the
+    // other of two LDS buffers): one dependent memory round trip per candidate instead of two.
+    constexpr int kPre = 4; // floats per lane: rows up to 256 floats; longer rows (bandwidth-bound anyway) are staged on demand
+    const bool prefetch = dim <= 64 * kPre;
+    float *buf[2] = {L.qs2, L.qs3};
+    int cur = 0;
+    double sbc = 0.0, sbn = 0.0;
     for (int i = 0; i < n && rc < max_edges; ++i) { // :23
         const ND c = cands[i];
-        if (rc == 0) { if (lane == 0) acc[0] = c.id; rc = 1; __syncthreads(); continue; }
-        const float *crow = rows + (size_t)c.id * dim;
-        for (int t = lane; t < dim; t += 64) L.qs2[t] = crow[t];
-        double sbc = 0.0;
-        if (METRIC == M_COS) sbc = row_sn[c.id];
-        __syncthreads();
-        // accepted ids are measured in chunks, in acceptance order, stopping at the first chunk
-        // that rejects (the reference breaks at the first hit, :34; later pairs cannot change the
-        // outcome) -- with long rows this saves most of the traffic of rejected candidates
-        const int chunk = dim >= 512 ? 16 : 32;
+        float pre[kPre];
+        const bool have_next = prefetch && i + 1 < n;
+        if (have_next) {
+            const int nid = cands[i + 1].id;
+            const float *nrow = rows + (size_t)nid * dim;
+#pragma unroll
+            for (int t = 0; t < kPre; ++t)
+                if (64 * t < dim) pre[t] = lane + 64 * t < dim ? nrow[lane + 64 * t] : 0.0f;
+            if (METRIC == M_COS) sbn = row_sn[nid];
+        }
         bool ok = true;
-        for (int a0 = 0; a0 < rc && ok; a0 += chunk) {
-            const int an = min(chunk, rc - a0);
-            measure_all<METRIC>(rows, row_sn, dim, L.qs2, sbc, acc + a0, L.dbuf, an, lane); // distanceFnc(s.Id, candidateId) :34
-            __syncthreads();
-            evals += (unsigned long long)an;
-            const float dj = lane < an ? L.dbuf[lane] : 0.0f;
-            ok = __ballot(lane < an && dj < c.dist) == 0ull;
-            __syncthreads();
+        if (rc > 0) {
+            if (!prefetch) { // candidate i on demand
+                const float *crow = rows + (size_t)c.id * dim;
+                for (int t = lane; t < dim; t += 64) buf[cur][t] = crow[t];
+                if (METRIC == M_COS) sbc = row_sn[c.id];
+                __syncthreads();
+            }
+            // accepted ids are measured in chunks, in acceptance order, stopping at the first chunk
+            // that rejects (the reference breaks at the first hit, :34; later pairs cannot change the
+            // outcome) -- with long rows this saves most of the traffic of rejected candidates
+            const int chunk = dim >= 512 ? 16 : 32;
+            for (int a0 = 0; a0 < rc && ok; a0 += chunk) {
+                const int an = min(chunk, rc - a0);
+                measure_all<METRIC>(rows, row_sn, dim, buf[cur], sbc, acc + a0, L.dbuf, an, lane); // distanceFnc(s.Id, candidateId) :34
+                __syncthreads();
+                evals += (unsigned long long)an;
+                const float dj = lane < an ? L.dbuf[lane] : 0.0f;
+                ok = __ballot(lane < an && dj < c.dist) == 0ull;
+                __syncthreads();
+            }
         }
         if (ok) { if (lane == 0) acc[rc] = c.id; rc++; }
+        if (have_next) {
+#pragma unroll
+            for (int t = 0; t < kPre; ++t)
+                if (64 * t < dim && lane + 64 * t < dim) buf[cur ^ 1][lane + 64 * t] = pre[t];
+            cur ^= 1;
+            sbc = sbn;
+        }
         __syncthreads();
     }
     return rc;
@@ -1305,7 +1333,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
 }
 
 template <int METRIC, int NS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS <= 4 ? 3 : 2))) // up to 256 candidates: 168 VGPRs, three waves per SIMD
 graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
