@@ -1077,7 +1077,28 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
         __syncthreads();
         return n;
     }
-    if (!presorted) dev_dotnet_sort(cands, n, L.stk); // :22 (a sorted-list traversal hands them over in order)
+    if (!presorted) { // :22 (a sorted-list traversal hands them over in order)
+        bool ranked = false;
+        if (n <= 64) {
+            // distinct ordinary distances have one ascending order whatever the sort: rank by counting
+            // (the link kernel's 2M+1 candidates; the scalar introsort below was 9 % of a PruneOverflow)
+            const ND mine = lane < n ? cands[lane] : ND{0, 0.0f};
+            const unsigned my_key = f2key(mine.dist);
+            bool odd = lane < n && key_unsafe(mine.dist);
+            int rank = 0;
+            for (int t = 0; t < n; ++t) {
+                const unsigned kt = (unsigned)__builtin_amdgcn_readlane((int)my_key, t);
+                rank += kt < my_key ? 1 : 0;
+                odd |= lane < n && t != lane && kt == my_key;
+            }
+            if (__ballot(odd) == 0ull) {
+                __syncthreads();
+                if (lane < n) cands[rank] = mine;
+                ranked = true;
+            }
+        }
+        if (!ranked) dev_dotnet_sort(cands, n, L.stk); // equal / NaN / -0 distances: the BCL introsort decides
+    }
     __syncthreads();
     int rc = 0;
     // The row of candidate i + 1 is fetched while candidate i is being tested (registers, then the
