@@ -150,6 +150,9 @@ private:
     int *g_adj0_ = nullptr, *g_level_ = nullptr, *g_pool_ = nullptr;
     int64_t *g_upper_ = nullptr;
     long long g_n_ = 0, g_cap_n_ = 0, g_pool_cap_ = 0;
+    // per adjacency list: how many leading entries are the ordered, mutually tested output of a
+    // RelativeNeighborPruning run (graph_link_kernel's shortcut); 0 = unknown
+    int *g_tested0_ = nullptr, *g_testedU_ = nullptr;
     int g_stride0_ = 0, g_strideU_ = 0;
     // search scratch
     unsigned *s_visited_ = nullptr;

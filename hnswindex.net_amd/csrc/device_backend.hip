@@ -440,6 +440,7 @@ __device__ __forceinline__ void measure_all(const float *rows, const double *row
     }
 }
 
+constexpr int kNewMax = 4;     // link kernel shortcut: new entries of an overflowing list measured against all others
 constexpr int kSpillCap = 8192; // candidate-heap entries per traversal that may spill to HBM
 constexpr int kNbufCap = 136; // upper bound of the id / distance scratch (2*M + 1 <= 128, set_graph)
 
@@ -1382,12 +1383,20 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
 // Insert, link half, on the HBM mirror.  (a) new nodes' own lists.
 __global__ void __launch_bounds__(64)
 graph_write_rows_kernel(int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool,
-                        int strideU, const int *__restrict__ recs, int row_stride)
+                        int strideU, const int *__restrict__ recs, int row_stride, int *__restrict__ tested0,
+                        int *__restrict__ testedU, int max_edges0)
 {
     const int *r = recs + (size_t)blockIdx.x * row_stride;
     const int node = r[0], layer = r[1], cnt = r[2];
     int *l = layer == 0 ? adj0 + (size_t)node * stride0 : pool + upper[node] + (size_t)(layer - 1) * strideU;
-    if (threadIdx.x == 0) l[0] = cnt;
+    if (threadIdx.x == 0) {
+        l[0] = cnt;
+        // a full list can only be the ordered output of the heuristic's greedy pass (fewer candidates
+        // than MaxEdges come back unsorted, Heuristic.cs:13-18): its entries are mutually tested
+        const int me = layer == 0 ? max_edges0 : (max_edges0 >> 1);
+        int *t = layer == 0 ? tested0 + node : testedU + (upper[node] / strideU + (layer - 1));
+        *t = cnt == me ? cnt : 0;
+    }
     for (int i = threadIdx.x; i < cnt; i += 64) l[1 + i] = r[3 + i];
 }
 
@@ -1401,10 +1410,14 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
                   int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
                   const int *__restrict__ g_node, const int *__restrict__ g_layer, const int *__restrict__ g_off,
                   const int *__restrict__ g_items, int max_edges0, int k_cap, int *__restrict__ out_lists, int list_stride,
-                  unsigned long long *__restrict__ eval_counter, int nbcap)
+                  unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchLds L = carve_lds(smem, k_cap, 0, dim, nbcap);
+    // shortcut scratch behind the common carve-up: distances of up to kNewMax new entries to every
+    // entry of the list, and the sorted order as original positions
+    float *Dm = reinterpret_cast<float *>(smem + ((search_lds_bytes(k_cap, 0, dim, true, nbcap) + 15) & ~(size_t)15));
+    int *perm = reinterpret_cast<int *>(Dm + kNewMax * nbcap);
     const int lane = threadIdx.x;
     const int g = blockIdx.x;
     const int node = g_node[g], layer = g_layer[g];
@@ -1416,6 +1429,8 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
     int cnt = l[0];
     for (int i = lane; i < cnt; i += 64) L.nbuf[i] = l[1 + i];
+    int *tested_p = layer == 0 ? tested0 + node : testedU + (upper[node] / strideU + (layer - 1));
+    int tested = min(max(*tested_p, 0), cnt); // leading entries that are an ordered, mutually tested heuristic output
     __syncthreads();
     unsigned long long evals = 0;
     PH_DECL();
@@ -1426,30 +1441,81 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
         __syncthreads();
         PH_COUNT(6, 1);
         if (cnt > max_edges) { // :209
-            PH_COUNT(7, 1);
             measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, L.nbuf, L.dbuf, cnt, lane); // Distance(cand, node.Id) :233
             __syncthreads();
-            PH(1);
             evals += (unsigned long long)cnt;
-            for (int i = lane; i < cnt; i += 64) L.top[i] = ND{L.nbuf[i], L.dbuf[i]};
-#ifdef EXP_PHASE_CLOCKS
-            __syncthreads();
-            dev_dotnet_sort(L.top, cnt, L.stk);
-            __syncthreads();
-            PH(2);
-            const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, cnt, max_edges, L, lane, evals, true);
-            PH(3);
-#else
-            const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, cnt, max_edges, L, lane, evals);
-#endif
+            int rc = -1;
+            // Shortcut.  The first `tested` entries are the output of an earlier greedy pass over this
+            // very list (same node, same distances): ascending, and every earlier one already passed
+            // the test `dist(s, c) < c.Dist` against every later one (Heuristic.cs:31-35).  Those pairs
+            // need not be measured again; only pairs with one of the entries appended since do.  With
+            // few new entries (typically one: lists are full, every append overflows) that is one
+            // batch of distances per new entry instead of one dependent batch per candidate.
+            const int n = cnt, u = n - tested;
+            if (tested > 0 && u <= kNewMax && n <= 64) {
+                const float my_d = lane < n ? L.dbuf[lane] : 0.0f;
+                const unsigned my_key = f2key(my_d);
+                bool odd = lane < n && key_unsafe(my_d);
+                int rank = 0;
+                for (int t2 = 0; t2 < n; ++t2) { // Span.Sort :22 -- distinct ordinary distances: rank by counting
+                    const unsigned kt = (unsigned)__builtin_amdgcn_readlane((int)my_key, t2);
+                    rank += kt < my_key ? 1 : 0;
+                    odd |= lane < n && t2 != lane && kt == my_key;
+                    // the tested prefix must still be ascending (it is, by construction)
+                    odd |= lane < tested && t2 < tested && ((t2 < lane && kt >= my_key) || (t2 > lane && kt <= my_key));
+                }
+                if (__ballot(odd) == 0ull) {
+                    if (lane < n) perm[rank] = lane;
+                    // distances of every new entry to all entries of the list
+                    for (int jn = 0; jn < u; ++jn) {
+                        const int xid = L.nbuf[tested + jn];
+                        const float *xrow = rows + (size_t)xid * dim;
+                        __syncthreads();
+                        for (int t2 = lane; t2 < dim; t2 += 64) L.qs2[t2] = xrow[t2];
+                        double sbx = 0.0;
+                        if (METRIC == M_COS) sbx = row_sn[xid];
+                        __syncthreads();
+                        measure_all<METRIC>(rows, row_sn, dim, L.qs2, sbx, L.nbuf, Dm + jn * nbcap, n, lane);
+                        evals += (unsigned long long)(n - 1);
+                    }
+                    __syncthreads();
+                    // greedy pass :23-40 in sorted order, on the distances at hand
+                    bool acc_me = false;            // lane i: entry i accepted
+                    unsigned new_acc = 0u;          // bit j: new entry j accepted
+                    rc = 0;
+                    for (int p2 = 0; p2 < n && rc < max_edges; ++p2) {
+                        const int i = perm[p2];
+                        const float di = L.dbuf[i];
+                        bool rej;
+                        if (i < tested) {           // an old entry: only accepted new ones can object
+                            rej = false;
+                            for (int jn = 0; jn < u; ++jn)
+                                if ((new_acc >> jn) & 1u) rej = rej || Dm[jn * nbcap + i] < di;
+                        } else {                    // a new entry: everything accepted so far can object
+                            const float dji = lane < n ? Dm[(i - tested) * nbcap + lane] : 0.0f;
+                            rej = __ballot(acc_me && dji < di) != 0ull;
+                        }
+                        if (!rej) {
+                            if (lane == i) acc_me = true;
+                            if (i >= tested) new_acc |= 1u << (i - tested);
+                            if (lane == 0) L.acc[rc] = L.nbuf[i];
+                            rc++;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (rc < 0) {
+                for (int i = lane; i < cnt; i += 64) L.top[i] = ND{L.nbuf[i], L.dbuf[i]};
+                rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, cnt, max_edges, L, lane, evals);
+            }
             for (int i = lane; i < rc; i += 64) L.nbuf[i] = L.acc[i]; // node.OutEdges[layer] = newOut :236
             cnt = rc;
+            tested = rc; // the whole list is a greedy output now
             __syncthreads();
         }
     }
-    PH(4);
-    PH_FLUSH_LINK();
-    if (lane == 0) { l[0] = cnt; out_lists[(size_t)g * list_stride] = cnt; }
+    if (lane == 0) { l[0] = cnt; *tested_p = tested; out_lists[(size_t)g * list_stride] = cnt; }
     for (int i = lane; i < cnt; i += 64) { l[1 + i] = L.nbuf[i]; out_lists[(size_t)g * list_stride + 1 + i] = L.nbuf[i]; }
     if (lane == 0) atomicAdd(eval_counter, evals);
 }
@@ -1572,7 +1638,7 @@ Device::~Device()
         }
     }
 #endif
-    for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)s_visited_, (void *)s_jobs_,
+    for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
                     (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vislog_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
@@ -1801,18 +1867,22 @@ bool Device::set_graph(const int *adj0, long long n, int stride0, const int *lev
         if (g_adj0_) HIP_OK(hipFree(g_adj0_));
         if (g_level_) HIP_OK(hipFree(g_level_));
         if (g_upper_) HIP_OK(hipFree(g_upper_));
-        g_adj0_ = nullptr; g_level_ = nullptr; g_upper_ = nullptr;
+        if (g_tested0_) HIP_OK(hipFree(g_tested0_));
+        g_adj0_ = nullptr; g_level_ = nullptr; g_upper_ = nullptr; g_tested0_ = nullptr;
         long long cap = std::max<long long>(n, std::max<long long>(capacity_, 1024));
         HIP_OK(hipMalloc(&g_adj0_, sizeof(int) * (size_t)cap * stride0));
         HIP_OK(hipMalloc(&g_level_, sizeof(int) * (size_t)cap));
         HIP_OK(hipMalloc(&g_upper_, sizeof(int64_t) * (size_t)cap));
+        HIP_OK(hipMalloc(&g_tested0_, sizeof(int) * (size_t)cap));
         g_cap_n_ = cap;
     }
     if (pool_len > g_pool_cap_) {
         if (g_pool_) HIP_OK(hipFree(g_pool_));
-        g_pool_ = nullptr;
+        if (g_testedU_) HIP_OK(hipFree(g_testedU_));
+        g_pool_ = nullptr; g_testedU_ = nullptr;
         long long cap = std::max<long long>(pool_len * 2, 4096);
         HIP_OK(hipMalloc(&g_pool_, sizeof(int) * (size_t)cap));
+        HIP_OK(hipMalloc(&g_testedU_, sizeof(int) * (size_t)cap)); // indexed by list offset / strideU: never more than cap
         g_pool_cap_ = cap;
     }
     g_n_ = n; g_stride0_ = stride0; g_strideU_ = strideU;
@@ -1822,6 +1892,9 @@ bool Device::set_graph(const int *adj0, long long n, int stride0, const int *lev
         HIP_OK(hipMemcpyAsync(g_upper_, upper, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
     }
     if (pool_len > 0) HIP_OK(hipMemcpyAsync(g_pool_, pool, sizeof(int) * (size_t)pool_len, hipMemcpyHostToDevice, st));
+    // lists that arrive from the host carry no pruning history
+    if (g_tested0_) HIP_OK(hipMemsetAsync(g_tested0_, 0, sizeof(int) * (size_t)g_cap_n_, st));
+    if (g_testedU_) HIP_OK(hipMemsetAsync(g_testedU_, 0, sizeof(int) * (size_t)g_pool_cap_, st));
     HIP_OK(hipStreamSynchronize(st)); // host arrays are borrowed only for this call
     return true;
 }
@@ -2058,6 +2131,8 @@ bool Device::graph_append_nodes(long long first, long long n, const int *level, 
     HIP_OK(hipMemcpyAsync(g_upper_ + first, upper + first, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st));
     // new nodes start with empty lists (GraphData.NewNode :224-242)
     HIP_OK(hipMemsetAsync(g_adj0_ + (size_t)first * g_stride0_, 0, sizeof(int) * (size_t)n * g_stride0_, st));
+    HIP_OK(hipMemsetAsync(g_tested0_ + first, 0, sizeof(int) * (size_t)n, st));
+    if (pool_len > pool_from) HIP_OK(hipMemsetAsync(g_testedU_ + pool_from / std::max(1, g_strideU_), 0, sizeof(int) * (size_t)((pool_len - pool_from) / std::max(1, g_strideU_) + 1), st));
     if (pool_len > pool_from) HIP_OK(hipMemcpyAsync(g_pool_ + pool_from, pool + pool_from, sizeof(int) * (size_t)(pool_len - pool_from), hipMemcpyHostToDevice, st));
     HIP_OK(hipStreamSynchronize(st));
     g_n_ = first + n;
@@ -2144,7 +2219,8 @@ bool Device::link_batch_begin(int set, const int *rows, int nrows, int row_strid
     ls.timed = false;
     if (nrows > 0) {
         HIP_OK(hipMemcpyAsync(s_lk_[0], h_rows, sizeof(int) * need[0], hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(graph_write_rows_kernel, dim3(nrows), dim3(64), 0, st, g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_lk_[0], row_stride);
+        hipLaunchKernelGGL(graph_write_rows_kernel, dim3(nrows), dim3(64), 0, st, g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_lk_[0], row_stride,
+                           g_tested0_, g_testedU_, max_edges0);
         HIP_OK(hipGetLastError());
     }
     if (ngroups > 0) {
@@ -2155,11 +2231,11 @@ bool Device::link_batch_begin(int set, const int *rows, int nrows, int row_strid
         ls.timed = profiling_;
         if (ls.timed) HIP_OK(hipEventRecord((hipEvent_t)ls.ev_start, st));
         const int k_cap = nbcap();
-        const size_t lds = search_lds_bytes(k_cap, 0, dim_, true, nbcap());
+        const size_t lds = ((search_lds_bytes(k_cap, 0, dim_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
 #define LAUNCH(M)                                                                                                          \
     hipLaunchKernelGGL(graph_link_kernel<M>, dim3(ngroups), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_,  \
                        g_upper_, g_pool_, g_strideU_, s_lk_[1], s_lk_[1] + ngroups, s_lk_[2], s_lk_[3], max_edges0, k_cap,    \
-                       s_lk_[4], list_stride, s_evals_, nbcap())
+                       s_lk_[4], list_stride, s_evals_, nbcap(), g_tested0_, g_testedU_)
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
         else LAUNCH(M_UCOS);
