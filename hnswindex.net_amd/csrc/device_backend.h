@@ -118,8 +118,10 @@ public:
     // copy-out on the stream; finish waits for that set and returns its lists (valid until the set
     // is used again).  Sub-batches are applied in the order they were begun.
     bool link_batch_begin(int set, const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
-                          const int *g_items, int ngroups, int max_edges0, int list_stride);
+                          const int *g_items, int ngroups, int max_edges0, int list_stride, bool want_lists = true);
     bool link_batch_finish(int set, const int **out_lists);
+    // The adjacency mirror back to the host (adj0: n x stride0 ints, pool: pool_len ints).
+    bool download_graph(int *adj0, long long n, int *pool, long long pool_len);
 
     // C-ABI conveniences (synchronous; validate ids on the host before launching).
     bool dist_query_batch(const float *queries, int nq, const int *offsets, const int *ids, float *out);

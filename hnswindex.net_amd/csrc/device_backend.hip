@@ -2151,7 +2151,7 @@ bool Device::link_batch(const int *rows, int nrows, int row_stride, const int *g
 }
 
 bool Device::link_batch_begin(int set, const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
-                              const int *g_items, int ngroups, int max_edges0, int list_stride)
+                              const int *g_items, int ngroups, int max_edges0, int list_stride, bool want_lists)
 {
     if (set < 0 || set > 1 || nrows < 0 || ngroups < 0 || (nrows > 0 && !rows) || (ngroups > 0 && (!g_node || !g_layer || !g_off || !g_items))) {
         set_dev_error("link_batch: bad argument");
@@ -2242,11 +2242,22 @@ bool Device::link_batch_begin(int set, const int *rows, int nrows, int row_strid
 #undef LAUNCH
         HIP_OK(hipGetLastError());
         if (ls.timed) HIP_OK(hipEventRecord((hipEvent_t)ls.ev_stop, st));
-        HIP_OK(hipMemcpyAsync(ls.h_out, s_lk_[4], sizeof(int) * (size_t)ngroups * list_stride, hipMemcpyDeviceToHost, st));
+        if (want_lists) HIP_OK(hipMemcpyAsync(ls.h_out, s_lk_[4], sizeof(int) * (size_t)ngroups * list_stride, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(ls.h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     }
     HIP_OK(hipEventRecord((hipEvent_t)ls.ev_done, st));
     ls.busy = true;
+    return true;
+}
+
+bool Device::download_graph(int *adj0, long long n, int *pool, long long pool_len)
+{
+    if (n < 0 || n > g_n_ || pool_len < 0 || pool_len > g_pool_cap_ || (n > 0 && !adj0) || (pool_len > 0 && !pool)) { set_dev_error("download_graph: bad argument"); return false; }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    if (n > 0) HIP_OK(hipMemcpyAsync(adj0, g_adj0_, sizeof(int) * (size_t)n * g_stride0_, hipMemcpyDeviceToHost, st));
+    if (pool_len > 0) HIP_OK(hipMemcpyAsync(pool, g_pool_, sizeof(int) * (size_t)pool_len, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
     return true;
 }
 

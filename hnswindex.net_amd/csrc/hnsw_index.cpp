@@ -682,6 +682,7 @@ bool HnswIndex::ensure_capacity(long long need, std::string &err)
 bool HnswIndex::search_half_lockstep(const std::vector<int> &bid, const std::vector<int> &items, Selection &sel, std::string &err)
 {
     if (items.empty()) return true;
+    if (!refresh_host_lists(err)) return false; // host traversal reads the neighbour lists
     InsertSource src;
     src.jobs.resize(items.size());
     for (size_t t = 0; t < items.size(); ++t) {
@@ -768,6 +769,7 @@ void collect_groups(Graph &g, const std::vector<int> &bid, const Sel &sel, std::
 
 bool HnswIndex::link_half_lockstep(const std::vector<int> &bid, const Selection &sel, std::string &err)
 {
+    if (!refresh_host_lists(err)) return false;
     std::vector<LinkGroup> groups;
     collect_groups(graph_, bid, sel, groups);
     LinkSource links;
@@ -797,19 +799,15 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
     // the next and files the previous one's lists.
     static const int split = [] { const char *e = std::getenv("HNSW_MI355X_LINK_SPLIT"); return e ? std::max(1, std::atoi(e)) : 4; }();
     const int S = n >= 2048 ? split : 1;
-    struct Pending { bool on = false; std::vector<int> node, layer; } pend[2];
+    // The lists the link kernel leaves behind stay in the HBM mirror; the host copy is marked stale
+    // and fetched back when something on the host needs it (refresh_host_lists).
+    host_lists_stale_ = true;
+    bool pend[2] = {false, false};
     auto finish = [&](int set) -> bool {
-        if (!pend[set].on) return true;
-        const int *out_lists = nullptr;
-        { Tick t(g_pt.link_dev); if (!dev_->link_batch_finish(set, &out_lists)) { err = get_dev_error(); return false; } }
-        Tick t(g_pt.link_host);
-        const std::vector<int> &gn = pend[set].node, &gl = pend[set].layer;
-        parallel_for((int)gn.size(), threads_, [&](int g) { // node.OutEdges[layer] as left by the appends / prunes
-            const int *o = out_lists + (size_t)g * list_stride;
-            int *l = graph_.list(gn[(size_t)g], gl[(size_t)g]);
-            std::memcpy(l, o, sizeof(int) * (size_t)(o[0] + 1));
-        });
-        pend[set].on = false;
+        if (!pend[set]) return true;
+        Tick t(g_pt.link_dev);
+        if (!dev_->link_batch_finish(set, nullptr)) { err = get_dev_error(); return false; }
+        pend[set] = false;
         return true;
     };
     // per-batch work arrays live in the index (their capacity settles after the first full batch)
@@ -832,10 +830,7 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
                 for (int layer = std::min(graph_.level[(size_t)id], top); layer >= 0; --layer) {
                     const int *sp; int sc;
                     sel.get(i, layer, sp, sc);
-                    int *l = graph_.list(id, layer); // currNode.OutEdges[layer] = selected (:192), host copy
-                    l[0] = sc;
-                    std::memcpy(l + 1, sp, sizeof(int) * (size_t)sc);
-                    size_t r0 = rows.size();
+                    size_t r0 = rows.size(); // currNode.OutEdges[layer] = selected (:192), written to the mirror by the launch
                     rows.resize(r0 + (size_t)row_stride); // the tail beyond sc ids is never read (link_batch validates [0, sc))
                     rows[r0] = id; rows[r0 + 1] = layer; rows[r0 + 2] = sc;
                     std::memcpy(rows.data() + r0 + 3, sp, sizeof(int) * (size_t)sc);
@@ -869,11 +864,9 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
             Tick t(g_pt.link_dev);
             g_pt.rounds++;
             if (!dev_->link_batch_begin(set, rows.data(), (int)(rows.size() / (size_t)row_stride), row_stride, g_node.data(), g_layer.data(),
-                                        g_off.data(), g_items.data(), (int)g_node.size(), M2, list_stride)) { err = get_dev_error(); return false; }
+                                        g_off.data(), g_items.data(), (int)g_node.size(), M2, list_stride, false)) { err = get_dev_error(); return false; }
         }
-        pend[set].node = g_node;
-        pend[set].layer = g_layer;
-        pend[set].on = true;
+        pend[set] = true;
     }
     // in the order they were begun
     const int first = S >= 2 ? (S & 1) : 0;
@@ -906,6 +899,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
     double t_nodes0 = g_pt.on ? now_s() : 0;
     // GraphData.AddItem (src/HNSWIndex/GraphData.cs:79-118): one RNG draw per item, in order;
     // vacated slots are reused first when removals are allowed (:85-91)
+    if (p_.allow_removals && !graph_.removed_stack.empty() && !refresh_host_lists(err)) return -1; // slot reuse rewrites host rows
     std::vector<int> ids((size_t)count), fresh; // fresh: the new nodes, in insertion order
     fresh.reserve((size_t)count);
     bool any_reused = false;
@@ -967,6 +961,7 @@ bool HnswIndex::sync_graph(std::string &err)
         }
         if (!full) { dev_pool_len_ = (long long)graph_.pool.size(); return true; }
     }
+    if (!refresh_host_lists(err)) return false; // a full upload sends the host copy: it must be current
     if (!dev_->set_graph(graph_.adj0.data(), graph_.length, graph_.stride0, graph_.level.data(), graph_.upper.data(),
                          graph_.pool.data(), (long long)graph_.pool.size(), graph_.strideU)) {
         err = get_dev_error();
@@ -980,6 +975,7 @@ bool HnswIndex::sync_graph(std::string &err)
 // Host lock-step traversal for the queries listed in `which` (nullptr: all `count` queries).
 int HnswIndex::knn_query_lockstep(const int *which, int count, int k, int *out_ids, float *out_dists, std::string &err)
 {
+    if (!refresh_host_lists(err)) return -1;
     QuerySource src;
     src.jobs.resize((size_t)count);
     const int ef = std::max(p_.min_nn, k); // HNSWIndex.cs:115
@@ -1056,6 +1052,7 @@ int HnswIndex::range_query(const float *queries, int count, int dim, float range
     out.assign((size_t)std::max(count, 0), {});
     if (count <= 0 || graph_.entry < 0) return 0; // HNSWIndex.cs:146
     if (!ensure_dim(dim, err)) return -1;
+    if (!refresh_host_lists(err)) return -1;
     if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; }
     RangeSource src;
     src.jobs.resize((size_t)count);
@@ -1080,6 +1077,7 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
 {
     if (!p_.allow_removals) { err = "System.InvalidOperationException: Removals are disabled in this index instance."; return -1; } // :85-86
     if (count <= 0) return 0;
+    if (!refresh_host_lists(err)) return -1;
     for (int t = 0; t < count; ++t) {
         const int id = ids[t];
         if (id < 0 || id >= graph_.length || graph_.removed[(size_t)id]) { err = "System.IndexOutOfRangeException: hnsw_remove: id " + std::to_string(id) + " is not in the index"; return -1; }
@@ -1163,6 +1161,7 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
 int HnswIndex::serialize(const char *path, std::string &err)
 {
     if (!path) { err = "System.ArgumentNullException: filePath"; return -1; }
+    if (!refresh_host_lists(err)) return -1;
     SnapshotParams sp;
     sp.max_edges = p_.max_edges;
     sp.distribution_rate = p_.distribution_rate;
@@ -1221,6 +1220,26 @@ HnswIndex *HnswIndex::deserialize(int metric, const Params &backend, const char 
     return ix;
 }
 
-uint64_t HnswIndex::graph_hash() const { return graph_hash_of(graph_); }
+uint64_t HnswIndex::graph_hash()
+{
+    std::string e;
+    (void)refresh_host_lists(e);
+    return graph_hash_of(graph_);
+}
+
+// Neighbour lists written by the device link half, back into the host copy.
+bool HnswIndex::refresh_host_lists(std::string &err)
+{
+    if (!host_lists_stale_) return true;
+    // nodes / pool blocks appended on the host since the last sync are not in the mirror yet (their lists are empty)
+    const long long n = std::min<long long>(graph_.length, dev_ ? dev_->graph_nodes() : 0);
+    const long long pl = std::min<long long>((long long)graph_.pool.size(), dev_pool_len_);
+    if (!dev_ || !dev_->download_graph(graph_.adj0.data(), n, graph_.pool.data(), pl)) {
+        err = get_dev_error();
+        return false;
+    }
+    host_lists_stale_ = false;
+    return true;
+}
 
 } // namespace hnsw

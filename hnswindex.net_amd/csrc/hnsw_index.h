@@ -60,9 +60,11 @@ public:
 
     int count() const { return graph_.count; }
     int dim() const { return dim_; }
-    const Graph &graph() const { return graph_; }
+    // The host copy of the graph.  After a device-linked Add the neighbour lists live in the HBM
+    // mirror only and are fetched back here on demand.
+    const Graph &graph() { std::string e; (void)refresh_host_lists(e); return graph_; }
     Device *device() { return dev_.get(); }
-    uint64_t graph_hash() const;
+    uint64_t graph_hash();
     void set_profiling(bool on) { profiling_ = on; if (dev_) dev_->set_profiling(on); }
 
 private:
@@ -91,6 +93,7 @@ private:
     bool link_half_lockstep(const std::vector<int> &bid, const Selection &sel, std::string &err);
     bool link_half_device(const std::vector<int> &bid, const Selection &sel, std::string &err);
     bool sync_graph(std::string &err);
+    bool refresh_host_lists(std::string &err);
     int knn_query_device(const float *queries, int count, int k, int *out_ids, float *out_dists, std::string &err);
     int knn_query_lockstep(const int *which, int count, int k, int *out_ids, float *out_dists, std::string &err);
 
@@ -109,6 +112,7 @@ private:
     bool profiling_ = false;
     int resident_queries_ = 0;
     bool graph_dirty_ = true;       // HBM mirror needs a full re-upload
+    bool host_lists_stale_ = false; // the HBM mirror holds newer neighbour lists than graph_ (device-linked Add)
     long long dev_pool_len_ = 0;    // pool ints already mirrored
     std::vector<int> grp_of_node0_; // link half: group index per layer-0 neighbour (-1 = none)
     std::vector<int> lk_rows_, lk_node_, lk_layer_, lk_cnt_, lk_off_, lk_items_, lk_fill_, lk_out_; // link half: per-batch work arrays
