@@ -1,4 +1,5 @@
-"""Parity soak at sizes between the unit tests and the full-size test: float-resolution ties are
+"""Parity soak at sizes between the unit tests and the full-size test (optional 4th argument
+`clustered`): float-resolution ties are
 common enough there (a few per thousand traversals) to exercise the sorted-list traversal's tie
 rules against the oracle.  Usage: python tools/soak.py [n] [dim] [nq]"""
 import sys
@@ -13,11 +14,17 @@ import oracle  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60_000
 dim = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
+clustered = len(sys.argv) > 4 and sys.argv[4] == "clustered"  # Gaussian mixture: the heuristic rejects far more than on uniform data
 fails = 0
 for seed, (M, efc, ef, k) in enumerate([(16, 200, 128, 10), (8, 100, 64, 5), (24, 300, 256, 20)]):
     rng = np.random.default_rng(900 + seed)
-    x = rng.random((n, dim), dtype=np.float32)
-    q = rng.random((nq, dim), dtype=np.float32)
+    if clustered:
+        centres = rng.random((200, dim), dtype=np.float32)
+        x = (centres[rng.integers(0, 200, n)] + 0.05 * rng.standard_normal((n, dim), dtype=np.float32)).astype(np.float32)
+        q = (centres[rng.integers(0, 200, nq)] + 0.05 * rng.standard_normal((nq, dim), dtype=np.float32)).astype(np.float32)
+    else:
+        x = rng.random((n, dim), dtype=np.float32)
+        q = rng.random((nq, dim), dtype=np.float32)
     ix = hnswindex.Index(dim)
     ix.set_collection_size(n); ix.set_max_edges(M); ix.set_max_candidates(efc); ix.set_min_nn(ef)
     t = time.time(); ix.add(x); tb = time.time() - t
