@@ -1452,20 +1452,25 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
             // few new entries (typically one: lists are full, every append overflows) that is one
             // batch of distances per new entry instead of one dependent batch per candidate.
             const int n = cnt, u = n - tested;
-            if (tested > 0 && u <= kNewMax && n <= 64) {
-                const float my_d = lane < n ? L.dbuf[lane] : 0.0f;
-                const unsigned my_key = f2key(my_d);
-                bool odd = lane < n && key_unsafe(my_d);
-                int rank = 0;
+            if (tested > 0 && u <= kNewMax && n <= 128) { // entries i = lane and i = lane + 64 on each lane
+                const int i1 = lane + 64;
+                const float d0 = lane < n ? L.dbuf[lane] : 0.0f, d1 = i1 < n ? L.dbuf[i1] : 0.0f;
+                const unsigned k0 = f2key(d0), k1 = f2key(d1);
+                bool odd = (lane < n && key_unsafe(d0)) || (i1 < n && key_unsafe(d1));
+                int rank0 = 0, rank1 = 0;
                 for (int t2 = 0; t2 < n; ++t2) { // Span.Sort :22 -- distinct ordinary distances: rank by counting
-                    const unsigned kt = (unsigned)__builtin_amdgcn_readlane((int)my_key, t2);
-                    rank += kt < my_key ? 1 : 0;
-                    odd |= lane < n && t2 != lane && kt == my_key;
+                    const unsigned kt = t2 < 64 ? (unsigned)__builtin_amdgcn_readlane((int)k0, t2) : (unsigned)__builtin_amdgcn_readlane((int)k1, t2 - 64);
+                    rank0 += kt < k0 ? 1 : 0;
+                    rank1 += kt < k1 ? 1 : 0;
+                    odd |= lane < n && t2 != lane && kt == k0;
+                    odd |= i1 < n && t2 != i1 && kt == k1;
                     // the tested prefix must still be ascending (it is, by construction)
-                    odd |= lane < tested && t2 < tested && ((t2 < lane && kt >= my_key) || (t2 > lane && kt <= my_key));
+                    odd |= lane < tested && t2 < tested && ((t2 < lane && kt >= k0) || (t2 > lane && kt <= k0));
+                    odd |= i1 < tested && t2 < tested && ((t2 < i1 && kt >= k1) || (t2 > i1 && kt <= k1));
                 }
                 if (__ballot(odd) == 0ull) {
-                    if (lane < n) perm[rank] = lane;
+                    if (lane < n) perm[rank0] = lane;
+                    if (i1 < n) perm[rank1] = i1;
                     // distances of every new entry to all entries of the list
                     for (int jn = 0; jn < u; ++jn) {
                         const int xid = L.nbuf[tested + jn];
@@ -1480,8 +1485,8 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
                     }
                     __syncthreads();
                     // greedy pass :23-40 in sorted order, on the distances at hand
-                    bool acc_me = false;            // lane i: entry i accepted
-                    unsigned new_acc = 0u;          // bit j: new entry j accepted
+                    bool acc0 = false, acc1 = false; // entries lane / lane + 64 accepted
+                    unsigned new_acc = 0u;           // bit j: new entry j accepted
                     rc = 0;
                     for (int p2 = 0; p2 < n && rc < max_edges; ++p2) {
                         const int i = perm[p2];
@@ -1492,11 +1497,13 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
                             for (int jn = 0; jn < u; ++jn)
                                 if ((new_acc >> jn) & 1u) rej = rej || Dm[jn * nbcap + i] < di;
                         } else {                    // a new entry: everything accepted so far can object
-                            const float dji = lane < n ? Dm[(i - tested) * nbcap + lane] : 0.0f;
-                            rej = __ballot(acc_me && dji < di) != 0ull;
+                            const float *Dj = Dm + (i - tested) * nbcap;
+                            const float e0 = lane < n ? Dj[lane] : 0.0f, e1 = i1 < n ? Dj[i1] : 0.0f;
+                            rej = __ballot((acc0 && e0 < di) || (acc1 && e1 < di)) != 0ull;
                         }
                         if (!rej) {
-                            if (lane == i) acc_me = true;
+                            if (lane == i) acc0 = true;
+                            if (i1 == i) acc1 = true;
                             if (i >= tested) new_acc |= 1u << (i - tested);
                             if (lane == 0) L.acc[rc] = L.nbuf[i];
                             rc++;
