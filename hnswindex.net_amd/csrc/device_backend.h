@@ -164,6 +164,9 @@ private:
     size_t s_vislog_cap_ = 0;
     bool visited_log(size_t vis_bytes_per_job, int **out);
     int num_cu_ = 256;
+    // Persistent launches never use more than 16 one-wave blocks per CU (the traversal kernels need
+    // >= 128 VGPRs): the per-wave scratch (visited bitsets, spill areas, logs) is sized for that.
+    int max_slots() const { return num_cu_ * 16; }
     SearchJob *s_jobs_ = nullptr;
     SearchHit *s_hits_ = nullptr;
     int *s_cnt_ = nullptr, *s_flag_ = nullptr;

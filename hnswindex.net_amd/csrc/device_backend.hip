@@ -1928,8 +1928,7 @@ static int resident_blocks(K kernel, size_t lds, int num_cu)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
     return per_cu * std::max(1, num_cu);
 }
-constexpr int kMaxSlots = 256 * 32;
-constexpr int kVisLogCap = 16384; // ids a traversal may log before it falls back to streaming the bitset clear // scratch is sized for this many resident waves (8 per SIMD, 256 CUs)
+constexpr int kVisLogCap = 16384; // ids a traversal may log before it falls back to streaming the bitset clear
 
 static int cand_lds_cap(int k, int dim, bool heur, int nbcap)
 {
@@ -1971,7 +1970,7 @@ bool Device::visited_log(size_t vis_bytes_per_job, int **out)
     const char *e = std::getenv("HNSW_MI355X_VIS_LOG"); // tests: 1 forces the log, 0 forbids it
     const bool want = e ? std::atoi(e) != 0 : vis_bytes_per_job > (512u << 10);
     if (!want) return true;
-    if (!grow_dev(&s_vislog_, &s_vislog_cap_, (size_t)kMaxSlots * kVisLogCap)) return false;
+    if (!grow_dev(&s_vislog_, &s_vislog_cap_, (size_t)max_slots() * kVisLogCap)) return false;
     *out = s_vislog_;
     return true;
 }
@@ -2034,7 +2033,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     const long long vis_words = ((g_n_ + 31) / 32 + 3) & ~3LL;
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
     const long long chunk = std::min<long long>(njobs, 1 << 20);
-    if (!ensure_search_scratch(chunk, kMaxSlots, 0, vis_bytes_per_job)) return false;
+    if (!ensure_search_scratch(chunk, max_slots(), 0, vis_bytes_per_job)) return false;
     int *vis_log = nullptr;
     if (!visited_log(vis_bytes_per_job, &vis_log)) return false;
     const size_t nU = (size_t)std::max(n_upper, 1);
@@ -2068,7 +2067,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
 #define LAUNCH2(M, NS_, GRID, LDS, CAP) \
     hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_>), \
-                       dim3(std::min<int>(GRID, std::min(kMaxSlots, resident_blocks(graph_insert_search_kernel<M, NS_>, LDS, num_cu_)))), \
+                       dim3(std::min<int>(GRID, std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_>, LDS, num_cu_)))), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_log, vis_log_cap_for_tests(), s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
@@ -2323,7 +2322,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     const long long vis_words = ((g_n_ + 31) / 32 + 3) & ~3LL;
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
     const long long chunk = std::min<long long>(njobs, 1 << 20);
-    if (!ensure_search_scratch(chunk, kMaxSlots, k_out, vis_bytes_per_job)) return false;
+    if (!ensure_search_scratch(chunk, max_slots(), k_out, vis_bytes_per_job)) return false;
     int *vis_log = nullptr;
     if (!visited_log(vis_bytes_per_job, &vis_log)) return false;
     // pinned layout: [evals (16 B) | jobs | ids | dists | flags]
@@ -2347,7 +2346,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
 #define LAUNCH2(M, NS_, GRID, LDS, CAP) \
     hipLaunchKernelGGL((graph_search_kernel<M, NS_>), \
-                       dim3(std::min<int>(GRID, std::min(kMaxSlots, resident_blocks(graph_search_kernel<M, NS_>, LDS, num_cu_)))), \
+                       dim3(std::min<int>(GRID, std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_>, LDS, num_cu_)))), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
                        spill_cap_for_tests(), s_visited_, vis_words, vis_log, vis_log_cap_for_tests(), k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_)
