@@ -169,3 +169,27 @@ def test_large_batches_link_in_pipelined_sub_batches(Index):
     ix = _build(Index, x, 8, 40, 10, 16384)
     assert ix.graph_hash() == ref.graph_hash()
     assert (ix.levels() == ref.levels()).all() and ix.entry_point == ref.entry_point
+
+
+def test_nan_and_negative_zero_distances_are_handed_back(Index):
+    # NaN / -0 distances have no place in the integer-key order of the device traversals: such jobs
+    # are handed to the host traversal (after a device-linked Add that means fetching the lists back)
+    rng = np.random.default_rng(77)
+    x = rng.random((3000, 8), dtype=np.float32)
+    x[100] = np.nan                       # every distance to this row is NaN
+    x[200] = x[201]                       # cosine distance of identical rows: 1 - 1 = +0; keep one exact -0 source too
+    q = rng.random((300, 8), dtype=np.float32)
+    q[5] = np.nan
+    for metric in ("sq_euclid", "cosine"):
+        ref = oracle.OracleIndex(8, metric, max_edges=8, max_candidates=40, min_nn=20, collection_size=3000)
+        ref.add_batched(x, 16384)
+        ix = Index(8, metric)
+        ix.set_collection_size(3000); ix.set_max_edges(8); ix.set_max_candidates(40); ix.set_min_nn(20)
+        ix.add(x)
+        assert ix.graph_hash() == ref.graph_hash(), metric
+        got, want = ix.knn_query(q, 5), ref.knn_query(q, 5)
+        assert (got[0] == want[0]).all(), metric
+        # NaN is NaN: x86 keeps the operand's sign in `a - NaN`, the GPU's subtract flips it
+        nan = np.isnan(want[1])
+        assert (np.isnan(got[1]) == nan).all() and got[1][~nan].tobytes() == want[1][~nan].tobytes(), metric
+        assert ix.stats()["search_overflows"] > 0

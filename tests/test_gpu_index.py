@@ -198,6 +198,7 @@ def test_candidate_heap_spill_and_handback_are_exact(Index, monkeypatch, spill_c
     ref = oracle.OracleIndex(64, collection_size=4000, min_nn=64)
     ref.add_batched(x, 512)
     want_ids, want_d = ref.knn_query(q, 10)
+    monkeypatch.setenv("HNSW_MI355X_SORTED_TOP", "0")   # the two-heap traversal is the one with a candidate heap
     monkeypatch.setenv("HNSW_MI355X_CAND_CAP", "24")
     monkeypatch.setenv("HNSW_MI355X_SPILL_CAP", spill_cap)
     ix = Index(64); ix.set_collection_size(4000); ix.set_min_nn(64); ix.set_insert_batch(512)
