@@ -140,11 +140,13 @@ def main():
     lo, hi = dmod.shard_bounds(nq_total, world, rank)
     ix.set_resident_queries(q_all[lo:hi])
 
+    # one all-gather of the packed top-k leaves the full result on every GPU; rank 0 copies it to its
+    # host (pinned buffer, returned as views) -- SURVEY.md 8e
     def step():
-        return dmod.knn_query_sharded(lambda qs, k: ix.knn_query_resident(k), q_all, a.k)
+        return dmod.knn_query_sharded(lambda qs, k: ix.knn_query_resident(k), q_all, a.k, dst_rank=0, copy=False)
 
     def step_pcie():  # same work with the queries handed over as host buffers every step
-        return dmod.knn_query_sharded(ix.knn_query, q_all, a.k)
+        return dmod.knn_query_sharded(ix.knn_query, q_all, a.k, dst_rank=0, copy=False)
 
     for _ in range(a.warmup):
         step()
@@ -156,6 +158,8 @@ def main():
         res_ids, res_d = step()
     barrier()
     dt = time.perf_counter() - t0
+    if res_ids is not None:  # views of the exchange buffer: keep them past the next call
+        res_ids, res_d = np.array(res_ids), np.array(res_d)
     st = ix.stats()
     ix.set_profiling(False)
     barrier()

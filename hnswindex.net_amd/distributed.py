@@ -26,33 +26,77 @@ def shard_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_buffers = {}
+
+
+def _buffer(key, shape, device, pinned=False):
+    """Cached exchange buffers: the gather runs every step with the same shapes."""
+    import torch
+    t = _buffers.get(key)
+    if t is None or tuple(t.shape) != tuple(shape) or t.device != torch.device(device):
+        t = torch.empty(shape, dtype=torch.int32, device=device, pin_memory=pinned)
+        _buffers[key] = t
+    return t
+
+
 def knn_query_sharded(search: Callable[[np.ndarray, int], Tuple[np.ndarray, np.ndarray]], queries: np.ndarray, k: int,
-                      group=None, device=None) -> Tuple[np.ndarray, np.ndarray]:
+                      group=None, device=None, dst_rank=None, copy: bool = True, _always_exchange: bool = False):
     """
     search(queries_shard, k) -> (ids int32 [m,k], dists float32 [m,k]) is this rank's local
     searcher (an `Index.knn_query` bound method).  Returns the full (ids, dists) for all
-    queries on every rank.  Without an initialised process group this is a plain call.
+    queries; without an initialised process group this is a plain call.
+
+    dst_rank=None: every rank copies the gathered result to its host.  dst_rank=r: the gathered
+    tensor stays on the device everywhere, only rank r copies it out (the others return
+    (None, None)) -- SURVEY.md 8e: "full result on every rank (rank 0 copies to host)".
+    copy=False returns views of a reused pinned buffer (valid until the next call).
     """
     import torch
     import torch.distributed as dist
 
     q = np.ascontiguousarray(queries, dtype=np.float32)
     nq = q.shape[0]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _always_exchange):
         return search(q, k)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = shard_bounds(nq, world, rank)
     per = -(-nq // world)  # every rank contributes the same number of rows to the gather
     ids, d = search(q[lo:hi], k) if hi > lo else (np.empty((0, k), np.int32), np.empty((0, k), np.float32))
-    packed = np.full((per, 2 * k), -1, dtype=np.int32)
-    packed[: hi - lo, :k] = ids
-    packed[: hi - lo, k:] = np.ascontiguousarray(d, dtype=np.float32).view(np.int32)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    mine = torch.from_numpy(packed).to(device)
-    gathered = torch.empty((world * per, 2 * k), dtype=torch.int32, device=device)
+    device = torch.device(device)
+    on_gpu = device.type == "cuda"
+    # ids and distance bit patterns side by side in one int32 tensor; staged through pinned memory
+    stage = _buffer(("stage", per, k), (per, 2 * k), "cpu", pinned=on_gpu)
+    st = stage.numpy()
+    st[: hi - lo, :k] = ids
+    st[: hi - lo, k:] = np.ascontiguousarray(d, dtype=np.float32).view(np.int32)
+    if hi - lo < per:
+        st[hi - lo:] = -1
+    if on_gpu:
+        mine = _buffer(("mine", per, k), (per, 2 * k), device)
+        mine.copy_(stage, non_blocking=True)
+    else:
+        mine = stage
+    gathered = _buffer(("gathered", world, per, k), (world * per, 2 * k), device)
     dist.all_gather_into_tensor(gathered, mine, group=group)  # RCCL ncclAllGather over xGMI
-    g = gathered.cpu().numpy().reshape(world, per, 2 * k)
+    if dst_rank is not None and rank != dst_rank:
+        if on_gpu:
+            torch.cuda.current_stream(device).synchronize()
+        return None, None
+    if on_gpu:
+        out = _buffer(("out", world, per, k), (world * per, 2 * k), "cpu", pinned=True)
+        out.copy_(gathered, non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+        g = out.numpy()
+    else:
+        g = gathered.numpy()
+    if nq == world * per:  # equal shards: the gathered rows are already in query order
+        out_ids, out_d = g[:, :k], g[:, k:].view(np.float32)
+        if copy or not on_gpu:
+            out_ids, out_d = out_ids.copy(), out_d.copy()
+        return out_ids, out_d
+    g = g.reshape(world, per, 2 * k)
     out_ids = np.empty((nq, k), dtype=np.int32)
     out_d = np.empty((nq, k), dtype=np.float32)
     for r in range(world):

@@ -47,6 +47,12 @@ def test_nccl_group_and_library_coexist():
         assert (ids2 == ids).all() and d2.tobytes() == d.tobytes()
         r_ids, r_d = hnswindex.net_amd.distributed.knn_query_sharded(ix.knn_query, q, 10)
         assert (r_ids == ids).all()
+        # the exchange path itself (pinned staging, cached device buffers, views of the pinned result),
+        # which a world of one would otherwise skip
+        for kw in (dict(), dict(dst_rank=0, copy=False)):
+            for _ in range(2):
+                e_ids, e_d = hnswindex.net_amd.distributed.knn_query_sharded(ix.knn_query, q, 10, _always_exchange=True, **kw)
+                assert (e_ids == ids).all() and np.ascontiguousarray(e_d).tobytes() == d.tobytes()
         ref = oracle.OracleIndex(64, collection_size=3000); ref.add_batched(x, 16384)
         assert (ref.knn_query(q, 10)[0] == ids).all()
     finally:
