@@ -442,7 +442,6 @@ __device__ __forceinline__ void measure_all(const float *rows, const double *row
 
 constexpr int kNewMax = 4;     // link kernel shortcut: new entries of an overflowing list measured against all others
 constexpr int kSpillCap = 8192; // candidate-heap entries per traversal that may spill to HBM
-constexpr int kNbufCap = 136; // upper bound of the id / distance scratch (2*M + 1 <= 128, set_graph)
 
 // LDS carve-up shared by the traversal kernels
 struct SearchLds {
