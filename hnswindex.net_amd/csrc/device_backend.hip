@@ -1479,8 +1479,10 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
                         double sbx = 0.0;
                         if (METRIC == M_COS) sbx = row_sn[xid];
                         __syncthreads();
-                        measure_all<METRIC>(rows, row_sn, dim, L.qs2, sbx, L.nbuf, Dm + jn * nbcap, n, lane);
-                        evals += (unsigned long long)(n - 1);
+                        // a single new entry only meets the old ones (one pass of <= 32 rows instead of two)
+                        const int mrows = u == 1 ? tested : n;
+                        measure_all<METRIC>(rows, row_sn, dim, L.qs2, sbx, L.nbuf, Dm + jn * nbcap, mrows, lane);
+                        evals += (unsigned long long)(u == 1 ? mrows : n - 1);
                     }
                     __syncthreads();
                     // greedy pass :23-40 in sorted order, on the distances at hand
