@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--max-edges", type=int, default=16)
     p.add_argument("--ef-construction", type=int, default=200)
     p.add_argument("--ef-search", type=int, default=128)
-    p.add_argument("--insert-batch", type=int, default=16384)
+    p.add_argument("--insert-batch", type=int, default=65536, help="cap of a snapshot batch (a batch is also <= linked/16)")
     p.add_argument("--slots", type=int, default=0, help="lock-step search slots (0 = library default)")
     p.add_argument("--threads", type=int, default=0, help="host threads of the driver (0 = library default)")
     p.add_argument("--recall-queries", type=int, default=1000)

@@ -24,7 +24,7 @@ struct Params {
     bool allow_removals = true;
     // backend
     int device = -1;         // -1: HNSW_MI355X_DEVICE or 0
-    int insert_batch = 16384; // 1 = strictly sequential inserts
+    int insert_batch = 65536; // cap of a snapshot batch (which is also <= linked/16); 1 = strictly sequential inserts
     int search_slots = 16384;
     int host_threads = 0;    // 0: min(hardware threads, 16)
     int device_traversal = 1; // 1: graph-resident search kernel; 0: host lock-step traversal

@@ -27,6 +27,7 @@ for seed, (M, efc, ef, k) in enumerate([(16, 200, 128, 10), (8, 100, 64, 5), (24
         q = rng.random((nq, dim), dtype=np.float32)
     ix = hnswindex.Index(dim)
     ix.set_collection_size(n); ix.set_max_edges(M); ix.set_max_candidates(efc); ix.set_min_nn(ef)
+    ix.set_insert_batch(16384)
     t = time.time(); ix.add(x); tb = time.time() - t
     ref = oracle.OracleIndex(dim, max_edges=M, max_candidates=efc, min_nn=ef, collection_size=n)
     t = time.time(); ref.add_batched(x, 16384); tr = time.time() - t
