@@ -120,6 +120,10 @@ public:
     bool link_batch_begin(int set, const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
                           const int *g_items, int ngroups, int max_edges0, int list_stride, bool want_lists = true);
     bool link_batch_finish(int set, const int **out_lists);
+    // Link half of the batch whose insert_search_batch just ran (its jobs and selections are still on
+    // the device): own lists, grouping of the back-edge appends and the appends / prunes, all on the
+    // device, nothing copied back.  Requires that no job of that batch was handed back.
+    bool link_batch_planned(int njobs, int n_upper, int max_edges0);
     // The adjacency mirror back to the host (adj0: n x stride0 ints, pool: pool_len ints).
     bool download_graph(int *adj0, long long n, int *pool, long long pool_len);
 
@@ -160,6 +164,12 @@ private:
     unsigned *s_visited_ = nullptr;
     size_t s_visited_bytes_ = 0;
     int *s_jobctr_ = nullptr; // persistent launches: next job
+    int *lp_slot_[3] = {nullptr, nullptr, nullptr}; // device-side link grouping: per list slot count / fill / offset
+    long long lp_slots_ = 0;
+    int *lp_grp_[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // per group node / layer / start / count; items as filed; items in batch order
+    size_t lp_grp_cap_[6] = {0, 0, 0, 0, 0, 0};
+    int *lp_counters_ = nullptr;
+    int last_insert_jobs_ = 0, last_insert_upper_ = 0, last_insert_stride_ = 0; // what insert_search_batch left on the device
     int *s_vislog_ = nullptr; // per-wave logs of visited ids (large graphs)
     size_t s_vislog_cap_ = 0;
     bool visited_log(size_t vis_bytes_per_job, int **out);

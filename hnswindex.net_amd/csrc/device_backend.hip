@@ -1403,23 +1403,21 @@ graph_write_rows_kernel(int *__restrict__ adj0, int stride0, const int64_t *__re
 // (neighbor.OutEdges[layer].Add(currNode.Id), GraphConnector.cs:207), each overflow pruned in
 // place (PruneOverflow :222-262: distances :230-234, sort + heuristic :235).  Lists are
 // independent, so the outcome equals the reference's sequential loop.
-template <int METRIC>
-__global__ void __launch_bounds__(64)
-graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, int *__restrict__ adj0,
+// next_item(): the next node id to append to this list, in item order, or -1.  out_list (optional):
+// [count, ids...] of the final list for the host.
+template <int METRIC, class NextItem>
+__device__ __forceinline__ void link_group(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, int *__restrict__ adj0,
                   int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
-                  const int *__restrict__ g_node, const int *__restrict__ g_layer, const int *__restrict__ g_off,
-                  const int *__restrict__ g_items, int max_edges0, int k_cap, int *__restrict__ out_lists, int list_stride,
-                  unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU)
+                  int node, int layer, NextItem next_item, int max_edges0, int k_cap, int *__restrict__ out_list,
+                  unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU,
+                  unsigned char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const SearchLds L = carve_lds(smem, k_cap, 0, dim, nbcap);
     // shortcut scratch behind the common carve-up: distances of up to kNewMax new entries to every
     // entry of the list, and the sorted order as original positions
     float *Dm = reinterpret_cast<float *>(smem + ((search_lds_bytes(k_cap, 0, dim, true, nbcap) + 15) & ~(size_t)15));
     int *perm = reinterpret_cast<int *>(Dm + kNewMax * nbcap);
     const int lane = threadIdx.x;
-    const int g = blockIdx.x;
-    const int node = g_node[g], layer = g_layer[g];
     const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1);
     int *l = layer == 0 ? adj0 + (size_t)node * stride0 : pool + upper[node] + (size_t)(layer - 1) * strideU;
     const float *q = rows + (size_t)node * dim;
@@ -1434,8 +1432,8 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
     unsigned long long evals = 0;
     PH_DECL();
     PH(0);
-    for (int t = g_off[g]; t < g_off[g + 1]; ++t) {
-        if (lane == 0) L.nbuf[cnt] = g_items[t]; // :207
+    for (int item = next_item(); item >= 0; item = next_item()) {
+        if (lane == 0) L.nbuf[cnt] = item; // :207
         cnt++;
         __syncthreads();
         PH_COUNT(6, 1);
@@ -1523,11 +1521,142 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
             __syncthreads();
         }
     }
-    if (lane == 0) { l[0] = cnt; *tested_p = tested; out_lists[(size_t)g * list_stride] = cnt; }
-    for (int i = lane; i < cnt; i += 64) { l[1 + i] = L.nbuf[i]; out_lists[(size_t)g * list_stride + 1 + i] = L.nbuf[i]; }
+    if (lane == 0) { l[0] = cnt; *tested_p = tested; if (out_list) out_list[0] = cnt; }
+    for (int i = lane; i < cnt; i += 64) { l[1 + i] = L.nbuf[i]; if (out_list) out_list[1 + i] = L.nbuf[i]; }
     if (lane == 0) atomicAdd(eval_counter, evals);
+    __syncthreads();
 }
 
+// groups prepared by the host: one block per group, items in CSR order
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, int *__restrict__ adj0,
+                  int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
+                  const int *__restrict__ g_node, const int *__restrict__ g_layer, const int *__restrict__ g_off,
+                  const int *__restrict__ g_count, const int *__restrict__ g_items, int max_edges0, int k_cap,
+                  int *__restrict__ out_lists, int list_stride,
+                  unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int g = blockIdx.x;
+    int t = g_off[g];
+    const int t_end = g_count ? t + g_count[g] : g_off[g + 1]; // CSR offsets, or start + count per group
+    link_group<METRIC>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, g_node[g], g_layer[g],
+                       [&]() { return t < t_end ? g_items[t++] : -1; }, max_edges0, k_cap,
+                       out_lists ? out_lists + (size_t)g * list_stride : (int *)nullptr, eval_counter, nbcap, tested0, testedU, smem);
+}
+
+// ---- the same with the grouping done on the device (no host work between the insert search and
+// the link half).  Per adjacency-list slot (layer 0: the node id; upper layers: cap_n + list index
+// in the pool) three counters, all zero between batches: appends, fill cursor, start offset. ----
+struct LinkPlan {
+    int *cnt, *fill, *off;                      // per list slot
+    int *g_node, *g_layer, *g_start, *g_count;  // per group (a list that receives appends), any order
+    int *items;                                 // batch positions of the appending items, grouped
+    int *counters;                              // [0] groups, [1] item cursor, [3] first guard that fired
+    long long cap_n;
+    long long n_slots, n_nodes; // capacities, for the guards below: an index outside them is reported, never used
+    int g_cap, n_jobs;
+};
+#define LINK_GUARD(cond, code) if (!(cond)) { atomicCAS(&P.counters[3], 0, (code)); continue; }
+__device__ __forceinline__ long long link_slot(const LinkPlan &P, const int64_t *upper, int strideU, int nb, int layer)
+{
+    return layer == 0 ? (long long)nb : P.cap_n + upper[nb] / strideU + (layer - 1);
+}
+// pass 1 (count = true): the new nodes' own lists go into the mirror (currNode.OutEdges[layer] =
+// selected, GraphConnector.cs:192), appends are counted per target list and the lists that receive
+// any are enumerated.  pass 2 (count = false): the appends are filed per list.
+template <bool COUNT>
+__global__ void __launch_bounds__(64)
+link_plan_kernel(const SearchJob *__restrict__ jobs, const int *__restrict__ sel0, const int *__restrict__ cnt0,
+                 const int *__restrict__ selU, const int *__restrict__ cntU, int sel_stride, int *__restrict__ adj0, int stride0,
+                 const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU, int *__restrict__ tested0,
+                 int *__restrict__ testedU, int max_edges0, LinkPlan P)
+{
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const SearchJob jb = jobs[t];
+    const int id = ~jb.qref;
+    for (int layer = jb.search_layer; layer >= 0; --layer) {
+        const int *sel = layer == 0 ? sel0 + (size_t)t * sel_stride : selU + (size_t)(jb.aux + layer - 1) * sel_stride;
+        const int sc = layer == 0 ? cnt0[t] : cntU[jb.aux + layer - 1];
+        LINK_GUARD(id >= 0 && id < P.n_nodes && sc >= 0 && sc <= sel_stride && sc <= (layer == 0 ? max_edges0 : (max_edges0 >> 1)), 1);
+        if (COUNT) {
+            int *l = layer == 0 ? adj0 + (size_t)id * stride0 : pool + upper[id] + (size_t)(layer - 1) * strideU;
+            if (lane == 0) {
+                l[0] = sc;
+                const int me = layer == 0 ? max_edges0 : (max_edges0 >> 1);
+                int *tp = layer == 0 ? tested0 + id : testedU + (upper[id] / strideU + (layer - 1));
+                *tp = sc == me ? sc : 0; // see graph_write_rows_kernel
+            }
+            for (int e = lane; e < sc; e += 64) l[1 + e] = sel[e];
+        }
+        for (int e = lane; e < sc; e += 64) {
+            const int nb = sel[e];
+            LINK_GUARD(nb >= 0 && nb < P.n_nodes, 2);
+            const long long slot = link_slot(P, upper, strideU, nb, layer);
+            LINK_GUARD(slot >= 0 && slot < P.n_slots, 3);
+            if (COUNT) {
+                if (atomicAdd(&P.cnt[slot], 1) == 0) {
+                    const int g = atomicAdd(&P.counters[0], 1);
+                    LINK_GUARD(g < P.g_cap, 4);
+                    P.g_node[g] = nb;
+                    P.g_layer[g] = layer;
+                }
+            } else {
+                const int p = atomicAdd(&P.fill[slot], 1);
+                const long long at = (long long)P.off[slot] + p;
+                LINK_GUARD(at >= 0 && at < P.g_cap, 5);
+                P.items[at] = t;
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+link_offsets_kernel(const int64_t *__restrict__ upper, int strideU, LinkPlan P)
+{
+    const int G = min(P.counters[0], P.g_cap);
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < G; g += gridDim.x * 256) {
+        const long long slot = link_slot(P, upper, strideU, P.g_node[g], P.g_layer[g]);
+        LINK_GUARD(slot >= 0 && slot < P.n_slots, 6);
+        const int c = P.cnt[slot];
+        const int start = atomicAdd(&P.counters[1], c);
+        LINK_GUARD(c >= 0 && start >= 0 && (long long)start + c <= P.g_cap, 7);
+        P.g_start[g] = start;
+        P.g_count[g] = c;
+        P.off[slot] = start;
+    }
+}
+// one block per group: its items (batch positions, filed in arbitrary order) become node ids in batch
+// order -- repeatedly the smallest position not yet taken; groups are tiny -- and the slot's
+// counters return to zero for the next batch
+__global__ void __launch_bounds__(64)
+link_order_kernel(const SearchJob *__restrict__ jobs, const int64_t *__restrict__ upper, int strideU, int *__restrict__ items_out, LinkPlan P)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int node = P.g_node[g], layer = P.g_layer[g], start = P.g_start[g], n_items = P.g_count[g];
+    if (!(node >= 0 && node < P.n_nodes && layer >= 0 && start >= 0 && n_items >= 0 && (long long)start + n_items <= P.g_cap)) {
+        atomicCAS(&P.counters[3], 0, 8);
+        return;
+    }
+    int last = -1;
+    for (int k = 0; k < n_items; ++k) {
+        int best = 0x7fffffff;
+        for (int i = lane; i < n_items; i += 64) {
+            const int p = P.items[start + i];
+            if (p > last && p < best) best = p;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+        if (best >= P.n_jobs) { atomicCAS(&P.counters[3], 0, 9); return; }
+        last = best;
+        if (lane == 0) items_out[start + k] = ~jobs[best].qref;
+    }
+    if (lane == 0) {
+        const long long slot = link_slot(P, upper, strideU, node, layer);
+        P.cnt[slot] = 0;
+        P.fill[slot] = 0;
+    }
+}
 
 // Flat id<->id pairs: 8 lanes per pair (hnswdev_dist_pair_batch).
 template <int METRIC>
@@ -1647,7 +1776,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vislog_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vislog_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -2114,6 +2243,9 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         if (h_flag[i] == 2) { stats_.search_repeats++; h_flag[i] = 0; }
         stats_.search_overflows += (uint64_t)(h_flag[i] != 0);
     }
+    last_insert_jobs_ = njobs <= chunk ? njobs : 0; // a single launch left everything in place
+    last_insert_upper_ = n_upper;
+    last_insert_stride_ = sel_stride;
     *res = InsertResults{h_sel0, h_cnt0, h_selU, h_cntU, h_flag, sel_stride};
     return true;
 }
@@ -2241,7 +2373,7 @@ bool Device::link_batch_begin(int set, const int *rows, int nrows, int row_strid
         const size_t lds = ((search_lds_bytes(k_cap, 0, dim_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
 #define LAUNCH(M)                                                                                                          \
     hipLaunchKernelGGL(graph_link_kernel<M>, dim3(ngroups), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_,  \
-                       g_upper_, g_pool_, g_strideU_, s_lk_[1], s_lk_[1] + ngroups, s_lk_[2], s_lk_[3], max_edges0, k_cap,    \
+                       g_upper_, g_pool_, g_strideU_, s_lk_[1], s_lk_[1] + ngroups, s_lk_[2], (const int *)nullptr, s_lk_[3], max_edges0, k_cap, \
                        s_lk_[4], list_stride, s_evals_, nbcap(), g_tested0_, g_testedU_)
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
@@ -2254,6 +2386,97 @@ bool Device::link_batch_begin(int set, const int *rows, int nrows, int row_strid
     }
     HIP_OK(hipEventRecord((hipEvent_t)ls.ev_done, st));
     ls.busy = true;
+    return true;
+}
+
+bool Device::link_batch_planned(int njobs, int n_upper, int max_edges0)
+{
+    if (njobs <= 0) return true;
+    if (njobs != last_insert_jobs_ || n_upper != last_insert_upper_ || max_edges0 != last_insert_stride_ || max_edges0 + 1 > nbcap()) {
+        set_dev_error("link_batch_planned: no matching insert_search_batch results on the device");
+        return false;
+    }
+    last_insert_jobs_ = 0;
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    if (!ensure_search_scratch(1, 1, 0, 16)) return false;
+    // per-slot counters: all zero between batches (the link kernel resets what it used)
+    const long long slots = g_cap_n_ + g_pool_cap_ / std::max(1, g_strideU_) + 2;
+    if (slots != lp_slots_) {
+        HIP_OK(hipStreamSynchronize(st));
+        for (int i = 0; i < 3; ++i) {
+            if (lp_slot_[i]) HIP_OK(hipFree(lp_slot_[i]));
+            lp_slot_[i] = nullptr;
+            HIP_OK(hipMalloc(&lp_slot_[i], sizeof(int) * (size_t)slots));
+            HIP_OK(hipMemsetAsync(lp_slot_[i], 0, sizeof(int) * (size_t)slots, st));
+        }
+        lp_slots_ = slots;
+    }
+    const size_t max_appends = (size_t)(njobs + n_upper) * (size_t)max_edges0 + 1;
+    for (int i = 0; i < 6; ++i) {
+        if (max_appends > lp_grp_cap_[i]) {
+            HIP_OK(hipStreamSynchronize(st));
+            if (!grow_dev(&lp_grp_[i], &lp_grp_cap_[i], max_appends * 2)) return false;
+        }
+    }
+    if (!lp_counters_) HIP_OK(hipMalloc(&lp_counters_, sizeof(int) * 4));
+    HIP_OK(hipMemsetAsync(lp_counters_, 0, sizeof(int) * 4, st));
+    HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
+    size_t g_cap = lp_grp_cap_[0];
+    for (int i = 1; i < 6; ++i) g_cap = std::min(g_cap, lp_grp_cap_[i]);
+    LinkPlan P{lp_slot_[0], lp_slot_[1], lp_slot_[2], lp_grp_[0], lp_grp_[1], lp_grp_[2], lp_grp_[3], lp_grp_[4], lp_counters_, g_cap_n_,
+               slots, g_n_, (int)std::min<size_t>(g_cap, 0x7fffffff), njobs};
+    const bool timed = profiling_;
+    if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
+    hipLaunchKernelGGL(link_plan_kernel<true>, dim3(njobs), dim3(64), 0, st, s_jobs_, s_sel_, s_lcnt_, s_selU_, s_cntU_, last_insert_stride_,
+                       g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, g_tested0_, g_testedU_, max_edges0, P);
+    hipLaunchKernelGGL(link_offsets_kernel, dim3(512), dim3(256), 0, st, g_upper_, g_strideU_, P);
+    hipLaunchKernelGGL(link_plan_kernel<false>, dim3(njobs), dim3(64), 0, st, s_jobs_, s_sel_, s_lcnt_, s_selU_, s_cntU_, last_insert_stride_,
+                       g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, g_tested0_, g_testedU_, max_edges0, P);
+    HIP_OK(hipGetLastError());
+    // the number of groups comes back to size the last two launches (16 bytes, one short wait)
+    unsigned long long *h_ev = static_cast<unsigned long long *>(pinned_stage(32));
+    if (!h_ev) return false;
+    int *h_ctr = reinterpret_cast<int *>(h_ev + 1);
+    HIP_OK(hipMemcpyAsync(h_ctr, lp_counters_, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    const int G = h_ctr[0];
+    if (h_ctr[3] != 0 || G < 0 || (size_t)G > g_cap) {
+        set_dev_error("link_batch_planned: inconsistent selection data on the device (guard " + std::to_string(h_ctr[3]) + ")");
+        return false;
+    }
+    if (G > 0) {
+        hipLaunchKernelGGL(link_order_kernel, dim3(G), dim3(64), 0, st, s_jobs_, g_upper_, g_strideU_, lp_grp_[5], P);
+        HIP_OK(hipGetLastError());
+            const int k_cap = nbcap();
+        const size_t lds = ((search_lds_bytes(k_cap, 0, dim_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
+#define LAUNCH(M)                                                                                                          \
+    hipLaunchKernelGGL(graph_link_kernel<M>, dim3(G), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_,       \
+                       g_upper_, g_pool_, g_strideU_, lp_grp_[0], lp_grp_[1], lp_grp_[2], lp_grp_[3], lp_grp_[5], max_edges0, k_cap, \
+                       (int *)nullptr, 0, s_evals_, nbcap(), g_tested0_, g_testedU_)
+        if (metric_ == M_SQ) LAUNCH(M_SQ);
+        else if (metric_ == M_COS) LAUNCH(M_COS);
+        else LAUNCH(M_UCOS);
+#undef LAUNCH
+        HIP_OK(hipGetLastError());
+    }
+    if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
+    HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_ctr, lp_counters_, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (h_ctr[3] != 0) {
+        set_dev_error("link_batch_planned: inconsistent selection data on the device (guard " + std::to_string(h_ctr[3]) + ")");
+        return false;
+    }
+    stats_.search_launches++;
+    stats_.search_evals += *h_ev;
+    if (timed) {
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
+        stats_.search_kernel_ms += ms;
+        stats_.search_timed_launches++;
+        stats_.search_timed_evals += *h_ev;
+    }
     return true;
 }
 

@@ -721,6 +721,7 @@ bool HnswIndex::search_half_device(const std::vector<int> &bid, Selection &sel, 
         if (l0 > 0) { sel.upper_base[(size_t)i] = n_upper; n_upper += l0; }
         jobs[(size_t)i] = SearchJob{~id, ep, top, l0, sel.upper_base[(size_t)i]}; // FindEntryPoint from the top (:174)
     }
+    sel.n_upper = n_upper;
     if (!dev_->insert_search_batch(jobs.data(), n, p_.max_candidates, 2 * p_.max_edges, n_upper, &sel.dev)) { err = get_dev_error(); return false; }
     std::vector<int> again;
     for (int i = 0; i < n; ++i) if (sel.dev.flag[i]) again.push_back(i);
@@ -793,7 +794,22 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
     const int n = (int)bid.size();
     const int M2 = 2 * p_.max_edges, row_stride = 3 + M2, list_stride = graph_.stride0;
     const int top = graph_.top_layer();
-    // The batch is linked in up to four sub-batches of consecutive items.  Appending the items of one
+    // Everything the link half needs is already on the device when no item was handed back to the
+    // host: own lists, grouping of the appends and the appends themselves run there, the host does
+    // nothing in between (HNSW_MI355X_LINK_PLAN=0 keeps the host-grouped path below, which is also
+    // the one used after a hand-back).
+    const char *plan_env = std::getenv("HNSW_MI355X_LINK_PLAN");
+    const bool plan_on_device = !plan_env || std::atoi(plan_env) != 0;
+    bool any_own = false;
+    for (int i = 0; i < n; ++i) any_own = any_own || sel.has_own[(size_t)i];
+    if (plan_on_device && !any_own) {
+        Tick t(g_pt.link_dev);
+        g_pt.rounds++;
+        host_lists_stale_ = true;
+        if (!dev_->link_batch_planned(n, sel.n_upper, M2)) { err = get_dev_error(); return false; }
+        return true;
+    }
+    // Host-grouped path: the batch is linked in up to four sub-batches of consecutive items.  Appending the items of one
     // adjacency list sub-batch after sub-batch is the same sequence as appending them all in item
     // order, so the outcome is unchanged -- but while the GPU links one sub-batch the host groups
     // the next and files the previous one's lists.

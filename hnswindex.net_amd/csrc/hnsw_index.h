@@ -76,7 +76,7 @@ private:
     // context's pinned buffers (layer 0: slot = item; layer L >= 1: slot upper_base[item] + L - 1);
     // items processed on the host (lock-step mode, hand-backs) carry their own lists.
     struct Selection {
-        int n = 0;
+        int n = 0, n_upper = 0;
         Device::InsertResults dev{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         std::vector<int> upper_base;
         std::vector<char> has_own;

@@ -159,10 +159,13 @@ def test_visited_id_log_clearing(Index, monkeypatch, sorted_top, log_cap):
     assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
 
 
-def test_large_batches_link_in_pipelined_sub_batches(Index):
-    # snapshot batches of >= 2048 items are linked in four sub-batches (host grouping overlapped with
-    # the link kernel); the result must equal linking the whole batch in item order
+@pytest.mark.parametrize("plan_on_device", ["1", "0"])
+def test_large_batches_link_half(Index, monkeypatch, plan_on_device):
+    # the link half of a batch: grouped on the device (default), or grouped by the host in four
+    # pipelined sub-batches (batches >= 2048 items; also the path after a hand-back).  Either must
+    # equal linking the whole batch in item order.
     from common import uniform
+    monkeypatch.setenv("HNSW_MI355X_LINK_PLAN", plan_on_device)
     x = uniform(60_000, 16, 501)
     ref = oracle.OracleIndex(16, max_edges=8, max_candidates=40, min_nn=10, collection_size=60_000)
     ref.add_batched(x, 16384)
