@@ -714,7 +714,8 @@ struct SortedTop {
 template <int METRIC, int NS>
 __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                                 const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet &V,
-                                                const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals)
+                                                const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals,
+                                                bool overlap)
 {
     int *nbuf = L.nbuf;
     float *dbuf = L.dbuf;
@@ -764,6 +765,52 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         int m = 0;
         __syncthreads();
         PH(2);
+        // candidate distances and ids of this expansion, one per lane, in adjacency order
+        bool have = false;     // this lane holds an unvisited neighbour
+        float lane_d = 0.0f;
+        int lane_id = 0;
+        const bool overlapped = overlap && n <= 64;
+        if (overlapped) {
+            // Latency-bound launch (fewer jobs than resident waves): the rows of ALL listed neighbours
+            // are fetched together with the visited atomics instead of after them -- one dependent
+            // round trip less per expansion; rows of neighbours that turn out visited are wasted
+            // bandwidth, of which such a launch has plenty.  Evaluations counted: the unvisited ones.
+            const bool in = lane < n;
+            if (in) nbuf[lane] = nb_a;
+            __syncthreads();
+            unsigned old = 0u;
+            const unsigned bit = 1u << (nb_a & 31);
+            if (in) old = atomicOr(&V.bits[nb_a >> 5], bit); // :181, in flight with the row loads below
+            pre_id = -1;
+            {
+                const int nxt = T.first_open(top_n, lane);
+                if (nxt >= 0) {
+                    const HEnt e = T.at(nxt);
+                    if (e.key == c.key) tie = true; // (ii)
+                    pre_id = e.id & kIdMask;
+                    const int *pl = G.list(pre_id, layer);
+                    pre_a = lane < lstride ? pl[lane] : 0;
+                    pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
+                }
+            }
+            if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
+            __syncthreads();
+            have = in && (old & bit) == 0u;
+            const unsigned long long mask = __ballot(have);
+            m = __popcll(mask);
+            lane_d = in ? dbuf[lane] : 0.0f;
+            lane_id = nb_a;
+            if (V.log != nullptr) { // the ids this expansion set, compacted, for the log
+                const int posn = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                __syncthreads();
+                if (have) nbuf[posn] = nb_a;
+                __syncthreads();
+                V.note(nbuf, m, lane);
+            }
+            PH(4);
+            if (m == 0) continue;
+            evals += (unsigned long long)m;
+        } else {
         for (int base = 0; base < n; base += 64) { // :158-161 keep only unvisited, in list order
             const int i = base + lane;
             bool fresh = false;
@@ -798,15 +845,18 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         __syncthreads();
         PH(4);
         evals += (unsigned long long)m;
+        }
         // the push loop (:165-178) in adjacency order; farthest never grows once the list is full,
         // so only the lanes passing the test now can pass it later: they are replayed one by one
-        for (int base = 0; base < m && !unsafe; base += 64) {
-            const int i = base + lane;
-            const float my_d = (i < m) ? dbuf[i] : 0.0f;
-            const int my_id = (i < m) ? nbuf[i] : 0;
+        const int rounds = overlapped ? 1 : (m + 63) / 64;
+        for (int r = 0; r < rounds && !unsafe; ++r) {
+            const int i = r * 64 + lane;
+            const bool valid = overlapped ? have : i < m;
+            const float my_d = overlapped ? lane_d : (i < m ? dbuf[i] : 0.0f);
+            const int my_id = overlapped ? lane_id : (i < m ? nbuf[i] : 0);
             const unsigned my_key = f2key(my_d);
-            if (__ballot(i < m && key_unsafe(my_d))) { unsafe = true; break; }
-            unsigned long long maybe = __ballot(i < m && (top_n < k || my_key < far_key));
+            if (__ballot(valid && key_unsafe(my_d))) { unsafe = true; break; }
+            unsigned long long maybe = __ballot(valid && (top_n < k || my_key < far_key));
             while (maybe) {
                 const int src = __builtin_ctzll(maybe);
                 maybe &= maybe - 1;
@@ -1167,7 +1217,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
                     const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
                     int spill_cap, VisitedSet &V, int k_out, int *__restrict__ out_ids,
                     float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
-                    unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job)
+                    unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, bool overlap)
 {
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
@@ -1190,7 +1240,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
     if constexpr (NS > 0) {
         bool tie = false;
         // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
-        const bool ok1 = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals);
+        const bool ok1 = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap);
         if (!(ok1 && tie)) {
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
             // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
@@ -1267,7 +1317,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
                     const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
                     int spill_cap, unsigned *__restrict__ visited, long long vis_words, int *__restrict__ vis_log, int vis_log_cap, int k_out,
                     int *__restrict__ out_ids, float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
-                    unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter)
+                    unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -1280,7 +1330,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
         job = __builtin_amdgcn_readfirstlane(job);
         if (job >= njobs) break;
         search_job<METRIC, NS>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
-                               V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job);
+                               V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job, overlap != 0);
         V.clear(lane);
     }
 }
@@ -1299,7 +1349,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, VisitedSet &V,
                            int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
-                           unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job)
+                           unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, bool overlap)
 {
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
@@ -1321,7 +1371,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         if constexpr (NS > 0) {
             bool tie = false;
             const unsigned long long ev0 = evals;
-            ok = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals); // Span.Sort consumes all
+            ok = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap); // Span.Sort consumes all
             if (!ok) break;
             // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
             // then returns them in HEAP order, Heuristic.cs:13-18): this layer again, exact traversal
@@ -1361,7 +1411,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
                            int *__restrict__ vis_log, int vis_log_cap, int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
-                           unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter)
+                           unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -1374,7 +1424,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         job = __builtin_amdgcn_readfirstlane(job);
         if (job >= njobs) break;
         insert_job<METRIC, NS>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
-                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job);
+                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap != 0);
         V.clear(lane);
     }
 }
@@ -2087,6 +2137,14 @@ static bool grow_dev(T **p, size_t *cap, size_t need)
 // chunk: jobs per launch (job / result buffers); slots: waves of a persistent launch (visited
 // bitsets, spill areas).  The visited arena is all zero between launches: zeroed when allocated,
 // and every wave clears its bitset after each job.
+// Row loads overlapped with the visited atomics in launches that do not fill the chip
+// (HNSW_MI355X_OVERLAP=0 disables, =2 forces it for every launch: tests).
+static int overlap_mode()
+{
+    const char *e = std::getenv("HNSW_MI355X_OVERLAP");
+    return e ? std::atoi(e) : 1;
+}
+
 static int vis_log_cap_for_tests()
 {
     if (const char *e = std::getenv("HNSW_MI355X_VIS_LOG_CAP")) return std::max(1, std::min(kVisLogCap, std::atoi(e)));
@@ -2196,12 +2254,14 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
 #define LAUNCH2(M, NS_, GRID, LDS, CAP) \
-    hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_>), \
-                       dim3(std::min<int>(GRID, std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_>, LDS, num_cu_)))), \
+    do { \
+        const int slots_ = std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_>, LDS, num_cu_)); \
+        hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_>), dim3(std::min<int>(GRID, slots_)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_log, vis_log_cap_for_tests(), s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
-                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_)
+                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0); \
+    } while (0)
 #define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
     do {                                                                                                                   \
         if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, CAP);                                                      \
@@ -2569,11 +2629,13 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
 #define LAUNCH2(M, NS_, GRID, LDS, CAP) \
-    hipLaunchKernelGGL((graph_search_kernel<M, NS_>), \
-                       dim3(std::min<int>(GRID, std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_>, LDS, num_cu_)))), \
+    do { \
+        const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_>, LDS, num_cu_)); \
+        hipLaunchKernelGGL((graph_search_kernel<M, NS_>), dim3(std::min<int>(GRID, slots_)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_log, vis_log_cap_for_tests(), k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_)
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_log, vis_log_cap_for_tests(), k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0); \
+    } while (0)
 #define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
     do {                                                                                                                   \
         if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, CAP);                                                      \

@@ -196,3 +196,24 @@ def test_nan_and_negative_zero_distances_are_handed_back(Index):
         nan = np.isnan(want[1])
         assert (np.isnan(got[1]) == nan).all() and got[1][~nan].tobytes() == want[1][~nan].tobytes(), metric
         assert ix.stats()["search_overflows"] > 0
+
+
+@pytest.mark.parametrize("overlap", ["2", "0"])
+def test_row_loads_overlapped_with_visited_atomics(Index, monkeypatch, overlap):
+    # launches that do not fill the chip fetch the rows of all listed neighbours together with the
+    # visited atomics (2 forces that for every launch, 0 forbids it): same results either way
+    from common import uniform
+    monkeypatch.setenv("HNSW_MI355X_OVERLAP", overlap)
+    monkeypatch.setenv("HNSW_MI355X_VIS_LOG", "1")
+    x, q = uniform(8000, 20, 601), uniform(20_000, 20, 602)
+    ref = oracle.OracleIndex(20, max_edges=10, max_candidates=60, min_nn=32, collection_size=8000)
+    ref.add_batched(x, 16384)
+    ix = _build(Index, x, 10, 60, 32, 16384)
+    assert ix.graph_hash() == ref.graph_hash()
+    got, want = ix.knn_query(q, 7), ref.knn_query(q, 7, threads=8)
+    assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
+    ix.set_profiling(True); ix.reset_stats()
+    ref.reset_n_eval()
+    ix.knn_query(q[:2000], 7); ref.knn_query(q[:2000], 7)
+    # evaluations are counted for the unvisited neighbours only, overlapped or not
+    assert abs(ix.stats()["search_evals"] - ref.n_eval) <= 2000 * (1 + ref.levels().max())
