@@ -2,6 +2,7 @@
 schedule, device traversal, device-grouped link half) against the oracle's batched restatement,
 hash for hash, plus a query batch.  Usage: python tools/parity_c2_half.py [n]"""
 import sys
+import threading
 import time
 
 import numpy as np
@@ -19,7 +20,19 @@ ix.set_collection_size(n); ix.set_max_edges(16); ix.set_max_candidates(200); ix.
 t = time.time(); ix.add(x); tg = time.time() - t
 print(f"gpu build {tg:.2f} s ({n / tg:.0f} adds/s)", flush=True)
 ref = oracle.OracleIndex(128, max_edges=16, max_candidates=200, min_nn=128, collection_size=n)
-t = time.time(); ref.add_batched(x, cap); tr = time.time() - t
+done = threading.Event()
+
+
+def heartbeat():  # the oracle call is silent for minutes; the GPU runner takes silence for a hang
+    while not done.wait(60):
+        print(f"  oracle building ... {time.time() - t:.0f} s", flush=True)
+
+
+t = time.time()
+threading.Thread(target=heartbeat, daemon=True).start()
+ref.add_batched(x, cap)
+done.set()
+tr = time.time() - t
 print(f"oracle build {tr:.1f} s ({n / tr:.0f} adds/s)", flush=True)
 same = ix.graph_hash() == ref.graph_hash()
 got, want = ix.knn_query(q, 10), ref.knn_query(q, 10, threads=16)
