@@ -18,10 +18,19 @@
 // written as __builtin_fmaf.
 //
 // Mapping to the wavefront: 8 lanes own the 8 partials of one candidate row, so a wave64
-// evaluates 8 candidates at a time; the collapse tree is three cross-lane adds.  One wave
-// serves one search slot (one expansion: <= 2M candidate rows against one query).  Wider
-// per-lane loads and lane-ring variants were measured no faster (tools/kbench.hip): with the
-// step inputs resident in HBM this mapping gathers random 512-B rows at 4.2-4.9 TB/s.
+// evaluates 8 candidates at a time (up to 4 rows per lane group in one memory round trip); the
+// collapse tree is three cross-lane adds.  Wider per-lane loads and lane-ring variants were
+// measured no faster (tools/kbench.hip): this mapping gathers random 512-B rows at 4.2-4.9 TB/s.
+//
+// Contents: (1) slot_distance_kernel / pair_distance_kernel -- batched distances for a host that
+// keeps the traversal (the hnswdev_dist_* entry points, the lock-step engine);  (2) the
+// graph-resident traversals -- traverse_sorted (one sorted list in registers; the default) and
+// traverse (the reference's two heaps in LDS; exact under equal distances), wrapped by the
+// persistent graph_search_kernel (KnnQuery) and graph_insert_search_kernel (Add, search half +
+// RelativeNeighborPruning);  (3) Add's link half -- link_plan / link_offsets / link_order
+// (grouping of the back-edge appends on the device) and graph_link_kernel (appends and
+// PruneOverflow with the tested-prefix shortcut);  (4) class Device: HBM matrix, graph mirror,
+// per-wave scratch, launches.  DESIGN.md section 3 has the reasoning and the measurements.
 
 #include <hip/hip_runtime.h>
 
@@ -202,9 +211,12 @@ slot_distance_kernel(const float *__restrict__ rows, const double *__restrict__ 
 // Graph-resident search: the whole traversal of one query on one wavefront.
 //
 // SearchLayer / SearchLayerQuery (GraphNavigator.cs:123-256) and FindEntryAtLayer (:51-82)
-// restated for a wave64: the two BinaryHeaps (BinaryHeap.cs:30-107) live in LDS and are
-// manipulated by wave-uniform scalar code with the reference's exact sift rules (so the heap
-// ARRAY, not just the heap SET, matches -- tie order decides ids); the visited set
+// restated for a wave64.  Two variants share everything but the search state: traverse_sorted
+// (further down) keeps one sorted list in registers and is what normally runs; the variant
+// below keeps the two BinaryHeaps (BinaryHeap.cs:30-107) in LDS, manipulated by wave-uniform
+// scalar code with the reference's exact sift rules (so the heap ARRAY, not just the heap SET,
+// matches -- tie order decides ids), and is what a wave falls back to when equal distances
+// make the heap layout observable; the visited set
 // (VisitedListPool.cs:10-67) is a private bitset in HBM; the out-edge lists come from the HBM
 // mirror of the host graph; candidate rows are measured 8 lanes per row exactly as in
 // slot_distance_kernel.  Unvisited neighbours keep their adjacency order (ballot + prefix
