@@ -802,7 +802,7 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
     const bool plan_on_device = !plan_env || std::atoi(plan_env) != 0;
     bool any_own = false;
     for (int i = 0; i < n; ++i) any_own = any_own || sel.has_own[(size_t)i];
-    if (plan_on_device && !any_own) {
+    if (plan_on_device && !any_own && n <= (1 << 20)) { // (a larger batch is searched in several launches: host path)
         Tick t(g_pt.link_dev);
         g_pt.rounds++;
         host_lists_stale_ = true;
