@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, nq, k, out_dir):
+def _worker(rank, world, port, nq, k, out_dir, dst_rank=None):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -37,9 +37,12 @@ def _worker(rank, world, port, nq, k, out_dir):
         calls.append(qs.shape[0])
         return ix.knn_query(qs, kk)
 
-    ids, d = hnswindex.net_amd.distributed.knn_query_sharded(search, q, k)
+    ids, d = hnswindex.net_amd.distributed.knn_query_sharded(search, q, k, dst_rank=dst_rank)
     full_ids, full_d = ix.knn_query(q, k)
-    ok = (ids == full_ids).all() and d.tobytes() == full_d.tobytes()
+    if dst_rank is not None and rank != dst_rank:
+        ok = ids is None and d is None  # the gathered result stays where it is on the other ranks
+    else:
+        ok = (ids == full_ids).all() and np.ascontiguousarray(d).tobytes() == full_d.tobytes()
     lo, hi = hnswindex.net_amd.distributed.shard_bounds(nq, world, rank)
     ok = ok and calls == ([hi - lo] if hi > lo else [])
     np.save(Path(out_dir) / f"ok_{rank}.npy", np.array([int(ok), hi - lo]))
@@ -47,7 +50,7 @@ def _worker(rank, world, port, nq, k, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nq", [101, 2, 1])
+@pytest.mark.parametrize("nq", [101, 100, 2, 1])
 def test_sharded_query_equals_single_rank(tmp_path, nq):
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
@@ -58,6 +61,15 @@ def test_sharded_query_equals_single_rank(tmp_path, nq):
         assert ok == 1
         sizes.append(int(m))
     assert sum(sizes) == nq and max(sizes) - min(sizes) <= 1
+
+
+def test_single_destination_rank(tmp_path):
+    # the all-gather leaves the result on every rank, rank 0 copies it out
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, 64, 5, str(tmp_path), 0), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(tmp_path / f"ok_{r}.npy")[0] == 1
 
 
 def test_shard_bounds_cover_without_overlap():
