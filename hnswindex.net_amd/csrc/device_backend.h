@@ -173,6 +173,10 @@ private:
     int *s_vislog_ = nullptr; // per-wave logs of visited ids (large graphs)
     size_t s_vislog_cap_ = 0;
     bool visited_log(size_t vis_bytes_per_job, int **out);
+    int *s_vistab_ = nullptr; // per-wave visited-id hash tables
+    size_t s_vistab_cap_ = 0;
+    int s_vistab_each_ = 0;
+    bool visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_cap);
     int num_cu_ = 256;
     // Persistent launches never use more than 16 one-wave blocks per CU (the traversal kernels need
     // >= 128 VGPRs): the per-wave scratch (visited bitsets, spill areas, logs) is sized for that.

@@ -217,3 +217,23 @@ def test_row_loads_overlapped_with_visited_atomics(Index, monkeypatch, overlap):
     ix.knn_query(q[:2000], 7); ref.knn_query(q[:2000], 7)
     # evaluations are counted for the unvisited neighbours only, overlapped or not
     assert abs(ix.stats()["search_evals"] - ref.n_eval) <= 2000 * (1 + ref.levels().max())
+
+
+@pytest.mark.parametrize("cap,expect_handback", [("16384", False), ("512", True)])
+@pytest.mark.parametrize("sorted_top", ["1", "0"])
+def test_visited_id_hash_table(Index, monkeypatch, sorted_top, cap, expect_handback):
+    # large graphs keep the visited ids of a traversal in a per-wave hash table instead of a bitset
+    # (forced here on a small graph); a table that fills up hands the job to the host traversal
+    from common import uniform
+    monkeypatch.setenv("HNSW_MI355X_VIS_HASH", "1")
+    monkeypatch.setenv("HNSW_MI355X_VIS_HASH_CAP", cap)
+    monkeypatch.setenv("HNSW_MI355X_SORTED_TOP", sorted_top)
+    x, q = uniform(6000, 24, 701), uniform(6000, 24, 702)
+    ref = oracle.OracleIndex(24, max_edges=8, max_candidates=50, min_nn=96, collection_size=6000)
+    ref.add_batched(x, 16384)
+    ix = _build(Index, x, 8, 50, 96, 16384)
+    assert ix.graph_hash() == ref.graph_hash()
+    ix.reset_stats()
+    got, want = ix.knn_query(q, 5), ref.knn_query(q, 5, threads=8)
+    assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
+    assert (ix.stats()["search_overflows"] > 0) == expect_handback
