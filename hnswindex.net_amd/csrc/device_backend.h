@@ -170,9 +170,6 @@ private:
     size_t lp_grp_cap_[6] = {0, 0, 0, 0, 0, 0};
     int *lp_counters_ = nullptr;
     int last_insert_jobs_ = 0, last_insert_upper_ = 0, last_insert_stride_ = 0; // what insert_search_batch left on the device
-    int *s_vislog_ = nullptr; // per-wave logs of visited ids (large graphs)
-    size_t s_vislog_cap_ = 0;
-    bool visited_log(size_t vis_bytes_per_job, int **out);
     int *s_vistab_ = nullptr; // per-wave visited-id hash tables
     size_t s_vistab_cap_ = 0;
     int s_vistab_each_ = 0;

@@ -503,27 +503,25 @@ struct GraphView {
     }
 };
 
-// A wave's visited set (VisitedListPool.cs:10-67 restated for one in-flight traversal): a bitset
-// over node ids in HBM, all zero between jobs.  Clearing streams over the whole bitset; for large
-// graphs (bitset > 512 KB, i.e. > 4M nodes) the ids that were set are logged instead and only their
-// words are cleared -- at 10M nodes the 1.25-MB stream per traversal cost as much as the row reads.
+// A wave's visited set (VisitedListPool.cs:10-67 restated for one in-flight traversal), empty
+// between jobs.  Up to 4M nodes: a bitset over node ids in HBM, cleared by streaming over it.
+// Above: an open-addressing hash table of the visited ids (tab != nullptr, entries -1 when empty),
+// 64 KB per wave whatever the graph size -- at 10M nodes the bitsets of all resident waves span
+// gigabytes, and streaming a 1.25-MB clear per traversal cost as much as the row reads (measured:
+// 0.98 M queries/s streaming, 1.28 M clearing through a log of the ids, 1.48 M with the table; at 1M
+// nodes the bitset wins, 2.5 M against 1.9 M).  `seen` counts insertions; beyond `limit` the
+// traversal is handed back to the host, so the table never fills.
+template <bool HASHED> // compile-time choice: the bitset kernels carry none of the table's code or registers
 struct VisitedSet {
     unsigned *bits;
     long long words; // multiple of 4; the arena is 16-byte aligned
-    int *log;        // nullptr: no log
-    int log_cap;
-    int n;           // logged ids, or -1 once the log overflowed (then clear() streams)
-    // Alternative representation: an open-addressing hash set of the visited ids (tab != nullptr),
-    // all entries -1 between jobs.  64 KB per wave whatever the graph size, so the working set of
-    // all resident waves fits the last-level cache instead of spreading atomics over gigabytes of
-    // bitsets.  `seen` counts insertions; beyond `limit` the traversal is handed back (never full).
     int *tab;
     unsigned tab_mask;
     int seen, limit;
     // true: id was not in the set (and now is).  Per lane; lists hold no duplicates.
     __device__ __forceinline__ bool first_visit(int id)
     {
-        if (tab == nullptr) {
+        if constexpr (!HASHED) {
             const unsigned bit = 1u << (id & 31);
             return (atomicOr(&bits[id >> 5], bit) & bit) == 0u;
         }
@@ -535,37 +533,20 @@ struct VisitedSet {
             h = (h + 1) & tab_mask;
         }
     }
-    __device__ __forceinline__ bool crowded() const { return tab != nullptr && seen > limit; }
-    __device__ __forceinline__ void note(const int *ids, int m, int lane) // ids: wave-visible array (LDS)
-    {
-        if (log == nullptr || n < 0) return;
-        if (n + m > log_cap) { n = -1; return; }
-        for (int i = lane; i < m; i += 64) log[n + i] = ids[i];
-        n += m;
-    }
-    __device__ __forceinline__ void note_one(int id, int lane)
-    {
-        if (log == nullptr || n < 0) return;
-        if (n + 1 > log_cap) { n = -1; return; }
-        if (lane == 0) log[n] = id;
-        n += 1;
-    }
+    __device__ __forceinline__ bool crowded() const { return HASHED && seen > limit; }
     __device__ __forceinline__ void clear(int lane)
     {
         __syncthreads();
-        if (tab != nullptr) {
+        if constexpr (HASHED) {
             uint4 *t4 = reinterpret_cast<uint4 *>(tab);
             const uint4 e = make_uint4(~0u, ~0u, ~0u, ~0u);
             for (unsigned w = lane; w < ((tab_mask + 1u) >> 2); w += 64) t4[w] = e;
-            seen = 0;
-        } else if (log != nullptr && n >= 0) {
-            for (int i = lane; i < n; i += 64) bits[log[i] >> 5] = 0u;
         } else {
             uint4 *v4 = reinterpret_cast<uint4 *>(bits);
             const uint4 z = make_uint4(0u, 0u, 0u, 0u);
             for (long long w = lane; w < (words >> 2); w += 64) v4[w] = z;
         }
-        n = 0;
+        seen = 0;
         __syncthreads();
     }
 };
@@ -751,9 +732,9 @@ struct SortedTop {
 
 // Returns false on a NaN / -0 distance (exact host re-run); `tie` asks for the exact two-heap
 // traversal.  Result: L.top[0..top_n) ascending by distance.  The query must be staged in L.qs.
-template <int METRIC, int NS>
+template <int METRIC, int NS, bool HASHED>
 __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
-                                                const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet &V,
+                                                const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet<HASHED> &V,
                                                 const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals,
                                                 bool overlap)
 {
@@ -774,7 +755,6 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     bool tie = false, hash_full = false;
     T.insert(f2key(cur), best, top_n, k, lane);                      // :134, :138
     if (lane == 0) (void)V.first_visit(best);                           // :140
-    V.note_one(best, lane);
     V.seen += 1;
     unsigned far_key = f2key(cur);                                   // farthestResultDist :135
     int pre_id = -1, pre_a = 0, pre_b = 0; // speculative prefetch of the next expansion's list (see traverse)
@@ -810,7 +790,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         bool have = false;     // this lane holds an unvisited neighbour
         float lane_d = 0.0f;
         int lane_id = 0;
-        const bool overlapped = overlap && n <= 64 && V.tab == nullptr;
+        const bool overlapped = overlap && n <= 64 && !HASHED;
         if (overlapped) {
             // Latency-bound launch (fewer jobs than resident waves): the rows of ALL listed neighbours
             // are fetched together with the visited atomics instead of after them -- one dependent
@@ -841,13 +821,6 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             m = __popcll(mask);
             lane_d = in ? dbuf[lane] : 0.0f;
             lane_id = nb_a;
-            if (V.log != nullptr) { // the ids this expansion set, compacted, for the log
-                const int posn = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                __syncthreads();
-                if (have) nbuf[posn] = nb_a;
-                __syncthreads();
-                V.note(nbuf, m, lane);
-            }
             PH(4);
             if (m == 0) continue;
             evals += (unsigned long long)m;
@@ -877,7 +850,6 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         }
         __syncthreads();
         if (m == 0) continue;
-        V.note(nbuf, m, lane);
         V.seen += m;
         if (V.crowded()) { hash_full = true; break; } // the id table is filling up: host traversal
         measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
@@ -932,10 +904,10 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
 
 // Descent + beam search of one job; result = L.top[0..top_n) in heap order.  Returns false on
 // candidate-heap overflow.  The query must already be staged in L.qs.
-template <int METRIC>
+template <int METRIC, bool HASHED>
 __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                          const GraphView &G, const SearchJob jb, int k, int cand_cap, ND *spill, int spill_cap,
-                                         VisitedSet &V, const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals)
+                                         VisitedSet<HASHED> &V, const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals)
 {
     const LdsHeap top{L.top};
     const SpillHeap cand{L.cand, cand_cap, spill};
@@ -983,8 +955,7 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
         heap_push<false>(top, top_n, e); // :134
         heap_push<true>(cand, cand_n, e); // :138
         if (lane == 0) (void)V.first_visit(best);                       // :140
-        V.note_one(best, lane);
-        V.seen += 1;
+            V.seen += 1;
     }
     unsigned far_key = f2key(cur); // farthestResultDist :135
     // Speculative prefetch of the NEXT expansion's out-edge list: while the current candidate
@@ -1030,7 +1001,6 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
         }
         __syncthreads();
         if (m == 0) continue;
-        V.note(nbuf, m, lane);
         V.seen += m;
         if (V.crowded()) { hash_full = true; break; } // the id table is filling up: host traversal
         measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
@@ -1249,12 +1219,12 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
 // informational).  NS = 0: two-heap traversal only.
 // One job on this wave.  `vis` / `spill`: the wave's own scratch (vis all zero on entry; the caller
 // clears it afterwards).
-template <int METRIC, int NS>
+template <int METRIC, int NS, bool HASHED>
 __device__ __forceinline__ void search_job(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
                     const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
-                    int spill_cap, VisitedSet &V, int k_out, int *__restrict__ out_ids,
+                    int spill_cap, VisitedSet<HASHED> &V, int k_out, int *__restrict__ out_ids,
                     float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
                     unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, bool overlap)
 {
@@ -1279,7 +1249,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
     if constexpr (NS > 0) {
         bool tie = false;
         // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
-        const bool ok1 = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap);
+        const bool ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap);
         if (!(ok1 && tie)) {
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
             // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
@@ -1301,7 +1271,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         top_n = 0;
         repeated = true;
     }
-    const bool ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
+    const bool ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
     // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(c => c.Dist) is a STABLE sort over the heap
     // array (ToArray(), BinaryHeap.cs:41-44) and only the first k_out survive -- so select the
     // k_out smallest (float.CompareTo order: NaN first, -0 == +0) with ties broken by array index:
@@ -1348,21 +1318,19 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
 // shared counter until none are left.  A wave owns one visited bitset and one spill area for the
 // whole launch and leaves the bitset clean after every job, so the scratch is sized by the
 // resident waves (not by the batch) and nothing is memset between launches.
-template <int METRIC, int NS>
-__global__ void __launch_bounds__(64)
+template <int METRIC, int NS, bool HASHED>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS <= 4 ? 3 : 2))) // 168 VGPRs: three waves per SIMD
 graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
                     const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
-                    int spill_cap, unsigned *__restrict__ visited, long long vis_words, int *__restrict__ vis_log, int vis_log_cap,
-                    int *__restrict__ vis_tab, int vis_tab_cap, int k_out,
+                    int spill_cap, unsigned *__restrict__ visited, long long vis_words, int *__restrict__ vis_tab, int vis_tab_cap, int k_out,
                     int *__restrict__ out_ids, float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
                     unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    VisitedSet V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
-                 vis_log ? vis_log + (size_t)blockIdx.x * (size_t)vis_log_cap : nullptr, vis_log_cap, 0,
+    VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
                  vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, (unsigned)(vis_tab_cap - 1), 0, vis_tab_cap / 4 * 3};
     ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
     for (;;) {
@@ -1370,7 +1338,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
         if (lane == 0) job = atomicAdd(job_counter, 1);
         job = __builtin_amdgcn_readfirstlane(job);
         if (job >= njobs) break;
-        search_job<METRIC, NS>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
+        search_job<METRIC, NS, HASHED>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
                                V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job, overlap != 0);
         V.clear(lane);
     }
@@ -1383,11 +1351,11 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
 // clear their visited bitset between layers).  Output per (job, layer): the selected ids in
 // selection order (layer 0 -> slot `job`; layer L >= 1 -> upper slot jobs[].aux + L - 1).
 // jobs[].search_layer = the item's first layer min(level, top).
-template <int METRIC, int NS>
+template <int METRIC, int NS, bool HASHED>
 __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
-                           int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, VisitedSet &V,
+                           int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, VisitedSet<HASHED> &V,
                            int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
                            unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, bool overlap)
@@ -1412,7 +1380,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         if constexpr (NS > 0) {
             bool tie = false;
             const unsigned long long ev0 = evals;
-            ok = traverse_sorted<METRIC, NS>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap); // Span.Sort consumes all
+            ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap); // Span.Sort consumes all
             if (!ok) break;
             // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
             // then returns them in HEAP order, Heuristic.cs:13-18): this layer again, exact traversal
@@ -1425,7 +1393,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
             }
         }
         if (exact) {
-            ok = traverse<METRIC>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
+            ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
             if (!ok) break;
         }
         const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact);
@@ -1444,20 +1412,19 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     }
 }
 
-template <int METRIC, int NS>
+template <int METRIC, int NS, bool HASHED>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS <= 4 ? 3 : 2))) // up to 256 candidates: 168 VGPRs, three waves per SIMD
 graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
-                           int *__restrict__ vis_log, int vis_log_cap, int *__restrict__ vis_tab, int vis_tab_cap, int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
+                           int *__restrict__ vis_tab, int vis_tab_cap, int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
                            unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    VisitedSet V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
-                 vis_log ? vis_log + (size_t)blockIdx.x * (size_t)vis_log_cap : nullptr, vis_log_cap, 0,
+    VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
                  vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, (unsigned)(vis_tab_cap - 1), 0, vis_tab_cap / 4 * 3};
     ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
     for (;;) { // persistent, see graph_search_kernel
@@ -1465,7 +1432,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         if (lane == 0) job = atomicAdd(job_counter, 1);
         job = __builtin_amdgcn_readfirstlane(job);
         if (job >= njobs) break;
-        insert_job<METRIC, NS>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
+        insert_job<METRIC, NS, HASHED>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
                                out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap != 0);
         V.clear(lane);
     }
@@ -1868,7 +1835,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vislog_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -2150,7 +2117,6 @@ static int resident_blocks(K kernel, size_t lds, int num_cu)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
     return per_cu * std::max(1, num_cu);
 }
-constexpr int kVisLogCap = 16384; // ids a traversal may log before it falls back to streaming the bitset clear
 
 static int cand_lds_cap(int k, int dim, bool heur, int nbcap)
 {
@@ -2176,21 +2142,12 @@ static bool grow_dev(T **p, size_t *cap, size_t need)
     return true;
 }
 
-// chunk: jobs per launch (job / result buffers); slots: waves of a persistent launch (visited
-// bitsets, spill areas).  The visited arena is all zero between launches: zeroed when allocated,
-// and every wave clears its bitset after each job.
 // Row loads overlapped with the visited atomics in launches that do not fill the chip
 // (HNSW_MI355X_OVERLAP=0 disables, =2 forces it for every launch: tests).
 static int overlap_mode()
 {
     const char *e = std::getenv("HNSW_MI355X_OVERLAP");
     return e ? std::atoi(e) : 1;
-}
-
-static int vis_log_cap_for_tests()
-{
-    if (const char *e = std::getenv("HNSW_MI355X_VIS_LOG_CAP")) return std::max(1, std::min(kVisLogCap, std::atoi(e)));
-    return kVisLogCap;
 }
 
 // The per-wave visited-id hash tables (VisitedSet): capacity a power of two, >= 16384 and >= 64 per
@@ -2223,18 +2180,9 @@ bool Device::visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_
     return true;
 }
 
-// The per-wave visited-id logs (VisitedSet), only for graphs whose bitset is large.
-bool Device::visited_log(size_t vis_bytes_per_job, int **out)
-{
-    *out = nullptr;
-    const char *e = std::getenv("HNSW_MI355X_VIS_LOG"); // tests: 1 forces the log, 0 forbids it
-    const bool want = e ? std::atoi(e) != 0 : vis_bytes_per_job > (512u << 10);
-    if (!want) return true;
-    if (!grow_dev(&s_vislog_, &s_vislog_cap_, (size_t)max_slots() * kVisLogCap)) return false;
-    *out = s_vislog_;
-    return true;
-}
-
+// chunk: jobs per launch (job / result buffers); slots: waves of a persistent launch (visited
+// bitsets, spill areas).  The visited arena is all zero between launches: zeroed when allocated,
+// and every wave clears its bitset after each job.
 bool Device::ensure_search_scratch(long long chunk, long long slots, int k, size_t vis_bytes_per_job)
 {
     if (vis_bytes_per_job * (size_t)slots > s_visited_bytes_) {
@@ -2294,10 +2242,9 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
     const long long chunk = std::min<long long>(njobs, 1 << 20);
     if (!ensure_search_scratch(chunk, max_slots(), 0, vis_bytes_per_job)) return false;
-    int *vis_log = nullptr, *vis_tab = nullptr;
+    int *vis_tab = nullptr;
     int vis_tab_cap = 0;
     if (!visited_table(vis_bytes_per_job, k, &vis_tab, &vis_tab_cap)) return false;
-    if (!vis_tab && !visited_log(vis_bytes_per_job, &vis_log)) return false;
     const size_t nU = (size_t)std::max(n_upper, 1);
     if (!grow_dev(&s_sel_, &s_sel_cap_, (size_t)njobs * sel_stride) || !grow_dev(&s_lcnt_, &s_lcnt_cap_, (size_t)njobs) ||
         !grow_dev(&s_selU_, &s_selU_cap_, nU * sel_stride) || !grow_dev(&s_cntU_, &s_cntU_cap_, nU) ||
@@ -2327,20 +2274,25 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-#define LAUNCH2(M, NS_, GRID, LDS, CAP) \
+#define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \
-        const int slots_ = std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_>, LDS, num_cu_)); \
-        hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_>), dim3(std::min<int>(GRID, slots_)), \
+        const int slots_ = std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_>, LDS, num_cu_)); \
+        hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
-                       max_edges0, s_visited_, vis_words, vis_log, vis_log_cap_for_tests(), vis_tab, vis_tab_cap, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
+                       max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
                        sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0); \
+    } while (0)
+#define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
+    do {                                                                                                                   \
+        if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, H_, GRID, LDS, CAP);                                                  \
+        else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, H_, GRID, LDS, CAP);                                           \
+        else LAUNCH2(M_UCOS, NS_, H_, GRID, LDS, CAP);                                                                \
     } while (0)
 #define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
     do {                                                                                                                   \
-        if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, CAP);                                                      \
-        else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, GRID, LDS, CAP);                                               \
-        else LAUNCH2(M_UCOS, NS_, GRID, LDS, CAP);                                                                    \
+        if (vis_tab) LAUNCH3(NS_, true, GRID, LDS, CAP);                                                              \
+        else LAUNCH3(NS_, false, GRID, LDS, CAP);                                                                     \
     } while (0)
         switch (ns) {
         case 1: LAUNCH(1, nj, lds, cand_cap); break;
@@ -2351,6 +2303,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         }
         HIP_OK(hipGetLastError());
 #undef LAUNCH
+#undef LAUNCH3
 #undef LAUNCH2
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -2681,10 +2634,9 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     const size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
     const long long chunk = std::min<long long>(njobs, 1 << 20);
     if (!ensure_search_scratch(chunk, max_slots(), k_out, vis_bytes_per_job)) return false;
-    int *vis_log = nullptr, *vis_tab = nullptr;
+    int *vis_tab = nullptr;
     int vis_tab_cap = 0;
     if (!visited_table(vis_bytes_per_job, k, &vis_tab, &vis_tab_cap)) return false;
-    if (!vis_tab && !visited_log(vis_bytes_per_job, &vis_log)) return false;
     // pinned layout: [evals (16 B) | jobs | ids | dists | flags]
     const size_t b_jobs = sizeof(SearchJob) * (size_t)chunk, b_res = 4u * (size_t)chunk * k_out;
     char *hs = static_cast<char *>(pinned_stage(16 + b_jobs + 2 * b_res + 4u * (size_t)chunk));
@@ -2704,19 +2656,24 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-#define LAUNCH2(M, NS_, GRID, LDS, CAP) \
+#define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \
-        const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_>, LDS, num_cu_)); \
-        hipLaunchKernelGGL((graph_search_kernel<M, NS_>), dim3(std::min<int>(GRID, slots_)), \
+        const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_>, LDS, num_cu_)); \
+        hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_log, vis_log_cap_for_tests(), vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0); \
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0); \
+    } while (0)
+#define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
+    do {                                                                                                                   \
+        if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, H_, GRID, LDS, CAP);                                                  \
+        else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, H_, GRID, LDS, CAP);                                           \
+        else LAUNCH2(M_UCOS, NS_, H_, GRID, LDS, CAP);                                                                \
     } while (0)
 #define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
     do {                                                                                                                   \
-        if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, GRID, LDS, CAP);                                                      \
-        else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, GRID, LDS, CAP);                                               \
-        else LAUNCH2(M_UCOS, NS_, GRID, LDS, CAP);                                                                    \
+        if (vis_tab) LAUNCH3(NS_, true, GRID, LDS, CAP);                                                              \
+        else LAUNCH3(NS_, false, GRID, LDS, CAP);                                                                     \
     } while (0)
         switch (ns) {
         case 1: LAUNCH(1, nj, lds, cand_cap); break;
@@ -2727,6 +2684,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         }
         HIP_OK(hipGetLastError());
 #undef LAUNCH
+#undef LAUNCH3
 #undef LAUNCH2
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         HIP_OK(hipMemcpyAsync(h_ids, d_ids, 4u * (size_t)nj * k_out, hipMemcpyDeviceToHost, st));

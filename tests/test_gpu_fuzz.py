@@ -141,70 +141,12 @@ def test_many_jobs_per_resident_wave(Index):
     assert (again[0] == want[0][:5000]).all()
 
 
-@pytest.mark.parametrize("log_cap", ["16384", "300"])
-@pytest.mark.parametrize("sorted_top", ["1", "0"])
-def test_visited_id_log_clearing(Index, monkeypatch, sorted_top, log_cap):
-    # large graphs clear their visited bitsets through a log of the ids they set (forced here on a
-    # small graph); a log that overflows falls back to streaming the bitset
-    from common import uniform
-    monkeypatch.setenv("HNSW_MI355X_VIS_LOG", "1")
-    monkeypatch.setenv("HNSW_MI355X_VIS_LOG_CAP", log_cap)
-    monkeypatch.setenv("HNSW_MI355X_SORTED_TOP", sorted_top)
-    x, q = uniform(5000, 24, 401), uniform(40_000, 24, 402)
-    ref = oracle.OracleIndex(24, max_edges=8, max_candidates=50, min_nn=30, collection_size=5000)
-    ref.add_batched(x, 16384)
-    ix = _build(Index, x, 8, 50, 30, 16384)
-    assert ix.graph_hash() == ref.graph_hash()
-    got, want = ix.knn_query(q, 5), ref.knn_query(q, 5, threads=8)
-    assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
-
-
-@pytest.mark.parametrize("plan_on_device", ["1", "0"])
-def test_large_batches_link_half(Index, monkeypatch, plan_on_device):
-    # the link half of a batch: grouped on the device (default), or grouped by the host in four
-    # pipelined sub-batches (batches >= 2048 items; also the path after a hand-back).  Either must
-    # equal linking the whole batch in item order.
-    from common import uniform
-    monkeypatch.setenv("HNSW_MI355X_LINK_PLAN", plan_on_device)
-    x = uniform(60_000, 16, 501)
-    ref = oracle.OracleIndex(16, max_edges=8, max_candidates=40, min_nn=10, collection_size=60_000)
-    ref.add_batched(x, 16384)
-    ix = _build(Index, x, 8, 40, 10, 16384)
-    assert ix.graph_hash() == ref.graph_hash()
-    assert (ix.levels() == ref.levels()).all() and ix.entry_point == ref.entry_point
-
-
-def test_nan_and_negative_zero_distances_are_handed_back(Index):
-    # NaN / -0 distances have no place in the integer-key order of the device traversals: such jobs
-    # are handed to the host traversal (after a device-linked Add that means fetching the lists back)
-    rng = np.random.default_rng(77)
-    x = rng.random((3000, 8), dtype=np.float32)
-    x[100] = np.nan                       # every distance to this row is NaN
-    x[200] = x[201]                       # cosine distance of identical rows: 1 - 1 = +0; keep one exact -0 source too
-    q = rng.random((300, 8), dtype=np.float32)
-    q[5] = np.nan
-    for metric in ("sq_euclid", "cosine"):
-        ref = oracle.OracleIndex(8, metric, max_edges=8, max_candidates=40, min_nn=20, collection_size=3000)
-        ref.add_batched(x, 16384)
-        ix = Index(8, metric)
-        ix.set_collection_size(3000); ix.set_max_edges(8); ix.set_max_candidates(40); ix.set_min_nn(20)
-        ix.add(x)
-        assert ix.graph_hash() == ref.graph_hash(), metric
-        got, want = ix.knn_query(q, 5), ref.knn_query(q, 5)
-        assert (got[0] == want[0]).all(), metric
-        # NaN is NaN: x86 keeps the operand's sign in `a - NaN`, the GPU's subtract flips it
-        nan = np.isnan(want[1])
-        assert (np.isnan(got[1]) == nan).all() and got[1][~nan].tobytes() == want[1][~nan].tobytes(), metric
-        assert ix.stats()["search_overflows"] > 0
-
-
 @pytest.mark.parametrize("overlap", ["2", "0"])
 def test_row_loads_overlapped_with_visited_atomics(Index, monkeypatch, overlap):
     # launches that do not fill the chip fetch the rows of all listed neighbours together with the
     # visited atomics (2 forces that for every launch, 0 forbids it): same results either way
     from common import uniform
     monkeypatch.setenv("HNSW_MI355X_OVERLAP", overlap)
-    monkeypatch.setenv("HNSW_MI355X_VIS_LOG", "1")
     x, q = uniform(8000, 20, 601), uniform(20_000, 20, 602)
     ref = oracle.OracleIndex(20, max_edges=10, max_candidates=60, min_nn=32, collection_size=8000)
     ref.add_batched(x, 16384)
