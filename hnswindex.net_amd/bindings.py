@@ -128,6 +128,11 @@ lib.hnswdev_set_profiling.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnswdev_get_stats.argtypes = [ct.c_void_p, ct.POINTER(Stats)]
 lib.hnswdev_reset_stats.argtypes = [ct.c_void_p]
 lib.hnswdev_last_error.argtypes = [ct.c_char_p, ct.c_int]
+lib.hnswdev_ctx_last_error.argtypes = [ct.c_void_p, ct.c_char_p, ct.c_int]
+lib.hnswdev_set_queries.argtypes = [ct.c_void_p, _F, ct.c_int]
+lib.hnswdev_step_buffers.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(_I), ct.POINTER(_F)]
+lib.hnswdev_step_submit.argtypes = [ct.c_void_p, ct.c_int, ct.c_int]
+lib.hnswdev_step_wait.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnswdev_test_sqrt_rn.argtypes = [ct.c_int, ct.POINTER(ct.c_double), ct.POINTER(ct.c_double), ct.c_int]
 
 METRICS = {"sq_euclid": 0, "cosine": 1, "ucosine": 2}
@@ -409,10 +414,15 @@ class DeviceBackend:
             lib.hnswdev_destroy(self._ctx)
             self._ctx = None
 
-    @staticmethod
-    def _check(rc):
+    def last_error(self) -> str:
+        """This context's own last error (hnswdev_ctx_last_error)."""
+        buf = ct.create_string_buffer(4096)
+        lib.hnswdev_ctx_last_error(self._ctx, buf, len(buf))
+        return buf.value.decode("utf-8", "replace")
+
+    def _check(self, rc):
         if rc != 0:
-            raise RuntimeError(_dev_error())
+            raise RuntimeError(self.last_error())
 
     def reserve(self, capacity: int):
         self._check(lib.hnswdev_reserve(self._ctx, capacity))
@@ -426,15 +436,40 @@ class DeviceBackend:
         self._check(lib.hnswdev_download_rows(self._ctx, first_id, n, out.ctypes.data_as(_F)))
         return out
 
-    def dist_query_batch(self, queries, cand_offsets, cand_ids):
+    def set_queries(self, queries):
+        """Uploads the query set of a batch of searches once; records name queries by row index."""
         q = _as_2d_f32(queries, self.dim)
+        self._check(lib.hnswdev_set_queries(self._ctx, q.ctypes.data_as(_F), q.shape[0]))
+
+    def dist_query_batch(self, queries, cand_offsets, cand_ids):
+        """queries=None: measure against the resident set (set_queries), nothing is re-uploaded."""
         off = np.ascontiguousarray(cand_offsets, dtype=np.int32)
         ids = np.ascontiguousarray(cand_ids, dtype=np.int32)
-        assert off.size == q.shape[0] + 1
         out = np.empty(ids.size, dtype=np.float32)
-        self._check(lib.hnswdev_dist_query_batch(self._ctx, q.ctypes.data_as(_F), q.shape[0], off.ctypes.data_as(_I),
-                                                 ids.ctypes.data_as(_I), out.ctypes.data_as(_F)))
+        if queries is None:
+            qp, nq = None, off.size - 1
+        else:
+            q = _as_2d_f32(queries, self.dim)
+            assert off.size == q.shape[0] + 1
+            qp, nq = q.ctypes.data_as(_F), q.shape[0]
+        self._check(lib.hnswdev_dist_query_batch(self._ctx, qp, nq, off.ctypes.data_as(_I), ids.ctypes.data_as(_I),
+                                                 out.ctypes.data_as(_F)))
         return out
+
+    def step_buffers(self, which: int, nslots: int, stride: int):
+        """The context's pinned step-buffer set `which` (0 | 1) as numpy views: records
+        [nslots, stride + 2] = (cnt, qidx, ids...) and distances [nslots, stride]."""
+        rec, dist = _I(), _F()
+        self._check(lib.hnswdev_step_buffers(self._ctx, which, nslots, stride, ct.byref(rec), ct.byref(dist)))
+        r = np.ctypeslib.as_array(rec, shape=(nslots, stride + 2))
+        d = np.ctypeslib.as_array(dist, shape=(nslots, stride))
+        return r, d
+
+    def step_submit(self, which: int, nslots_used: int):
+        self._check(lib.hnswdev_step_submit(self._ctx, which, nslots_used))
+
+    def step_wait(self, which: int):
+        self._check(lib.hnswdev_step_wait(self._ctx, which))
 
     def dist_pair_batch(self, a_ids, b_ids):
         a = np.ascontiguousarray(a_ids, dtype=np.int32)

@@ -4,14 +4,24 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <string>
 
 #include "../../include/hnsw_mi355x.h"
 
 namespace hnsw {
 
+// Last error: one process-wide string (hnswdev_last_error: creation failures have no context yet)
+// and one per context (hnswdev_ctx_last_error).  set_dev_error() files the message under the context
+// the calling thread is currently inside (ErrorScope), if any.
 void set_dev_error(const std::string &msg);
 std::string get_dev_error();
+class Device;
+struct ErrorScope { // RAII: the calling thread is inside a call on `d`
+    explicit ErrorScope(Device *d);
+    ~ErrorScope();
+    Device *prev;
+};
 
 // One lock-step "step" worth of work for up to nslots concurrent searches.
 // The host driver fills one packed record per slot in pinned host memory,
@@ -24,11 +34,12 @@ std::string get_dev_error();
 // 2-3x slower: tools/kbench.hip, DESIGN.md "Step buffers".)
 //   slot s evaluates metric(row[ids[c]], Q(s)) for c < cnt
 struct StepBuffers {
+    enum { kHeader = 16 }; // floats in front of the distances; word 0 = the kernel's guard flag, so one D2H copy brings both
     int nslots = 0, stride = 0, rec_stride = 0;
     int *rec = nullptr;     // pinned host, nslots * rec_stride
-    float *dist = nullptr;  // pinned host, nslots * stride
+    float *dist = nullptr;  // pinned host, nslots * stride (dist - kHeader is the allocation)
     int *d_rec = nullptr;   // HBM mirrors
-    float *d_dist = nullptr;
+    float *d_dist = nullptr; // kHeader + nslots * stride
     void *done = nullptr;      // hipEvent_t recorded after the D2H copy
     void *t0 = nullptr, *t1 = nullptr; // hipEvent_t pair around the kernel when profiling
     bool timed = false, in_flight = false;
@@ -127,7 +138,16 @@ public:
     // The adjacency mirror back to the host (adj0: n x stride0 ints, pool: pool_len ints).
     bool download_graph(int *adj0, long long n, int *pool, long long pool_len);
 
-    // C-ABI conveniences (synchronous; validate ids on the host before launching).
+    // ---- the inner boundary as a foreign host drives it (hnswdev_step_* / hnswdev_dist_*) ----
+    // Two step-buffer sets owned by the context (pinned host + HBM mirror), (re)allocated only when
+    // they grow: the host fills set A's records while the GPU works on set B.  The lock-step engine
+    // of this library is a client of exactly these calls.
+    bool step_buffers(int set, int nslots, int stride, int **rec, float **dist);
+    bool step_submit(int set, int nslots_used); // async: H2D, kernel, D2H on the context's stream
+    bool step_wait(int set);                    // distances of that set are in its pinned array
+    long long resident_queries() const { return n_queries_; }
+    // Synchronous conveniences on the same buffers (ids are guarded on the device).  queries ==
+    // nullptr: the resident set (hnswdev_set_queries) is used, otherwise it is replaced first.
     bool dist_query_batch(const float *queries, int nq, const int *offsets, const int *ids, float *out);
     bool dist_pair_batch(const int *a, const int *b, int n, float *out);
 
@@ -141,8 +161,16 @@ public:
     void get_stats(hnswdev_stats *out);
     void reset_stats();
 
+    // C-ABI callers: one call at a time per context (hnswdev_* exports hold this), and the
+    // context's own last-error string.
+    std::mutex &mutex() { return mu_; }
+    void set_error(const std::string &msg) { std::lock_guard<std::mutex> lk(err_mu_); err_ = msg; }
+    std::string error() { std::lock_guard<std::mutex> lk(err_mu_); return err_; }
+
 private:
     Device() = default;
+    std::mutex mu_, err_mu_;
+    std::string err_;
     bool bind();
     int device_ = 0, dim_ = 0, metric_ = 0;
     long long capacity_ = 0;
@@ -206,6 +234,10 @@ private:
         bool busy = false, timed = false;
         int ngroups = 0;
     } lset_[2];
+    StepBuffers *abi_sb_[2] = {nullptr, nullptr}; // context-owned step-buffer sets of the C ABI
+    int *d_guard_ = nullptr;                      // guard flag of pair_distance_kernel
+    int *pair_dev_ = nullptr;                     // dist_pair_batch: [a | b | out] on the device
+    size_t pair_dev_cap_ = 0;
     void *stream_ = nullptr;
     bool profiling_ = false;
     hnswdev_stats stats_{};

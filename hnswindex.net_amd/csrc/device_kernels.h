@@ -1,0 +1,1758 @@
+// device_kernels.h -- all gfx950 device code of the backend (included by device_backend.hip, which
+// holds the host side, and by the traverse_*.hip units, which only instantiate the two big
+// traversal kernel templates -- one metric each -- so that the build compiles them in parallel).
+// See device_backend.hip's header comment for what the kernels replace and the numerical contract.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_backend.h"
+
+namespace hnsw {
+
+// ------------------------------------------------------------------------------------
+// device code
+// ------------------------------------------------------------------------------------
+enum { M_SQ = HNSWDEV_SQ_EUCLID, M_COS = HNSWDEV_COSINE, M_UCOS = HNSWDEV_UCOSINE };
+
+__device__ __forceinline__ float lane_xor_add(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
+
+// Collapse of the eight lane partials, L2 order: EuclideanMetric.cs:45-50.
+__device__ __forceinline__ float collapse_l2(float p)
+{
+    float t = lane_xor_add(p, 4); // p_j + p_{j+4}
+    t = lane_xor_add(t, 1);       // (t0+t1), (t2+t3)
+    t = lane_xor_add(t, 2);       // (t0+t1)+(t2+t3)
+    return t;
+}
+// Collapse, cosine-family order: CosineMetric.cs:145-171.
+__device__ __forceinline__ float collapse_cos(float p)
+{
+    float u = lane_xor_add(p, 4); // p_j + p_{j+4}
+    u = lane_xor_add(u, 2);       // (u0+u2), (u1+u3)
+    u = lane_xor_add(u, 1);       // (u0+u2)+(u1+u3)
+    return u;
+}
+
+// Lane j (0..7) of an 8-lane group walks elements j, j+8, j+16, ... of rows a and b.
+template <int METRIC>
+__device__ __forceinline__ float lane_chain(const float *__restrict__ a, const float *__restrict__ b, int dim, int j)
+{
+    const int nblk = dim >> 3;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < nblk; ++k) {
+        float x = a[8 * k + j], y = b[8 * k + j];
+        if (METRIC == M_SQ) {
+            float d = x - y;
+            acc = __builtin_fmaf(d, d, acc); // Fma.MultiplyAdd, EuclideanMetric.cs:30
+        } else {
+            float p = x * y;                 // Avx.Multiply, CosineMetric.cs:114
+            acc = acc + p;                   // Avx.Add      :115
+        }
+    }
+    return acc;
+}
+
+// Scalar tail for dim % 8 != 0 (every lane redundantly; mul then add, no fma).
+template <int METRIC>
+__device__ __forceinline__ float scalar_tail(float s, const float *__restrict__ a, const float *__restrict__ b, int dim)
+{
+    for (int i = dim & ~7; i < dim; ++i) {
+        float x = a[i], y = b[i];
+        if (METRIC == M_SQ) {
+            float d = x - y;
+            float m = d * d;
+            s = s + m; // EuclideanMetric.cs:53-57
+        } else {
+            float p = x * y;
+            s = s + p; // CosineMetric.cs:135-138 / :78-85
+        }
+    }
+    return s;
+}
+
+// Correctly rounded double sqrt from the device's sqrt plus an exact one-ulp repair
+// (residual via fma; see DESIGN.md "cosine epilogue").  Math.Sqrt at CosineMetric.cs:88 is
+// IEEE correctly rounded; this must be too.
+__device__ inline double sqrt_rn(double x)
+{
+    if (!(x > 0.0) || x == __builtin_inf()) return x == 0.0 ? x : sqrt(x);
+    double scale = 1.0;
+    if (x < 0x1p-900) { x *= 0x1p200; scale = 0x1p-100; } // keep the residual test clear of underflow
+    double y = sqrt(x);
+    for (int it = 0; it < 2; ++it) {
+        double r = __builtin_fma(-y, y, x);
+        double yu = __longlong_as_double(__double_as_longlong(y) + 1);
+        double yd = __longlong_as_double(__double_as_longlong(y) - 1);
+        if (r > y * (yu - y)) y = yu;
+        else if (r <= -(y * (y - yd))) y = yd;
+        else break;
+    }
+    return y * scale;
+}
+
+// Full metric for one (row a, vector b) pair evaluated by an 8-lane group; every lane of the
+// group returns the same value.  sa/sb: precomputed sqrt((double)|.|^2) for cosine.
+template <int METRIC>
+__device__ __forceinline__ float group_metric(const float *__restrict__ a, const float *__restrict__ b, int dim, int j,
+                                              double sa, double sb)
+{
+    float p = lane_chain<METRIC>(a, b, dim, j);
+    float s = (METRIC == M_SQ) ? collapse_l2(p) : collapse_cos(p);
+    if (dim & 7) s = scalar_tail<METRIC>(s, a, b, dim);
+    if (METRIC == M_SQ) return s;
+    if (METRIC == M_UCOS) return 1.0f - s; // CosineMetric.cs:141
+    float denom = (float)(sa * sb);        // :88  (float)(Math.Sqrt(nA) * Math.Sqrt(nB))
+    if (denom < 1e-30f) return 1.0f;       // :89-90
+    return 1.0f - s / denom;               // :91
+}
+
+// One wave per search slot; inputs are the packed per-slot records (device_backend.h).
+// Guards: a record that names a row / query outside what was uploaded, or more ids than the slot
+// holds, is never dereferenced -- its distances come back NaN and `guard` is raised, which
+// wait_step() turns into an error return (the records may come from a foreign host through
+// hnswdev_step_submit; a bad id must not become a GPU fault).
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+slot_distance_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn,
+                     const float *__restrict__ queries, const double *__restrict__ q_sn, int dim,
+                     const int *__restrict__ rec, float *__restrict__ out, int stride, int rec_stride, int nslots,
+                     long long n_rows, long long n_queries, int *__restrict__ guard)
+{
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= nslots) return;
+    const int *r = rec + (size_t)s * rec_stride;
+    int cnt = r[0];
+    if (cnt <= 0) return;
+    const int qraw = r[1];
+    const int *sid = r + 2;
+    const bool q_ok = qraw >= 0 ? qraw < n_queries : (long long)(~qraw) < n_rows;
+    if (cnt > stride || !q_ok) {
+        if (lane == 0) atomicOr(guard, 1);
+        cnt = min(cnt, stride);
+        for (int c = lane; c < cnt; c += 64) out[(size_t)s * stride + c] = __uint_as_float(0x7fc00000u);
+        return;
+    }
+    const float *q;
+    double sb = 0.0;
+    if (qraw >= 0) {
+        q = queries + (size_t)qraw * dim;
+        if (METRIC == M_COS) sb = q_sn[qraw];
+    } else {
+        q = rows + (size_t)(~qraw) * dim;
+        if (METRIC == M_COS) sb = row_sn[~qraw];
+    }
+    const int grp = lane >> 3, j = lane & 7;
+    float *so = out + (size_t)s * stride;
+    for (int c0 = 0; c0 < cnt; c0 += 8) {
+        const int c = c0 + grp;
+        const bool act = c < cnt;
+        int id = sid[act ? c : c0]; // idle groups shadow a valid row and discard
+        const bool bad = (unsigned long long)(long long)id >= (unsigned long long)n_rows;
+        if (bad) id = 0;
+        double sa = 0.0;
+        if (METRIC == M_COS) sa = row_sn[id];
+        float v = group_metric<METRIC>(rows + (size_t)id * dim, q, dim, j, sa, sb);
+        if (act && j == 0) {
+            so[c] = bad ? __uint_as_float(0x7fc00000u) : v;
+            if (bad) atomicOr(guard, 1);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------
+// Graph-resident search: the whole traversal of one query on one wavefront.
+//
+// SearchLayer / SearchLayerQuery (GraphNavigator.cs:123-256) and FindEntryAtLayer (:51-82)
+// restated for a wave64.  Two variants share everything but the search state: traverse_sorted
+// (further down) keeps one sorted list in registers and is what normally runs; the variant
+// below keeps the two BinaryHeaps (BinaryHeap.cs:30-107) in LDS, manipulated by wave-uniform
+// scalar code with the reference's exact sift rules (so the heap ARRAY, not just the heap SET,
+// matches -- tie order decides ids), and is what a wave falls back to when equal distances
+// make the heap layout observable; the visited set
+// (VisitedListPool.cs:10-67) is a private bitset in HBM; the out-edge lists come from the HBM
+// mirror of the host graph; candidate rows are measured 8 lanes per row exactly as in
+// slot_distance_kernel.  Unvisited neighbours keep their adjacency order (ballot + prefix
+// count), so pushes happen in the reference's order.
+// ------------------------------------------------------------------------------------
+struct ND {
+    int id;
+    float dist;
+};
+
+__device__ __forceinline__ int dev_float_compare_to(float x, float y)
+{
+    if (x < y) return -1;
+    if (x > y) return 1;
+    if (x == y) return 0;
+    if (x != x) return (y != y) ? 0 : -1;
+    return 1;
+}
+// DistanceComparer (farther first) / ReverseDistanceComparer (closer first), DistanceComparer.cs:9-25
+template <bool CLOSER>
+__device__ __forceinline__ int nd_cmp(ND x, ND y)
+{
+    if (CLOSER) {
+        if (x.dist > y.dist) return -1;
+        if (x.dist < y.dist) return 1;
+        return dev_float_compare_to(y.dist, x.dist);
+    }
+    if (x.dist < y.dist) return -1;
+    if (x.dist > y.dist) return 1;
+    return dev_float_compare_to(x.dist, y.dist);
+}
+// Heap entries on the device are {id, key}: key = the distance's float bits mapped to an
+// unsigned integer with the same order (sign flip).  For every float except NaN and -0 the
+// integer order IS the float.CompareTo order the reference's comparers use
+// (DistanceComparer.cs:9-25), equal keys <=> equal distances, so every sift decision -- ties
+// included -- is unchanged; a traversal that meets a NaN or -0 distance is flagged and re-run on
+// the host path, where the comparers are restated literally.  Why keys: every value below is
+// wave-uniform; with integer keys pulled through readfirstlane the whole heap logic compiles to
+// SCALAR compares and branches (no exec-mask juggling), ~5x fewer instructions per sift level
+// than float compares on "divergent" VGPRs -- and this serial code, not memory, was the
+// bottleneck of the traversal kernels.
+__device__ __forceinline__ unsigned f2key(float d)
+{
+    unsigned u = __float_as_uint(d);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__device__ __forceinline__ bool key_unsafe(float d) { return d != d || __float_as_uint(d) == 0x80000000u; } // NaN or -0
+
+struct HEnt {
+    int id;
+    unsigned key;
+};
+__device__ __forceinline__ HEnt uniform_ent(int2 v) // two 32-bit scalars (keeps the key compares on s_cmp_*_u32)
+{
+    HEnt e;
+    e.id = __builtin_amdgcn_readfirstlane(v.x);
+    e.key = (unsigned)__builtin_amdgcn_readfirstlane(v.y);
+    return e;
+}
+__device__ __forceinline__ int2 pack_ent(HEnt e) { return make_int2(e.id, (int)e.key); }
+
+// `top` lives entirely in LDS; `cand` keeps its first `cap` entries in LDS and spills the
+// (rarely reached) deep leaves to a private HBM area, so the LDS footprint -- and with it the
+// number of resident waves -- is set by the common case, not the worst one.
+struct LdsHeap {
+    ND *b;
+    __device__ __forceinline__ HEnt get(int i) const { return uniform_ent(*reinterpret_cast<const int2 *>(b + i)); }
+    __device__ __forceinline__ void set(int i, HEnt v) const { *reinterpret_cast<int2 *>(b + i) = pack_ent(v); }
+    // both children in one LDS round trip (entry i + 1 may be one past the heap: never used then)
+    __device__ __forceinline__ void get2(int i, HEnt &x, HEnt &y) const
+    {
+        const int2 *p = reinterpret_cast<const int2 *>(b + i);
+        const int2 vx = p[0], vy = p[1];
+        x = uniform_ent(vx);
+        y = uniform_ent(vy);
+    }
+};
+struct SpillHeap {
+    ND *b;
+    int cap;
+    ND *g;
+    __device__ __forceinline__ HEnt get(int i) const
+    {
+        return uniform_ent(i < cap ? *reinterpret_cast<const int2 *>(b + i) : *reinterpret_cast<const int2 *>(g + (i - cap)));
+    }
+    __device__ __forceinline__ void set(int i, HEnt v) const
+    {
+        if (i < cap) *reinterpret_cast<int2 *>(b + i) = pack_ent(v);
+        else *reinterpret_cast<int2 *>(g + (i - cap)) = pack_ent(v);
+    }
+    __device__ __forceinline__ void get2(int i, HEnt &x, HEnt &y) const
+    {
+        if (i + 1 < cap) {
+            const int2 *p = reinterpret_cast<const int2 *>(b + i);
+            const int2 vx = p[0], vy = p[1];
+            x = uniform_ent(vx);
+            y = uniform_ent(vy);
+        } else {
+            x = get(i);
+            y = get(i + 1); // i + 1 <= count <= cap + spill_cap - 1: inside the spill area
+        }
+    }
+};
+// comparer outcomes on keys: FartherFirst cmp(x,y) = sign(kx - ky); CloserFirst the reverse
+template <bool CLOSER> __device__ __forceinline__ bool cmp_le0(HEnt x, HEnt y) { return CLOSER ? x.key >= y.key : x.key <= y.key; }
+template <bool CLOSER> __device__ __forceinline__ bool cmp_lt0(HEnt x, HEnt y) { return CLOSER ? x.key > y.key : x.key < y.key; }
+
+template <bool CLOSER, class H>
+__device__ __forceinline__ void heap_push(const H &h, int &count, HEnt item) // BinaryHeap.cs:30-34, :89-107
+{
+    int i = count++;
+    while (i > 0) {
+        int p = (i - 1) >> 1;
+        HEnt parent = h.get(p);
+        if (cmp_le0<CLOSER>(item, parent)) break;
+        h.set(i, parent);
+        i = p;
+    }
+    h.set(i, item);
+}
+template <bool CLOSER, class H>
+__device__ __forceinline__ HEnt heap_pop(const H &h, int &count) // BinaryHeap.cs:53-87
+{
+    HEnt result = h.get(0);
+    int n = --count;
+    HEnt item = h.get(n);
+    if (n != 0) {
+        int i = 0, half = n >> 1;
+        while (i < half) {
+            int left = (i << 1) + 1, right = left + 1;
+            HEnt mv, rv;
+            h.get2(left, mv, rv);
+            int mc = left;
+            if (right < n && cmp_lt0<CLOSER>(mv, rv)) { mc = right; mv = rv; }
+            if (cmp_le0<CLOSER>(mv, item)) break;
+            h.set(i, mv);
+            i = mc;
+        }
+        h.set(i, item);
+    }
+    return result;
+}
+
+// Distances of nbuf[0..m) to the query staged in LDS (qs), written to dbuf[0..m).
+// 8 lanes per candidate, NP candidates per lane group in flight (row loads of all NP passes
+// are independent, so one HBM round trip serves up to 8*NP rows).
+template <int METRIC, int NP>
+__device__ __forceinline__ void measure_pass(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                                             const float *qs, double sb, const int *nbuf, float *dbuf, int p0, int m, int lane)
+{
+    const int grp = lane >> 3, j = lane & 7;
+    const float *a[NP];
+    int cidx[NP];
+    float acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        int c = p0 + grp + 8 * p;
+        cidx[p] = c;
+        int id = nbuf[c < m ? c : p0]; // idle groups shadow a valid row
+        a[p] = rows + (size_t)id * dim;
+        acc[p] = 0.0f;
+    }
+    const int nblk = dim >> 3;
+    int k = 0;
+    // All row loads of a 16-block (128-float) chunk are issued before any arithmetic, so a chunk
+    // costs ONE memory round trip for its 8 * NP rows: the lane partials must be summed in k
+    // order, the loads need not be issued in it.  (A plain unrolled loop waits per unroll group --
+    // four dependent round trips per 512-B row pass, most of an expansion's latency.)
+    for (; k + 16 <= nblk; k += 16) {
+        float x[NP][16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) x[p][kk] = a[p][8 * (k + kk) + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float y = qs[8 * (k + kk) + j];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (METRIC == M_SQ) {
+                    const float d = x[p][kk] - y;
+                    acc[p] = __builtin_fmaf(d, d, acc[p]);
+                } else {
+                    const float pr = x[p][kk] * y;
+                    acc[p] = acc[p] + pr;
+                }
+            }
+        }
+    }
+#pragma unroll 4
+    for (; k < nblk; ++k) {
+        float y = qs[8 * k + j];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float x = a[p][8 * k + j];
+            if (METRIC == M_SQ) {
+                float d = x - y;
+                acc[p] = __builtin_fmaf(d, d, acc[p]);
+            } else {
+                float pr = x * y;
+                acc[p] = acc[p] + pr;
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float s = (METRIC == M_SQ) ? collapse_l2(acc[p]) : collapse_cos(acc[p]);
+        if (dim & 7) s = scalar_tail<METRIC>(s, a[p], qs, dim);
+        float r;
+        if (METRIC == M_SQ) r = s;
+        else if (METRIC == M_UCOS) r = 1.0f - s;
+        else {
+            int id = nbuf[cidx[p] < m ? cidx[p] : p0];
+            float denom = (float)(row_sn[id] * sb);
+            r = (denom < 1e-30f) ? 1.0f : 1.0f - s / denom;
+        }
+        if (j == 0 && cidx[p] < m) dbuf[cidx[p]] = r;
+    }
+}
+
+template <int METRIC>
+__device__ __forceinline__ void measure_all(const float *rows, const double *row_sn, int dim, const float *qs, double sb,
+                                            const int *nbuf, float *dbuf, int m, int lane)
+{
+    for (int p0 = 0; p0 < m; p0 += 32) {
+        int left = m - p0;
+        if (left > 24) measure_pass<METRIC, 4>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
+        else if (left > 16) measure_pass<METRIC, 3>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
+        else if (left > 8) measure_pass<METRIC, 2>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
+        else measure_pass<METRIC, 1>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
+    }
+}
+
+constexpr int kNewMax = 4;     // link kernel shortcut: new entries of an overflowing list measured against all others
+constexpr int kSpillCap = 8192; // candidate-heap entries per traversal that may spill to HBM
+
+// LDS carve-up shared by the traversal kernels
+struct SearchLds {
+    ND *top;    // k + 1
+    ND *cand;   // cand_cap
+    float *qs;  // dim (padded to 4)
+    float *qs2; // dim (padded to 4): second vector (heuristic / prune)
+    float *qs3; // dim (padded to 4): the heuristic's next candidate, staged while the current one is tested
+    int *nbuf;  // nbcap
+    float *dbuf; // nbcap
+    int *acc;   // nbcap: accepted ids of the heuristic
+    int *stk;   // 3 * 40: introsort work stack
+};
+// heur: also room for the heuristic (second vector, accepted ids, introsort stack)
+// nbcap: capacity of the id / distance scratch = longest adjacency list, rounded up to 8
+__host__ __device__ inline size_t search_lds_bytes(int k, int cand_cap, int dim, bool heur, int nbcap)
+{
+    size_t b = sizeof(ND) * (size_t)(k + 1 + cand_cap) + sizeof(float) * (size_t)((dim + 3) & ~3) + 2u * 4u * (size_t)nbcap;
+    if (heur) b += 2u * sizeof(float) * (size_t)((dim + 3) & ~3) + 4u * (size_t)nbcap + 4u * 3u * 40u;
+    return b;
+}
+__device__ __forceinline__ SearchLds carve_lds(unsigned char *smem, int k, int cand_cap, int dim, int nbcap)
+{
+    SearchLds L;
+    L.top = reinterpret_cast<ND *>(smem);
+    L.cand = L.top + (k + 1);
+    L.qs = reinterpret_cast<float *>(L.cand + cand_cap);
+    L.nbuf = reinterpret_cast<int *>(L.qs + ((dim + 3) & ~3));
+    L.dbuf = reinterpret_cast<float *>(L.nbuf + nbcap);
+    // heuristic-only regions (present when the launch sized LDS with heur = true)
+    L.qs2 = L.dbuf + nbcap;
+    L.qs3 = L.qs2 + ((dim + 3) & ~3);
+    L.acc = reinterpret_cast<int *>(L.qs3 + ((dim + 3) & ~3));
+    L.stk = L.acc + nbcap;
+    return L;
+}
+
+struct GraphView {
+    const int *adj0;
+    int stride0;
+    const int64_t *upper;
+    const int *pool;
+    int strideU;
+    __device__ __forceinline__ const int *list(int id, int layer) const
+    {
+        return layer == 0 ? adj0 + (size_t)id * stride0 : pool + upper[id] + (size_t)(layer - 1) * strideU;
+    }
+};
+
+// A wave's visited set (VisitedListPool.cs:10-67 restated for one in-flight traversal), empty
+// between jobs.  Up to 4M nodes: a bitset over node ids in HBM, cleared by streaming over it.
+// Above: an open-addressing hash table of the visited ids (tab != nullptr, entries -1 when empty),
+// 64 KB per wave whatever the graph size -- at 10M nodes the bitsets of all resident waves span
+// gigabytes, and streaming a 1.25-MB clear per traversal cost as much as the row reads (measured:
+// 0.98 M queries/s streaming, 1.28 M clearing through a log of the ids, 1.48 M with the table; at 1M
+// nodes the bitset wins, 2.5 M against 1.9 M).  `seen` counts insertions; beyond `limit` the
+// traversal is handed back to the host, so the table never fills.
+template <bool HASHED> // compile-time choice: the bitset kernels carry none of the table's code or registers
+struct VisitedSet {
+    unsigned *bits;
+    long long words; // multiple of 4; the arena is 16-byte aligned
+    int *tab;
+    unsigned tab_mask;
+    int seen, limit;
+    // true: id was not in the set (and now is).  Per lane; lists hold no duplicates.
+    __device__ __forceinline__ bool first_visit(int id)
+    {
+        if constexpr (!HASHED) {
+            const unsigned bit = 1u << (id & 31);
+            return (atomicOr(&bits[id >> 5], bit) & bit) == 0u;
+        }
+        unsigned h = ((unsigned)id * 2654435761u) & tab_mask;
+        for (;;) {
+            const int old = atomicCAS(&tab[h], -1, id);
+            if (old == -1) return true;
+            if (old == id) return false;
+            h = (h + 1) & tab_mask;
+        }
+    }
+    __device__ __forceinline__ bool crowded() const { return HASHED && seen > limit; }
+    __device__ __forceinline__ void clear(int lane)
+    {
+        __syncthreads();
+        if constexpr (HASHED) {
+            uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+            const uint4 e = make_uint4(~0u, ~0u, ~0u, ~0u);
+            for (unsigned w = lane; w < ((tab_mask + 1u) >> 2); w += 64) t4[w] = e;
+        } else {
+            uint4 *v4 = reinterpret_cast<uint4 *>(bits);
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            for (long long w = lane; w < (words >> 2); w += 64) v4[w] = z;
+        }
+        seen = 0;
+        __syncthreads();
+    }
+};
+
+#ifdef EXP_PHASE_CLOCKS // experiment build: shader-clock cycles per traversal phase, summed over waves
+#ifndef HNSW_SINGLE_TU
+#error "EXP_PHASE_CLOCKS needs -DHNSW_SINGLE_TU: the counters below are per-translation-unit device globals"
+#endif
+__device__ unsigned long long g_phase[12];
+__device__ unsigned long long g_phase_link[12];
+#define PH_FLUSH_LINK() do { if (lane == 0) for (int ph_i = 0; ph_i < 8; ++ph_i) atomicAdd(&g_phase_link[ph_i], (unsigned long long)ph_acc[ph_i]); } while (0)
+#define PH_DECL() long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_t = __builtin_readcyclecounter()
+#define PH(i) do { long long ph_n = __builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; } while (0)
+#define PH_COUNT(i, v) ph_acc[i] += (v)
+#define PH_FLUSH() do { if (lane == 0) for (int ph_i = 0; ph_i < 8; ++ph_i) atomicAdd(&g_phase[ph_i], (unsigned long long)ph_acc[ph_i]); } while (0)
+#else
+#define PH_DECL() do {} while (0)
+#define PH(i) do {} while (0)
+#define PH_COUNT(i, v) do {} while (0)
+#define PH_FLUSH() do {} while (0)
+#define PH_FLUSH_LINK() do {} while (0)
+#endif
+
+// FindEntryPoint / FindEntryAtLayer (GraphNavigator.cs:27-82): greedy descent from jb.entry at
+// jb.entry_layer down to (not including) jb.search_layer.  Leaves the entry of the search layer
+// in `best` and its distance in `cur` (both wave-uniform).
+template <int METRIC>
+__device__ __forceinline__ void descend(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
+                                        const GraphView &G, const SearchJob jb, const SearchLds &L, int lane, int &best, float &cur,
+                                        unsigned long long &evals)
+{
+    int *nbuf = L.nbuf;
+    float *dbuf = L.dbuf;
+    const float *qs = L.qs;
+    best = jb.entry;
+    __syncthreads();
+    if (lane == 0) nbuf[0] = best;
+    __syncthreads();
+    measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, 1, lane);
+    __syncthreads();
+    cur = dbuf[0]; // :57
+    evals += 1;
+    for (int layer = jb.entry_layer; layer > jb.search_layer; --layer) {
+        bool changed = true;
+        while (changed) { // :60
+            changed = false;
+            const int *l = G.list(best, layer);
+            const int n = l[0];
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) nbuf[i] = l[1 + i]; // :65 span taken once per pass
+            __syncthreads();
+            if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane);
+            __syncthreads();
+            evals += (unsigned long long)n;
+            for (int i = 0; i < n; ++i) { // :67-78
+                float d = dbuf[i];
+                if (d < cur) { cur = d; best = nbuf[i]; changed = true; }
+            }
+        }
+    }
+    best = __builtin_amdgcn_readfirstlane(best);
+    cur = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cur)));
+}
+
+// ---- SearchLayer on ONE sorted list in registers ---------------------------------------------
+// The reference keeps two heaps (GraphNavigator.cs:126-127): topCandidates (the k closest seen,
+// farthest at the root) and candidates (everything accepted, closest at the root).  An accepted
+// element is pushed to both; it leaves topCandidates only when k closer ones exist, and from
+// then on its distance exceeds farthestResultDist for good, so popping it from `candidates` can
+// only end the loop (:147-150).  Hence the live part of `candidates` is exactly the not yet
+// expanded members of topCandidates, and when no two coexisting entries have equal distances
+// the whole state is one ascending list of <= k entries with an "expanded" mark:
+//   pop closest candidate  = first unmarked entry            (ballot + ctz)
+//   push / trim to k       = ranked insertion, last one drops (compare + popcount + lane shift)
+//   farthestResultDist     = entry k - 1
+// which is straight-line wave-wide code instead of scalar sift loops in LDS (2/3 of the traversal
+// time at C2, all of it scalar-issue bound).  Equal distances: a heap removes "the" extreme
+// element, so as long as the extreme is unique the SETS in both heaps evolve identically whatever
+// the array layout.  The layout shows only when (i) the farthest result is evicted while another
+// entry has the same distance, (ii) the closest candidate is popped while another open candidate
+// has the same distance, or (iii) equal distances sit next to each other in what the caller
+// consumes in order (OrderBy + Take(k), Span.Sort).  (ii) and (iii) raise `tie` and the caller
+// repeats the job with the exact two-heap traversal below.  After (i) the survivor (the reference
+// may hold its twin instead -- same distance, other id, possibly still a candidate there) is only
+// marked DOUBTFUL: the search goes on, and `tie` is raised if a doubtful entry is popped or is still
+// in the list at the end; usually the next few insertions push it out and nothing depended on it.
+// Equal distances elsewhere in the list are harmless.  Position p lives in lane p & 63 of register
+// set p >> 6; id bit 31 = expanded, bit 30 = doubtful (node ids stay below 2^30).
+__device__ __forceinline__ int dpp_wave_shr1(int carry_in, int v)
+{
+    return __builtin_amdgcn_update_dpp(carry_in, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); // lane 0 keeps carry_in
+}
+template <int NS>
+struct SortedTop {
+    unsigned key[NS];
+    int id[NS];
+    __device__ __forceinline__ HEnt at(int p) const // uniform p
+    {
+        HEnt e{__builtin_amdgcn_readlane(id[0], p & 63), (unsigned)__builtin_amdgcn_readlane((int)key[0], p & 63)};
+#pragma unroll
+        for (int t = 1; t < NS; ++t) {
+            const int wi = __builtin_amdgcn_readlane(id[t], p & 63);
+            const unsigned wk = (unsigned)__builtin_amdgcn_readlane((int)key[t], p & 63);
+            if ((p >> 6) == t) { e.id = wi; e.key = wk; }
+        }
+        return e;
+    }
+    __device__ __forceinline__ unsigned key_at(int p) const
+    {
+        unsigned v = (unsigned)__builtin_amdgcn_readlane((int)key[0], p & 63);
+#pragma unroll
+        for (int t = 1; t < NS; ++t) {
+            const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)key[t], p & 63);
+            if ((p >> 6) == t) v = w;
+        }
+        return v;
+    }
+    // first entry not yet expanded, or -1
+    __device__ __forceinline__ int first_open(int count, int lane) const
+    {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (64 * t >= count) break;
+            const unsigned long long m = __ballot(lane + 64 * t < count && id[t] >= 0);
+            if (m) return 64 * t + (int)__builtin_ctzll(m);
+        }
+        return -1;
+    }
+    __device__ __forceinline__ void mark(int p, int lane, int bit = (int)0x80000000)
+    {
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            if ((p >> 6) == t && lane == (p & 63)) id[t] |= bit;
+    }
+    __device__ __forceinline__ void mark_key(unsigned k0, int count, int lane, int bit) // every entry of that key
+    {
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            if (lane + 64 * t < count && key[t] == k0) id[t] |= bit;
+    }
+    __device__ __forceinline__ bool any_flagged(int count, int lane, int bit) const // uniform result
+    {
+        bool f = false;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) f |= lane + 64 * t < count && (id[t] & bit) != 0;
+        return __ballot(f) != 0ull;
+    }
+    // ranked insertion of (xk, xid), before any entries of equal key; beyond k entries the last one drops
+    __device__ __forceinline__ void insert(unsigned xk, int xid, int &count, int k, int lane)
+    {
+        int r = 0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (64 * t >= count) break;
+            r += (int)__popcll(__ballot(lane + 64 * t < count && key[t] < xk));
+        }
+#pragma unroll
+        for (int t = NS - 1; t >= 0; --t) {
+            if (64 * t > count || 64 * (t + 1) <= r) continue; // nothing at or after r in this set
+            int ck = 0, ci = 0;
+            if (t > 0) { ck = __builtin_amdgcn_readlane((int)key[t - 1], 63); ci = __builtin_amdgcn_readlane(id[t - 1], 63); }
+            const int sk = dpp_wave_shr1(ck, (int)key[t]);
+            const int si = dpp_wave_shr1(ci, id[t]);
+            const int p = lane + 64 * t;
+            key[t] = p == r ? xk : p > r ? (unsigned)sk : key[t];
+            id[t] = p == r ? xid : p > r ? si : id[t];
+        }
+        if (count < k) ++count;
+    }
+    // any p in [1, upto) with key[p] == key[p - 1]?  (uniform result)
+    __device__ __forceinline__ bool adjacent_equal(int upto, int lane) const
+    {
+        bool eq = false;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (64 * t >= upto) break;
+            int ck = 0;
+            if (t > 0) ck = __builtin_amdgcn_readlane((int)key[t - 1], 63);
+            const unsigned prev = (unsigned)dpp_wave_shr1(ck, (int)key[t]);
+            const int p = lane + 64 * t;
+            eq |= p >= 1 && p < upto && key[t] == prev;
+        }
+        return __ballot(eq) != 0ull;
+    }
+};
+
+// Returns false on a NaN / -0 distance (exact host re-run); `tie` asks for the exact two-heap
+// traversal.  Result: L.top[0..top_n) ascending by distance.  The query must be staged in L.qs.
+template <int METRIC, int NS, bool HASHED>
+__device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
+                                                const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet<HASHED> &V,
+                                                const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals,
+                                                bool overlap)
+{
+    int *nbuf = L.nbuf;
+    float *dbuf = L.dbuf;
+    const float *qs = L.qs;
+    PH_DECL();
+    int best;
+    float cur;
+    descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals);
+    // ---- SearchLayer (GraphNavigator.cs:123-189) ----
+    const int layer = jb.search_layer;
+    SortedTop<NS> T;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) { T.key[t] = 0u; T.id[t] = 0; }
+    int top_n = 0;
+    bool unsafe = key_unsafe(cur); // NaN / -0 (see f2key)
+    bool tie = false, hash_full = false;
+    T.insert(f2key(cur), best, top_n, k, lane);                      // :134, :138
+    if (lane == 0) (void)V.first_visit(best);                           // :140
+    V.seen += 1;
+    unsigned far_key = f2key(cur);                                   // farthestResultDist :135
+    int pre_id = -1, pre_a = 0, pre_b = 0; // speculative prefetch of the next expansion's list (see traverse)
+    const int lstride = layer == 0 ? G.stride0 : G.strideU;
+    PH(0);
+    constexpr int kDoubt = 0x40000000, kIdMask = 0x3fffffff;
+    while (!unsafe && !tie) {
+        const int pos = T.first_open(top_n, lane); // :146 closest candidate; none left <=> :147-150 / empty
+        if (pos < 0) break;
+        const HEnt c = T.at(pos);
+        if (c.id & kDoubt) { tie = true; break; } // the reference may be expanding its twin instead
+        T.mark(pos, lane);
+        PH(1);
+        int n, nb_a = 0, nb_b = 0;
+        if (c.id == pre_id) {
+            n = __builtin_amdgcn_readlane(pre_a, 0);
+            nb_a = __shfl(pre_a, (lane + 1) & 63, 64);
+            const int w64 = __builtin_amdgcn_readlane(pre_b, 0);
+            if (lane == 63) nb_a = w64;
+            nb_b = __shfl(pre_b, (lane + 1) & 63, 64);
+        } else {
+            const int *l = G.list(c.id, layer);
+            n = __builtin_amdgcn_readfirstlane(l[0]);
+            if (lane < n) nb_a = l[1 + lane];
+            if (lane + 64 < n) nb_b = l[65 + lane];
+        }
+        PH_COUNT(6, c.id == pre_id);
+        PH_COUNT(7, 1);
+        int m = 0;
+        __syncthreads();
+        PH(2);
+        // candidate distances and ids of this expansion, one per lane, in adjacency order
+        bool have = false;     // this lane holds an unvisited neighbour
+        float lane_d = 0.0f;
+        int lane_id = 0;
+        const bool overlapped = overlap && n <= 64 && !HASHED;
+        if (overlapped) {
+            // Latency-bound launch (fewer jobs than resident waves): the rows of ALL listed neighbours
+            // are fetched together with the visited atomics instead of after them -- one dependent
+            // round trip less per expansion; rows of neighbours that turn out visited are wasted
+            // bandwidth, of which such a launch has plenty.  Evaluations counted: the unvisited ones.
+            const bool in = lane < n;
+            if (in) nbuf[lane] = nb_a;
+            __syncthreads();
+            unsigned old = 0u;
+            const unsigned bit = 1u << (nb_a & 31);
+            if (in) old = atomicOr(&V.bits[nb_a >> 5], bit); // :181, in flight with the row loads below
+            pre_id = -1;
+            {
+                const int nxt = T.first_open(top_n, lane);
+                if (nxt >= 0) {
+                    const HEnt e = T.at(nxt);
+                    if (e.key == c.key) tie = true; // (ii)
+                    pre_id = e.id & kIdMask;
+                    const int *pl = G.list(pre_id, layer);
+                    pre_a = lane < lstride ? pl[lane] : 0;
+                    pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
+                }
+            }
+            if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
+            __syncthreads();
+            have = in && (old & bit) == 0u;
+            const unsigned long long mask = __ballot(have);
+            m = __popcll(mask);
+            lane_d = in ? dbuf[lane] : 0.0f;
+            lane_id = nb_a;
+            PH(4);
+            if (m == 0) continue;
+            evals += (unsigned long long)m;
+        } else {
+        for (int base = 0; base < n; base += 64) { // :158-161 keep only unvisited, in list order
+            const int i = base + lane;
+            bool fresh = false;
+            const int nb = base == 0 ? nb_a : nb_b;
+            if (i < n) fresh = V.first_visit(nb); // :181 (lists hold no duplicates)
+            const unsigned long long mask = __ballot(fresh);
+            const int posn = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (fresh) nbuf[m + posn] = nb;
+            m += __popcll(mask);
+        }
+        PH(3);
+        pre_id = -1;
+        {
+            const int nxt = T.first_open(top_n, lane);
+            if (nxt >= 0) {
+                const HEnt e = T.at(nxt);
+                if (e.key == c.key) tie = true; // (ii): which of the two the reference pops first is a matter of heap layout
+                pre_id = e.id & kIdMask;
+                const int *pl = G.list(pre_id, layer);
+                pre_a = lane < lstride ? pl[lane] : 0;
+                pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
+            }
+        }
+        __syncthreads();
+        if (m == 0) continue;
+        V.seen += m;
+        if (V.crowded()) { hash_full = true; break; } // the id table is filling up: host traversal
+        measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
+        __syncthreads();
+        PH(4);
+        evals += (unsigned long long)m;
+        }
+        // the push loop (:165-178) in adjacency order; farthest never grows once the list is full,
+        // so only the lanes passing the test now can pass it later: they are replayed one by one
+        const int rounds = overlapped ? 1 : (m + 63) / 64;
+        for (int r = 0; r < rounds && !unsafe; ++r) {
+            const int i = r * 64 + lane;
+            const bool valid = overlapped ? have : i < m;
+            const float my_d = overlapped ? lane_d : (i < m ? dbuf[i] : 0.0f);
+            const int my_id = overlapped ? lane_id : (i < m ? nbuf[i] : 0);
+            const unsigned my_key = f2key(my_d);
+            if (__ballot(valid && key_unsafe(my_d))) { unsafe = true; break; }
+            unsigned long long maybe = __ballot(valid && (top_n < k || my_key < far_key));
+            while (maybe) {
+                const int src = __builtin_ctzll(maybe);
+                maybe &= maybe - 1;
+                const unsigned dk = (unsigned)__builtin_amdgcn_readlane((int)my_key, src);
+                if (top_n < k || dk < far_key) { // :165
+                    const bool evicts = top_n == k;
+                    T.insert(dk, __builtin_amdgcn_readlane(my_id, src), top_n, k, lane); // :168-174
+                    if (top_n == k) {
+                        const unsigned nf = T.key_at(k - 1);                             // :176-177
+                        if (evicts && nf == far_key) T.mark_key(nf, top_n, lane, kDoubt); // (i): one of several equally far results was dropped
+                        far_key = nf;
+                    }
+                }
+            }
+        }
+        PH(5);
+    }
+    PH_FLUSH();
+    // ToArray() for the callers: with distinct distances any order-insensitive consumer (OrderBy,
+    // Span.Sort) sees the same thing; ascending order is also what they would produce
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int p = lane + 64 * t;
+        if (p < top_n) { L.top[p].id = T.id[t] & kIdMask; L.top[p].dist = key2f(T.key[t]); }
+    }
+    __syncthreads();
+    top_n_out = top_n;
+    if (T.adjacent_equal(min(top_n, ordered_prefix), lane)) tie = true; // (iii)
+    if (T.any_flagged(top_n, lane, kDoubt)) tie = true;                  // (i) left unresolved
+    tie_out = tie;
+    return !unsafe && !hash_full;
+}
+
+// Descent + beam search of one job; result = L.top[0..top_n) in heap order.  Returns false on
+// candidate-heap overflow.  The query must already be staged in L.qs.
+template <int METRIC, bool HASHED>
+__device__ __forceinline__ bool traverse(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
+                                         const GraphView &G, const SearchJob jb, int k, int cand_cap, ND *spill, int spill_cap,
+                                         VisitedSet<HASHED> &V, const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals)
+{
+    const LdsHeap top{L.top};
+    const SpillHeap cand{L.cand, cand_cap, spill};
+    const int cand_limit = cand_cap + spill_cap;
+    int *nbuf = L.nbuf;
+    float *dbuf = L.dbuf;
+    const float *qs = L.qs;
+    // ---- FindEntryPoint / FindEntryAtLayer (GraphNavigator.cs:27-82) ----
+    int best = jb.entry;
+    __syncthreads();
+    if (lane == 0) nbuf[0] = best;
+    __syncthreads();
+    measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, 1, lane);
+    __syncthreads();
+    float cur = dbuf[0]; // :57
+    evals += 1;
+    for (int layer = jb.entry_layer; layer > jb.search_layer; --layer) {
+        bool changed = true;
+        while (changed) { // :60
+            changed = false;
+            const int *l = G.list(best, layer);
+            const int n = l[0];
+            __syncthreads();
+            for (int i = lane; i < n; i += 64) nbuf[i] = l[1 + i]; // :65 span taken once per pass
+            __syncthreads();
+            if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane);
+            __syncthreads();
+            evals += (unsigned long long)n;
+            for (int i = 0; i < n; ++i) { // :67-78
+                float d = dbuf[i];
+                if (d < cur) { cur = d; best = nbuf[i]; changed = true; }
+            }
+        }
+    }
+    // ---- SearchLayer (GraphNavigator.cs:123-189) ----
+    const int layer = jb.search_layer;
+    int top_n = 0, cand_n = 0;
+    bool overflow = false; // also raised for NaN / -0 distances (see f2key)
+    bool hash_full = false;
+    best = __builtin_amdgcn_readfirstlane(best);
+    cur = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cur)));
+    if (key_unsafe(cur)) overflow = true;
+    {
+        HEnt e{best, f2key(cur)};
+        heap_push<false>(top, top_n, e); // :134
+        heap_push<true>(cand, cand_n, e); // :138
+        if (lane == 0) (void)V.first_visit(best);                       // :140
+            V.seen += 1;
+    }
+    unsigned far_key = f2key(cur); // farthestResultDist :135
+    // Speculative prefetch of the NEXT expansion's out-edge list: while the current candidate
+    // rows are in flight, lanes 0..stride fetch the list of the heap's current root.  If that
+    // node is indeed popped next (it is, unless this expansion pushes something closer) its list
+    // is already in registers and one dependent memory round trip disappears.
+    int pre_id = -1, pre_a = 0, pre_b = 0;
+    const int lstride = layer == 0 ? G.stride0 : G.strideU;
+    while (cand_n > 0 && !overflow) {
+        HEnt c = heap_pop<true>(cand, cand_n);          // :146
+        if (c.key > far_key && top_n >= k) break;       // :147-150
+        int n, nb_a = 0, nb_b = 0; // this lane's neighbour ids (list positions lane and lane + 64)
+        if (c.id == pre_id) {
+            n = __builtin_amdgcn_readlane(pre_a, 0);
+            nb_a = __shfl(pre_a, (lane + 1) & 63, 64);            // list word lane + 1
+            const int w64 = __builtin_amdgcn_readlane(pre_b, 0);  // list word 64
+            if (lane == 63) nb_a = w64;
+            nb_b = __shfl(pre_b, (lane + 1) & 63, 64);            // list word lane + 65
+        } else {
+            const int *l = G.list(c.id, layer);
+            n = __builtin_amdgcn_readfirstlane(l[0]);
+            if (lane < n) nb_a = l[1 + lane];
+            if (lane + 64 < n) nb_b = l[65 + lane];
+        }
+        int m = 0;
+        __syncthreads();
+        for (int base = 0; base < n; base += 64) { // :158-161 keep only unvisited, in list order
+            const int i = base + lane;
+            bool fresh = false;
+            const int nb = base == 0 ? nb_a : nb_b;
+            if (i < n) fresh = V.first_visit(nb); // :181 (lists hold no duplicates)
+            const unsigned long long mask = __ballot(fresh);
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (fresh) nbuf[m + pos] = nb;
+            m += __popcll(mask);
+        }
+        pre_id = -1;
+        if (cand_n > 0) {
+            pre_id = cand.get(0).id;
+            const int *pl = G.list(pre_id, layer);
+            pre_a = lane < lstride ? pl[lane] : 0;
+            pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
+        }
+        __syncthreads();
+        if (m == 0) continue;
+        V.seen += m;
+        if (V.crowded()) { hash_full = true; break; } // the id table is filling up: host traversal
+        measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
+        __syncthreads();
+        evals += (unsigned long long)m;
+        // Replay of the push loop (:165-178) in adjacency order.  farthest never grows once the
+        // result heap is full, so a candidate that fails `d < farthest` now can never pass later:
+        // only the lanes of the ballot are visited, and the exact test is repeated on each.
+        for (int base = 0; base < m && !overflow; base += 64) {
+            const int i = base + lane;
+            const float my_d = (i < m) ? dbuf[i] : 0.0f;
+            const int my_id = (i < m) ? nbuf[i] : 0;
+            const unsigned my_key = f2key(my_d);
+            if (__ballot(i < m && key_unsafe(my_d))) { overflow = true; break; }
+            unsigned long long maybe = __ballot(i < m && (top_n < k || my_key < far_key));
+            while (maybe) {
+                const int src = __builtin_ctzll(maybe);
+                maybe &= maybe - 1;
+                const unsigned dk = (unsigned)__builtin_amdgcn_readlane((int)my_key, src);
+                if (top_n < k || dk < far_key) { // :165
+                    HEnt sel{__builtin_amdgcn_readlane(my_id, src), dk};
+                    if (cand_n >= cand_limit) { overflow = true; break; }
+                    heap_push<true>(cand, cand_n, sel);               // :168
+                    heap_push<false>(top, top_n, sel);                // :171
+                    if (top_n > k) (void)heap_pop<false>(top, top_n); // :173-174
+                    far_key = top.get(0).key;                         // :176-177
+                }
+            }
+        }
+    }
+    // back to float distances for the callers (ToArray(): heap order, BinaryHeap.cs:41-44)
+    __syncthreads();
+    for (int i = lane; i < top_n; i += 64) L.top[i].dist = key2f(__float_as_uint(L.top[i].dist));
+    __syncthreads();
+    top_n_out = top_n;
+    return !overflow && !hash_full;
+}
+
+// ---- MemoryExtensions.Sort(Span<NodeDistance>, DistanceComparer) on an LDS array: the BCL
+// introsort restated (insertion sort <= 16, median of three, heapsort at depth limit
+// 2*(log2 n + 1)); wave-uniform scalar code, recursion replaced by a work stack in LDS.
+// Same algorithm as csrc/host_structs.h::dotnet_sort, so tie order is identical. ----
+__device__ __forceinline__ void sw_swap(ND *k, int i, int j) { ND t = k[i]; k[i] = k[j]; k[j] = t; }
+__device__ __forceinline__ void sw_swap_if_greater(ND *k, int i, int j) { if (nd_cmp<false>(k[i], k[j]) > 0) sw_swap(k, i, j); }
+__device__ inline void sw_insertion(ND *k, int n)
+{
+    for (int i = 0; i < n - 1; i++) {
+        ND t = k[i + 1];
+        int j = i;
+        while (j >= 0 && nd_cmp<false>(t, k[j]) < 0) { k[j + 1] = k[j]; j--; }
+        k[j + 1] = t;
+    }
+}
+__device__ inline void sw_down_heap(ND *k, int i, int n)
+{
+    ND d = k[i - 1];
+    while (i <= (n >> 1)) {
+        int child = 2 * i;
+        if (child < n && nd_cmp<false>(k[child - 1], k[child]) < 0) child++;
+        if (!(nd_cmp<false>(d, k[child - 1]) < 0)) break;
+        k[i - 1] = k[child - 1];
+        i = child;
+    }
+    k[i - 1] = d;
+}
+__device__ inline void sw_heap_sort(ND *k, int n)
+{
+    for (int i = n >> 1; i >= 1; i--) sw_down_heap(k, i, n);
+    for (int i = n; i > 1; i--) { sw_swap(k, 0, i - 1); sw_down_heap(k, 1, i - 1); }
+}
+__device__ inline int sw_partition(ND *k, int n)
+{
+    int hi = n - 1, mid = hi >> 1;
+    sw_swap_if_greater(k, 0, mid);
+    sw_swap_if_greater(k, 0, hi);
+    sw_swap_if_greater(k, mid, hi);
+    ND pivot = k[mid];
+    sw_swap(k, mid, hi - 1);
+    int left = 0, right = hi - 1;
+    while (left < right) {
+        while (nd_cmp<false>(k[++left], pivot) < 0) {}
+        while (nd_cmp<false>(pivot, k[--right]) < 0) {}
+        if (left >= right) break;
+        sw_swap(k, left, right);
+    }
+    if (left != hi - 1) sw_swap(k, left, hi - 1);
+    return left;
+}
+__device__ inline void dev_dotnet_sort(ND *arr, int n, int *stk)
+{
+    if (n <= 1) return;
+    int sp = 0;
+    stk[0] = 0; stk[1] = n; stk[2] = 2 * ((31 - __clz(n)) + 1);
+    sp = 1;
+    while (sp > 0) {
+        --sp;
+        ND *k = arr + stk[3 * sp];
+        int ps = stk[3 * sp + 1];
+        int depth = stk[3 * sp + 2];
+        while (ps > 1) {
+            if (ps <= 16) {
+                if (ps == 2) { sw_swap_if_greater(k, 0, 1); break; }
+                if (ps == 3) { sw_swap_if_greater(k, 0, 1); sw_swap_if_greater(k, 0, 2); sw_swap_if_greater(k, 1, 2); break; }
+                sw_insertion(k, ps);
+                break;
+            }
+            if (depth == 0) { sw_heap_sort(k, ps); break; }
+            depth--;
+            int p = sw_partition(k, ps);
+            // right part [p+1, ps) is an independent sub-problem: queue it (the BCL recurses into it)
+            if (sp < 39) {
+                stk[3 * sp] = (int)(k - arr) + p + 1; stk[3 * sp + 1] = ps - (p + 1); stk[3 * sp + 2] = depth;
+                ++sp;
+            }
+            ps = p;
+        }
+    }
+}
+
+// Heuristic.RelativeNeighborPruning (Heuristic.cs:11-46) on cands[0..n) (LDS): writes the
+// selected ids to L.acc, returns their count.  The candidate under test is staged in L.qs2
+// and measured against ALL accepted rows at once (the reference's early break only skips
+// evaluations).
+template <int METRIC>
+__device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                                                         ND *cands, int n, int max_edges, const SearchLds &L, int lane,
+                                                         unsigned long long &evals, bool presorted = false)
+{
+    int *acc = L.acc;
+    __syncthreads();
+    if (n < max_edges) { // :13-18 input (heap) order, unsorted
+        for (int i = lane; i < n; i += 64) acc[i] = cands[i].id;
+        __syncthreads();
+        return n;
+    }
+    if (!presorted) { // :22 (a sorted-list traversal hands them over in order)
+        bool ranked = false;
+        if (n <= 64) {
+            // distinct ordinary distances have one ascending order whatever the sort: rank by counting
+            // (the link kernel's 2M+1 candidates; the scalar introsort below was 9 % of a PruneOverflow)
+            const ND mine = lane < n ? cands[lane] : ND{0, 0.0f};
+            const unsigned my_key = f2key(mine.dist);
+            bool odd = lane < n && key_unsafe(mine.dist);
+            int rank = 0;
+            for (int t = 0; t < n; ++t) {
+                const unsigned kt = (unsigned)__builtin_amdgcn_readlane((int)my_key, t);
+                rank += kt < my_key ? 1 : 0;
+                odd |= lane < n && t != lane && kt == my_key;
+            }
+            if (__ballot(odd) == 0ull) {
+                __syncthreads();
+                if (lane < n) cands[rank] = mine;
+                ranked = true;
+            }
+        }
+        if (!ranked) dev_dotnet_sort(cands, n, L.stk); // equal / NaN / -0 distances: the BCL introsort decides
+    }
+    __syncthreads();
+    int rc = 0;
+    // The row of candidate i + 1 is fetched while candidate i is being tested (registers, then the
+    // other of two LDS buffers): one dependent memory round trip per candidate instead of two.
+    constexpr int kPre = 4; // floats per lane: rows up to 256 floats; longer rows (bandwidth-bound anyway) are staged on demand
+    const bool prefetch = dim <= 64 * kPre;
+    float *buf[2] = {L.qs2, L.qs3};
+    int cur = 0;
+    double sbc = 0.0, sbn = 0.0;
+    for (int i = 0; i < n && rc < max_edges; ++i) { // :23
+        const ND c = cands[i];
+        float pre[kPre];
+        const bool have_next = prefetch && i + 1 < n;
+        if (have_next) {
+            const int nid = cands[i + 1].id;
+            const float *nrow = rows + (size_t)nid * dim;
+#pragma unroll
+            for (int t = 0; t < kPre; ++t)
+                if (64 * t < dim) pre[t] = lane + 64 * t < dim ? nrow[lane + 64 * t] : 0.0f;
+            if (METRIC == M_COS) sbn = row_sn[nid];
+        }
+        bool ok = true;
+        if (rc > 0) {
+            if (!prefetch) { // candidate i on demand
+                const float *crow = rows + (size_t)c.id * dim;
+                for (int t = lane; t < dim; t += 64) buf[cur][t] = crow[t];
+                if (METRIC == M_COS) sbc = row_sn[c.id];
+                __syncthreads();
+            }
+            // accepted ids are measured in chunks, in acceptance order, stopping at the first chunk
+            // that rejects (the reference breaks at the first hit, :34; later pairs cannot change the
+            // outcome) -- with long rows this saves most of the traffic of rejected candidates
+            const int chunk = dim >= 512 ? 16 : 32;
+            for (int a0 = 0; a0 < rc && ok; a0 += chunk) {
+                const int an = min(chunk, rc - a0);
+                measure_all<METRIC>(rows, row_sn, dim, buf[cur], sbc, acc + a0, L.dbuf, an, lane); // distanceFnc(s.Id, candidateId) :34
+                __syncthreads();
+                evals += (unsigned long long)an;
+                const float dj = lane < an ? L.dbuf[lane] : 0.0f;
+                ok = __ballot(lane < an && dj < c.dist) == 0ull;
+                __syncthreads();
+            }
+        }
+        if (ok) { if (lane == 0) acc[rc] = c.id; rc++; }
+        if (have_next) {
+#pragma unroll
+            for (int t = 0; t < kPre; ++t)
+                if (64 * t < dim && lane + 64 * t < dim) buf[cur ^ 1][lane + 64 * t] = pre[t];
+            cur ^= 1;
+            sbc = sbn;
+        }
+        __syncthreads();
+    }
+    return rc;
+}
+
+// NS > 0: sorted-list traversal with NS register sets (k <= 64 * NS); a wave that meets equal
+// distances where the heap layout shows starts over with the exact two-heap traversal (out_flag 2,
+// informational).  NS = 0: two-heap traversal only.
+// One job on this wave.  `vis` / `spill`: the wave's own scratch (vis all zero on entry; the caller
+// clears it afterwards).
+template <int METRIC, int NS, bool HASHED>
+__device__ __forceinline__ void search_job(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
+                    const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
+                    const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
+                    const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
+                    int spill_cap, VisitedSet<HASHED> &V, int k_out, int *__restrict__ out_ids,
+                    float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
+                    unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, bool overlap)
+{
+    const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
+    const int lane = threadIdx.x;
+    const SearchJob jb = jobs[job];
+    const GraphView G{adj0, stride0, upper, pool, strideU};
+
+    const float *q;
+    double sb = 0.0;
+    if (jb.qref >= 0) {
+        q = queries + (size_t)jb.qref * dim;
+        if (METRIC == M_COS) sb = q_sn[jb.qref];
+    } else {
+        q = rows + (size_t)(~jb.qref) * dim;
+        if (METRIC == M_COS) sb = row_sn[~jb.qref];
+    }
+    for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+    unsigned long long evals = 0;
+    int top_n = 0;
+    bool repeated = false;
+    if constexpr (NS > 0) {
+        bool tie = false;
+        // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
+        const bool ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap);
+        if (!(ok1 && tie)) {
+            // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
+            // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
+            for (int r = lane; r < k_out; r += 64) {
+                const bool have = r < top_n;
+                out_ids[(size_t)job * k_out + r] = have ? L.top[r].id : -1;
+                out_d[(size_t)job * k_out + r] = have ? L.top[r].dist : __uint_as_float(0x7fc00000u);
+            }
+            if (lane == 0) {
+                out_cnt[job] = ok1 ? top_n : 0;
+                out_flag[job] = ok1 ? 0 : 1;
+                atomicAdd(eval_counter, evals);
+            }
+            return;
+        }
+        // equal distances where the heap layout shows: this wave starts over with the exact traversal
+        V.clear(lane);
+        evals = 0;
+        top_n = 0;
+        repeated = true;
+    }
+    const bool ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
+    // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(c => c.Dist) is a STABLE sort over the heap
+    // array (ToArray(), BinaryHeap.cs:41-44) and only the first k_out survive -- so select the
+    // k_out smallest (float.CompareTo order: NaN first, -0 == +0) with ties broken by array index:
+    // exactly the stable sort's prefix.  Key = (order-preserving bits << 32) | index, wave min.
+    __syncthreads();
+    unsigned long long used = 0; // bit t: entry lane + 64*t already emitted
+    for (int r = 0; r < k_out; ++r) {
+        unsigned long long best = ~0ull;
+        for (int t = 0, i = lane; i < top_n; ++t, i += 64) {
+            if ((used >> t) & 1ull) continue;
+            float d = L.top[i].dist;
+            unsigned u;
+            if (d != d) u = 0u;                      // NaN sorts first
+            else {
+                if (d == 0.0f) d = 0.0f;             // -0 and +0 compare equal
+                u = __float_as_uint(d);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                if (u == 0u) u = 1u;                 // keep NaN's key unique (only -NaN-like bit patterns reach 0)
+            }
+            unsigned long long key = ((unsigned long long)u << 32) | (unsigned)i;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned long long o = __shfl_xor(best, off, 64);
+            best = o < best ? o : best;
+        }
+        if (best == ~0ull) { // fewer than k_out results: pad (HNSWIndexExports.cs:144)
+            if (lane == 0) { out_ids[(size_t)job * k_out + r] = -1; out_d[(size_t)job * k_out + r] = __uint_as_float(0x7fc00000u); }
+            continue;
+        }
+        const int wi = (int)(best & 0xffffffffu);
+        if ((wi & 63) == lane) used |= 1ull << (wi >> 6);
+        if (lane == 0) { ND w = L.top[wi]; out_ids[(size_t)job * k_out + r] = w.id; out_d[(size_t)job * k_out + r] = w.dist; }
+    }
+    if (lane == 0) {
+        out_cnt[job] = ok ? top_n : 0;
+        out_flag[job] = ok ? (repeated ? 2 : 0) : 1; // 2: informational (answered by the exact traversal)
+        atomicAdd(eval_counter, evals);
+    }
+}
+
+// Persistent launch: one wave per block, as many blocks as stay resident; each takes jobs from a
+// shared counter until none are left.  A wave owns one visited bitset and one spill area for the
+// whole launch and leaves the bitset clean after every job, so the scratch is sized by the
+// resident waves (not by the batch) and nothing is memset between launches.
+template <int METRIC, int NS, bool HASHED>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS <= 4 ? 3 : 2))) // 168 VGPRs: three waves per SIMD
+graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
+                    const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
+                    const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
+                    const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
+                    int spill_cap, unsigned *__restrict__ visited, long long vis_words, int *__restrict__ vis_tab, int vis_tab_cap, int k_out,
+                    int *__restrict__ out_ids, float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
+                    unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
+                 vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, (unsigned)(vis_tab_cap - 1), 0, vis_tab_cap / 4 * 3};
+    ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
+    for (;;) {
+        int job = 0;
+        if (lane == 0) job = atomicAdd(job_counter, 1);
+        job = __builtin_amdgcn_readfirstlane(job);
+        if (job >= njobs) break;
+        search_job<METRIC, NS, HASHED>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
+                               V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job, overlap != 0);
+        V.clear(lane);
+    }
+}
+
+// Insert, search half, fused: for one new item, GraphConnector.AddNewConnections' whole loop
+// (GraphConnector.cs:172-181): FindEntryPoint, then for every layer of the item ConnectAtLayer's
+// SearchLayer + RelativeNeighborPruning (:189-190) with the next layer's entry = selected[0]
+// (:216).  One launch serves every layer of every item of a batch (the few multi-layer items
+// clear their visited bitset between layers).  Output per (job, layer): the selected ids in
+// selection order (layer 0 -> slot `job`; layer L >= 1 -> upper slot jobs[].aux + L - 1).
+// jobs[].search_layer = the item's first layer min(level, top).
+template <int METRIC, int NS, bool HASHED>
+__device__ __forceinline__ void insert_job(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                           const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
+                           const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
+                           int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, VisitedSet<HASHED> &V,
+                           int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
+                           int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
+                           unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, bool overlap)
+{
+    const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
+    const int lane = threadIdx.x;
+    SearchJob jb = jobs[job];
+    const GraphView G{adj0, stride0, upper, pool, strideU};
+    const int item = ~jb.qref;
+    const float *q = rows + (size_t)item * dim;
+    double sb = 0.0;
+    if (METRIC == M_COS) sb = row_sn[item];
+    for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+    unsigned long long evals = 0;
+    bool ok = true, repeat = false;
+    const int first_layer = jb.search_layer;
+    for (int layer = first_layer; layer >= 0 && ok; --layer) {
+        if (layer != first_layer) V.clear(lane); // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
+        int top_n = 0;
+        const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
+        bool exact = NS == 0;
+        if constexpr (NS > 0) {
+            bool tie = false;
+            const unsigned long long ev0 = evals;
+            ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap); // Span.Sort consumes all
+            if (!ok) break;
+            // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
+            // then returns them in HEAP order, Heuristic.cs:13-18): this layer again, exact traversal
+            if (tie || top_n < max_edges) {
+                exact = true;
+                repeat = true;
+                evals = ev0;
+                top_n = 0;
+                V.clear(lane);
+            }
+        }
+        if (exact) {
+            ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
+            if (!ok) break;
+        }
+        const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact);
+        int *osel = layer == 0 ? out_sel0 + (size_t)job * sel_stride : out_selU + (size_t)(jb.aux + layer - 1) * sel_stride;
+        for (int i = lane; i < rc; i += 64) osel[i] = L.acc[i];
+        if (lane == 0) { if (layer == 0) out_cnt0[job] = rc; else out_cntU[jb.aux + layer - 1] = rc; }
+        const int next_entry = __builtin_amdgcn_readfirstlane(L.acc[0]); // :216 selected[0] -> bestPeer of the next layer (:179)
+        jb.entry = next_entry;
+        jb.entry_layer = layer - 1;
+        jb.search_layer = layer - 1;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        out_flag[job] = ok ? (repeat ? 2 : 0) : 1; // 2: informational (a layer was answered by the exact traversal)
+        atomicAdd(eval_counter, evals);
+    }
+}
+
+template <int METRIC, int NS, bool HASHED>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS <= 4 ? 3 : 2))) // up to 256 candidates: 168 VGPRs, three waves per SIMD
+graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                           const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
+                           const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
+                           int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
+                           int *__restrict__ vis_tab, int vis_tab_cap, int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
+                           int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
+                           unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
+                 vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, (unsigned)(vis_tab_cap - 1), 0, vis_tab_cap / 4 * 3};
+    ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
+    for (;;) { // persistent, see graph_search_kernel
+        int job = 0;
+        if (lane == 0) job = atomicAdd(job_counter, 1);
+        job = __builtin_amdgcn_readfirstlane(job);
+        if (job >= njobs) break;
+        insert_job<METRIC, NS, HASHED>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
+                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap != 0);
+        V.clear(lane);
+    }
+}
+
+// Insert, link half, on the HBM mirror.  (a) new nodes' own lists.
+#ifdef HNSW_HOST_TU // non-template kernels: only the unit that launches them defines them
+__global__ void __launch_bounds__(64)
+graph_write_rows_kernel(int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool,
+                        int strideU, const int *__restrict__ recs, int row_stride, int *__restrict__ tested0,
+                        int *__restrict__ testedU, int max_edges0)
+{
+    const int *r = recs + (size_t)blockIdx.x * row_stride;
+    const int node = r[0], layer = r[1], cnt = r[2];
+    int *l = layer == 0 ? adj0 + (size_t)node * stride0 : pool + upper[node] + (size_t)(layer - 1) * strideU;
+    if (threadIdx.x == 0) {
+        l[0] = cnt;
+        // a full list can only be the ordered output of the heuristic's greedy pass (fewer candidates
+        // than MaxEdges come back unsorted, Heuristic.cs:13-18): its entries are mutually tested
+        const int me = layer == 0 ? max_edges0 : (max_edges0 >> 1);
+        int *t = layer == 0 ? tested0 + node : testedU + (upper[node] / strideU + (layer - 1));
+        *t = cnt == me ? cnt : 0;
+    }
+    for (int i = threadIdx.x; i < cnt; i += 64) l[1 + i] = r[3 + i];
+}
+#endif
+
+// (b) one wave per (neighbour, layer) list: every back-edge append of the batch, in item order
+// (neighbor.OutEdges[layer].Add(currNode.Id), GraphConnector.cs:207), each overflow pruned in
+// place (PruneOverflow :222-262: distances :230-234, sort + heuristic :235).  Lists are
+// independent, so the outcome equals the reference's sequential loop.
+// next_item(): the next node id to append to this list, in item order, or -1.  out_list (optional):
+// [count, ids...] of the final list for the host.
+template <int METRIC, class NextItem>
+__device__ __forceinline__ void link_group(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, int *__restrict__ adj0,
+                  int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
+                  int node, int layer, NextItem next_item, int max_edges0, int k_cap, int *__restrict__ out_list,
+                  unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU,
+                  unsigned char *smem)
+{
+    const SearchLds L = carve_lds(smem, k_cap, 0, dim, nbcap);
+    // shortcut scratch behind the common carve-up: distances of up to kNewMax new entries to every
+    // entry of the list, and the sorted order as original positions
+    float *Dm = reinterpret_cast<float *>(smem + ((search_lds_bytes(k_cap, 0, dim, true, nbcap) + 15) & ~(size_t)15));
+    int *perm = reinterpret_cast<int *>(Dm + kNewMax * nbcap);
+    const int lane = threadIdx.x;
+    const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1);
+    int *l = layer == 0 ? adj0 + (size_t)node * stride0 : pool + upper[node] + (size_t)(layer - 1) * strideU;
+    const float *q = rows + (size_t)node * dim;
+    double sb = 0.0;
+    if (METRIC == M_COS) sb = row_sn[node];
+    for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+    int cnt = l[0];
+    for (int i = lane; i < cnt; i += 64) L.nbuf[i] = l[1 + i];
+    int *tested_p = layer == 0 ? tested0 + node : testedU + (upper[node] / strideU + (layer - 1));
+    int tested = min(max(*tested_p, 0), cnt); // leading entries that are an ordered, mutually tested heuristic output
+    __syncthreads();
+    unsigned long long evals = 0;
+    PH_DECL();
+    PH(0);
+    for (int item = next_item(); item >= 0; item = next_item()) {
+        if (lane == 0) L.nbuf[cnt] = item; // :207
+        cnt++;
+        __syncthreads();
+        PH_COUNT(6, 1);
+        if (cnt > max_edges) { // :209
+            measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, L.nbuf, L.dbuf, cnt, lane); // Distance(cand, node.Id) :233
+            __syncthreads();
+            evals += (unsigned long long)cnt;
+            int rc = -1;
+            // Shortcut.  The first `tested` entries are the output of an earlier greedy pass over this
+            // very list (same node, same distances): ascending, and every earlier one already passed
+            // the test `dist(s, c) < c.Dist` against every later one (Heuristic.cs:31-35).  Those pairs
+            // need not be measured again; only pairs with one of the entries appended since do.  With
+            // few new entries (typically one: lists are full, every append overflows) that is one
+            // batch of distances per new entry instead of one dependent batch per candidate.
+            const int n = cnt, u = n - tested;
+            if (tested > 0 && u <= kNewMax && n <= 128) { // entries i = lane and i = lane + 64 on each lane
+                const int i1 = lane + 64;
+                const float d0 = lane < n ? L.dbuf[lane] : 0.0f, d1 = i1 < n ? L.dbuf[i1] : 0.0f;
+                const unsigned k0 = f2key(d0), k1 = f2key(d1);
+                bool odd = (lane < n && key_unsafe(d0)) || (i1 < n && key_unsafe(d1));
+                int rank0 = 0, rank1 = 0;
+                for (int t2 = 0; t2 < n; ++t2) { // Span.Sort :22 -- distinct ordinary distances: rank by counting
+                    const unsigned kt = t2 < 64 ? (unsigned)__builtin_amdgcn_readlane((int)k0, t2) : (unsigned)__builtin_amdgcn_readlane((int)k1, t2 - 64);
+                    rank0 += kt < k0 ? 1 : 0;
+                    rank1 += kt < k1 ? 1 : 0;
+                    odd |= lane < n && t2 != lane && kt == k0;
+                    odd |= i1 < n && t2 != i1 && kt == k1;
+                    // the tested prefix must still be ascending (it is, by construction)
+                    odd |= lane < tested && t2 < tested && ((t2 < lane && kt >= k0) || (t2 > lane && kt <= k0));
+                    odd |= i1 < tested && t2 < tested && ((t2 < i1 && kt >= k1) || (t2 > i1 && kt <= k1));
+                }
+                if (__ballot(odd) == 0ull) {
+                    if (lane < n) perm[rank0] = lane;
+                    if (i1 < n) perm[rank1] = i1;
+                    // distances of every new entry to all entries of the list
+                    for (int jn = 0; jn < u; ++jn) {
+                        const int xid = L.nbuf[tested + jn];
+                        const float *xrow = rows + (size_t)xid * dim;
+                        __syncthreads();
+                        for (int t2 = lane; t2 < dim; t2 += 64) L.qs2[t2] = xrow[t2];
+                        double sbx = 0.0;
+                        if (METRIC == M_COS) sbx = row_sn[xid];
+                        __syncthreads();
+                        // a single new entry only meets the old ones (one pass of <= 32 rows instead of two)
+                        const int mrows = u == 1 ? tested : n;
+                        measure_all<METRIC>(rows, row_sn, dim, L.qs2, sbx, L.nbuf, Dm + jn * nbcap, mrows, lane);
+                        evals += (unsigned long long)(u == 1 ? mrows : n - 1);
+                    }
+                    __syncthreads();
+                    // greedy pass :23-40 in sorted order, on the distances at hand
+                    bool acc0 = false, acc1 = false; // entries lane / lane + 64 accepted
+                    unsigned new_acc = 0u;           // bit j: new entry j accepted
+                    rc = 0;
+                    for (int p2 = 0; p2 < n && rc < max_edges; ++p2) {
+                        const int i = perm[p2];
+                        const float di = L.dbuf[i];
+                        bool rej;
+                        if (i < tested) {           // an old entry: only accepted new ones can object
+                            rej = false;
+                            for (int jn = 0; jn < u; ++jn)
+                                if ((new_acc >> jn) & 1u) rej = rej || Dm[jn * nbcap + i] < di;
+                        } else {                    // a new entry: everything accepted so far can object
+                            const float *Dj = Dm + (i - tested) * nbcap;
+                            const float e0 = lane < n ? Dj[lane] : 0.0f, e1 = i1 < n ? Dj[i1] : 0.0f;
+                            rej = __ballot((acc0 && e0 < di) || (acc1 && e1 < di)) != 0ull;
+                        }
+                        if (!rej) {
+                            if (lane == i) acc0 = true;
+                            if (i1 == i) acc1 = true;
+                            if (i >= tested) new_acc |= 1u << (i - tested);
+                            if (lane == 0) L.acc[rc] = L.nbuf[i];
+                            rc++;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (rc < 0) {
+                for (int i = lane; i < cnt; i += 64) L.top[i] = ND{L.nbuf[i], L.dbuf[i]};
+                rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, cnt, max_edges, L, lane, evals);
+            }
+            for (int i = lane; i < rc; i += 64) L.nbuf[i] = L.acc[i]; // node.OutEdges[layer] = newOut :236
+            cnt = rc;
+            tested = rc; // the whole list is a greedy output now
+            __syncthreads();
+        }
+    }
+    if (lane == 0) { l[0] = cnt; *tested_p = tested; if (out_list) out_list[0] = cnt; }
+    for (int i = lane; i < cnt; i += 64) { l[1 + i] = L.nbuf[i]; if (out_list) out_list[1 + i] = L.nbuf[i]; }
+    if (lane == 0) atomicAdd(eval_counter, evals);
+    __syncthreads();
+}
+
+// groups prepared by the host: one block per group, items in CSR order
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, int *__restrict__ adj0,
+                  int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
+                  const int *__restrict__ g_node, const int *__restrict__ g_layer, const int *__restrict__ g_off,
+                  const int *__restrict__ g_count, const int *__restrict__ g_items, int max_edges0, int k_cap,
+                  int *__restrict__ out_lists, int list_stride,
+                  unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int g = blockIdx.x;
+    int t = g_off[g];
+    const int t_end = g_count ? t + g_count[g] : g_off[g + 1]; // CSR offsets, or start + count per group
+    link_group<METRIC>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, g_node[g], g_layer[g],
+                       [&]() { return t < t_end ? g_items[t++] : -1; }, max_edges0, k_cap,
+                       out_lists ? out_lists + (size_t)g * list_stride : (int *)nullptr, eval_counter, nbcap, tested0, testedU, smem);
+}
+
+// ---- the same with the grouping done on the device (no host work between the insert search and
+// the link half).  Per adjacency-list slot (layer 0: the node id; upper layers: cap_n + list index
+// in the pool) three counters, all zero between batches: appends, fill cursor, start offset. ----
+struct LinkPlan {
+    int *cnt, *fill, *off;                      // per list slot
+    int *g_node, *g_layer, *g_start, *g_count;  // per group (a list that receives appends), any order
+    int *items;                                 // batch positions of the appending items, grouped
+    int *counters;                              // [0] groups, [1] item cursor, [3] first guard that fired
+    long long cap_n;
+    long long n_slots, n_nodes; // capacities, for the guards below: an index outside them is reported, never used
+    int g_cap, n_jobs;
+};
+#define LINK_GUARD(cond, code) if (!(cond)) { atomicCAS(&P.counters[3], 0, (code)); continue; }
+__device__ __forceinline__ long long link_slot(const LinkPlan &P, const int64_t *upper, int strideU, int nb, int layer)
+{
+    return layer == 0 ? (long long)nb : P.cap_n + upper[nb] / strideU + (layer - 1);
+}
+// pass 1 (count = true): the new nodes' own lists go into the mirror (currNode.OutEdges[layer] =
+// selected, GraphConnector.cs:192), appends are counted per target list and the lists that receive
+// any are enumerated.  pass 2 (count = false): the appends are filed per list.
+template <bool COUNT>
+__global__ void __launch_bounds__(64)
+link_plan_kernel(const SearchJob *__restrict__ jobs, const int *__restrict__ sel0, const int *__restrict__ cnt0,
+                 const int *__restrict__ selU, const int *__restrict__ cntU, int sel_stride, int *__restrict__ adj0, int stride0,
+                 const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU, int *__restrict__ tested0,
+                 int *__restrict__ testedU, int max_edges0, LinkPlan P)
+{
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const SearchJob jb = jobs[t];
+    const int id = ~jb.qref;
+    for (int layer = jb.search_layer; layer >= 0; --layer) {
+        const int *sel = layer == 0 ? sel0 + (size_t)t * sel_stride : selU + (size_t)(jb.aux + layer - 1) * sel_stride;
+        const int sc = layer == 0 ? cnt0[t] : cntU[jb.aux + layer - 1];
+        LINK_GUARD(id >= 0 && id < P.n_nodes && sc >= 0 && sc <= sel_stride && sc <= (layer == 0 ? max_edges0 : (max_edges0 >> 1)), 1);
+        if (COUNT) {
+            int *l = layer == 0 ? adj0 + (size_t)id * stride0 : pool + upper[id] + (size_t)(layer - 1) * strideU;
+            if (lane == 0) {
+                l[0] = sc;
+                const int me = layer == 0 ? max_edges0 : (max_edges0 >> 1);
+                int *tp = layer == 0 ? tested0 + id : testedU + (upper[id] / strideU + (layer - 1));
+                *tp = sc == me ? sc : 0; // see graph_write_rows_kernel
+            }
+            for (int e = lane; e < sc; e += 64) l[1 + e] = sel[e];
+        }
+        for (int e = lane; e < sc; e += 64) {
+            const int nb = sel[e];
+            LINK_GUARD(nb >= 0 && nb < P.n_nodes, 2);
+            const long long slot = link_slot(P, upper, strideU, nb, layer);
+            LINK_GUARD(slot >= 0 && slot < P.n_slots, 3);
+            if (COUNT) {
+                if (atomicAdd(&P.cnt[slot], 1) == 0) {
+                    const int g = atomicAdd(&P.counters[0], 1);
+                    LINK_GUARD(g < P.g_cap, 4);
+                    P.g_node[g] = nb;
+                    P.g_layer[g] = layer;
+                }
+            } else {
+                const int p = atomicAdd(&P.fill[slot], 1);
+                const long long at = (long long)P.off[slot] + p;
+                LINK_GUARD(at >= 0 && at < P.g_cap, 5);
+                P.items[at] = t;
+            }
+        }
+    }
+}
+#ifdef HNSW_HOST_TU // non-template kernels: only the unit that launches them defines them
+__global__ void __launch_bounds__(256)
+link_offsets_kernel(const int64_t *__restrict__ upper, int strideU, LinkPlan P)
+{
+    const int G = min(P.counters[0], P.g_cap);
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < G; g += gridDim.x * 256) {
+        const long long slot = link_slot(P, upper, strideU, P.g_node[g], P.g_layer[g]);
+        LINK_GUARD(slot >= 0 && slot < P.n_slots, 6);
+        const int c = P.cnt[slot];
+        const int start = atomicAdd(&P.counters[1], c);
+        LINK_GUARD(c >= 0 && start >= 0 && (long long)start + c <= P.g_cap, 7);
+        P.g_start[g] = start;
+        P.g_count[g] = c;
+        P.off[slot] = start;
+    }
+}
+#endif
+// one block per group: its items (batch positions, filed in arbitrary order) become node ids in batch
+// order -- repeatedly the smallest position not yet taken; groups are tiny -- and the slot's
+// counters return to zero for the next batch
+#ifdef HNSW_HOST_TU // non-template kernels: only the unit that launches them defines them
+__global__ void __launch_bounds__(64)
+link_order_kernel(const SearchJob *__restrict__ jobs, const int64_t *__restrict__ upper, int strideU, int *__restrict__ items_out, LinkPlan P)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int node = P.g_node[g], layer = P.g_layer[g], start = P.g_start[g], n_items = P.g_count[g];
+    if (!(node >= 0 && node < P.n_nodes && layer >= 0 && start >= 0 && n_items >= 0 && (long long)start + n_items <= P.g_cap)) {
+        atomicCAS(&P.counters[3], 0, 8);
+        return;
+    }
+    int last = -1;
+    for (int k = 0; k < n_items; ++k) {
+        int best = 0x7fffffff;
+        for (int i = lane; i < n_items; i += 64) {
+            const int p = P.items[start + i];
+            if (p > last && p < best) best = p;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+        if (best >= P.n_jobs) { atomicCAS(&P.counters[3], 0, 9); return; }
+        last = best;
+        if (lane == 0) items_out[start + k] = ~jobs[best].qref;
+    }
+    if (lane == 0) {
+        const long long slot = link_slot(P, upper, strideU, node, layer);
+        P.cnt[slot] = 0;
+        P.fill[slot] = 0;
+    }
+}
+#endif
+
+// Flat id<->id pairs: 8 lanes per pair (hnswdev_dist_pair_batch).  Ids outside the uploaded rows
+// give NaN and raise `guard` (see slot_distance_kernel).
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+pair_distance_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                     const int *__restrict__ a_ids, const int *__restrict__ b_ids, float *__restrict__ out, int n,
+                     long long n_rows, int *__restrict__ guard)
+{
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int j = threadIdx.x & 7;
+    const bool act = g < n;
+    int a = a_ids[act ? g : 0], b = b_ids[act ? g : 0];
+    const bool bad = (unsigned long long)(long long)a >= (unsigned long long)n_rows || (unsigned long long)(long long)b >= (unsigned long long)n_rows;
+    if (bad) { a = 0; b = 0; }
+    double sa = 0.0, sb = 0.0;
+    if (METRIC == M_COS) { sa = row_sn[a]; sb = row_sn[b]; }
+    float r = group_metric<METRIC>(rows + (size_t)a * dim, rows + (size_t)b * dim, dim, j, sa, sb);
+    if (act && j == 0) {
+        out[g] = bad ? __uint_as_float(0x7fc00000u) : r;
+        if (bad) atomicOr(guard, 1);
+    }
+}
+
+// sqrt((double)|row|^2) with |row|^2 summed in f32 in the reference's lane order
+// (CosineMetric.cs:40-41,47 / :43-44,48 and the tail :83-84): 8 lanes per row.
+#ifdef HNSW_HOST_TU // non-template kernels: only the unit that launches them defines them
+__global__ void __launch_bounds__(256)
+row_sqrtnorm_kernel(const float *__restrict__ rows, int dim, long long first, int n, double *__restrict__ out)
+{
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int j = threadIdx.x & 7;
+    const bool act = g < n;
+    const float *a = rows + (size_t)(first + (act ? g : 0)) * dim;
+    float p = lane_chain<M_COS>(a, a, dim, j);
+    float s = collapse_cos(p);
+    if (dim & 7) s = scalar_tail<M_COS>(s, a, a, dim);
+    if (act && j == 0) out[first + g] = sqrt_rn((double)s);
+}
+#endif
+
+// exposed for tests: sqrt_rn over an array
+#ifdef HNSW_HOST_TU // non-template kernels: only the unit that launches them defines them
+__global__ void sqrt_rn_kernel(const double *in, double *out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sqrt_rn(in[i]);
+}
+#endif
+
+
+// Explicit instantiations of the two traversal kernels live in traverse_<metric>_<search|insert>.hip;
+// every other unit only declares them.
+#define HNSW_FOR_EACH_TRAVERSAL(X, M) \
+    X(M, 0, false) X(M, 1, false) X(M, 2, false) X(M, 4, false) X(M, 8, false) \
+    X(M, 0, true) X(M, 1, true) X(M, 2, true) X(M, 4, true) X(M, 8, true)
+#define HNSW_SEARCH_SIGNATURE(PREFIX, M, NS, H)                                                                                  \
+    PREFIX template __global__ void graph_search_kernel<M, NS, H>(                                                              \
+        const float *__restrict__, const double *__restrict__, const float *__restrict__, const double *__restrict__, int,      \
+        const int *__restrict__, int, const int64_t *__restrict__, const int *__restrict__, int, const SearchJob *__restrict__,  \
+        int, int, ND *__restrict__, int, unsigned *__restrict__, long long, int *__restrict__, int, int, int *__restrict__,      \
+        float *__restrict__, int *__restrict__, int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int);
+#define HNSW_INSERT_SIGNATURE(PREFIX, M, NS, H)                                                                                  \
+    PREFIX template __global__ void graph_insert_search_kernel<M, NS, H>(                                                       \
+        const float *__restrict__, const double *__restrict__, int, const int *__restrict__, int, const int64_t *__restrict__,   \
+        const int *__restrict__, int, const SearchJob *__restrict__, int, int, ND *__restrict__, int, int, unsigned *__restrict__, \
+        long long, int *__restrict__, int, int *__restrict__, int *__restrict__, int *__restrict__, int *__restrict__, int,      \
+        int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int);
+#define HNSW_DECLARE_TRAVERSAL(M, NS, H) HNSW_SEARCH_SIGNATURE(extern, M, NS, H) HNSW_INSERT_SIGNATURE(extern, M, NS, H)
+#define HNSW_DEFINE_TRAVERSAL(M, NS, H) HNSW_SEARCH_SIGNATURE(, M, NS, H) HNSW_INSERT_SIGNATURE(, M, NS, H)
+#define HNSW_DEFINE_SEARCH(M, NS, H) HNSW_SEARCH_SIGNATURE(, M, NS, H)
+#define HNSW_DEFINE_INSERT(M, NS, H) HNSW_INSERT_SIGNATURE(, M, NS, H)
+
+} // namespace hnsw

@@ -31,6 +31,8 @@ void set_error(const std::string &s)
 } // namespace
 
 #define API extern "C" __attribute__((visibility("default")))
+// serialises the calls on one handle (HnswIndex::mutex)
+#define LOCK_INDEX(h) std::lock_guard<std::mutex> index_lock_(static_cast<HnswIndex *>(h)->mutex())
 
 API int hnsw_get_last_error_utf8(void *buf, int buf_len) // :27-39
 {
@@ -86,6 +88,7 @@ API int hnsw_add(void *handle, const float *vectors, int count, int dim, int *ou
 {
     if (!handle) return 0;
     if (!vectors || count <= 0 || dim <= 0) return 0;
+    LOCK_INDEX(handle);
     std::string err;
     int n = static_cast<HnswIndex *>(handle)->add(vectors, count, dim, out_ids, err);
     if (n < 0) { set_error(err); return -1; }
@@ -96,6 +99,7 @@ API int hnsw_remove(void *handle, const int *ids, int count) // :102-117
 {
     if (!handle) return 0;
     if (!ids || count <= 0) return 0;
+    LOCK_INDEX(handle);
     std::string err;
     if (static_cast<HnswIndex *>(handle)->remove(ids, count, err) < 0) { set_error(err); return -1; }
     return 0;
@@ -106,6 +110,7 @@ API int hnsw_knn_query(void *handle, const float *vectors, int count, int dim, i
     if (!handle) return 0;
     if (count <= 0) return 0;
     if (!vectors || !out_ids || !out_dists || dim <= 0) { set_error("System.ArgumentNullException: hnsw_knn_query"); return -1; }
+    LOCK_INDEX(handle);
     std::string err;
     int rc = static_cast<HnswIndex *>(handle)->knn_query(vectors, count, dim, k, out_ids, out_dists, err);
     if (rc < 0) { set_error(err); return -1; }
@@ -122,7 +127,10 @@ API int hnsw_range_query(void *handle, const float *vectors, int count, int dim,
     for (int i = 0; i < count; ++i) { out_ids[i] = nullptr; out_dists[i] = nullptr; counts[i] = 0; }
     std::string err;
     std::vector<std::vector<hnsw::NodeDist>> res;
-    if (static_cast<HnswIndex *>(handle)->range_query(vectors, count, dim, range, res, err) < 0) { set_error(err); return -1; }
+    {
+        LOCK_INDEX(handle);
+        if (static_cast<HnswIndex *>(handle)->range_query(vectors, count, dim, range, res, err) < 0) { set_error(err); return -1; }
+    }
     for (int i = 0; i < count; ++i) { // callee-allocated per-query arrays (Marshal.AllocHGlobal :172-173), freed by hnsw_free_results
         const int n = (int)res[(size_t)i].size();
         if (n > 0) {
@@ -181,11 +189,17 @@ API int hnsw_set_distribution_rate(float dist_rate) // :247 -- crosses the ABI a
 }
 
 // ---- introspection / counters ----
-API int hnsw_mi355x_count(void *h) { return h ? static_cast<HnswIndex *>(h)->count() : 0; }
+API int hnsw_mi355x_count(void *h)
+{
+    if (!h) return 0;
+    LOCK_INDEX(h);
+    return static_cast<HnswIndex *>(h)->count();
+}
 // measurement aid: queries resident in HBM across calls (bench.py's timed region)
 API int hnsw_mi355x_set_queries(void *h, const float *queries, int count, int dim)
 {
     if (!h || !queries || count <= 0 || dim <= 0) return -1;
+    LOCK_INDEX(h);
     std::string err;
     if (static_cast<HnswIndex *>(h)->set_resident_queries(queries, count, dim, err) < 0) { set_error(err); return -1; }
     return 0;
@@ -193,30 +207,49 @@ API int hnsw_mi355x_set_queries(void *h, const float *queries, int count, int di
 API int hnsw_mi355x_knn_query_resident(void *h, int k, int *out_ids, float *out_dists)
 {
     if (!h || !out_ids || !out_dists) return -1;
+    LOCK_INDEX(h);
     std::string err;
     if (static_cast<HnswIndex *>(h)->knn_query_resident(k, out_ids, out_dists, err) < 0) { set_error(err); return -1; }
     return 0;
 }
-API int hnsw_mi355x_dim(void *h) { return h ? static_cast<HnswIndex *>(h)->dim() : 0; }
-API int hnsw_mi355x_length(void *h) { return h ? static_cast<HnswIndex *>(h)->graph().length : 0; }
+API int hnsw_mi355x_dim(void *h)
+{
+    if (!h) return 0;
+    LOCK_INDEX(h);
+    return static_cast<HnswIndex *>(h)->dim();
+}
+API int hnsw_mi355x_length(void *h)
+{
+    if (!h) return 0;
+    LOCK_INDEX(h);
+    return static_cast<HnswIndex *>(h)->graph().length;
+}
 API int hnsw_mi355x_active_ids(void *h, int *out, int cap)
 {
     if (!h || !out) return -1;
+    LOCK_INDEX(h);
     const hnsw::Graph &g = static_cast<HnswIndex *>(h)->graph();
     int n = std::min(g.count, cap);
     std::memcpy(out, g.dense.data(), sizeof(int) * (size_t)n);
     return g.count;
 }
-API int hnsw_mi355x_entry_point(void *h) { return h ? static_cast<HnswIndex *>(h)->graph().entry : -1; }
+API int hnsw_mi355x_entry_point(void *h)
+{
+    if (!h) return -1;
+    LOCK_INDEX(h);
+    return static_cast<HnswIndex *>(h)->graph().entry;
+}
 API int hnsw_mi355x_node_max_layer(void *h, int id)
 {
     if (!h) return -1;
+    LOCK_INDEX(h);
     const hnsw::Graph &g = static_cast<HnswIndex *>(h)->graph();
     return (id < 0 || id >= g.length) ? -1 : g.level[(size_t)id];
 }
 API int hnsw_mi355x_get_out_edges(void *h, int id, int layer, int *out, int cap)
 {
     if (!h) return -1;
+    LOCK_INDEX(h);
     const hnsw::Graph &g = static_cast<HnswIndex *>(h)->graph();
     if (id < 0 || id >= g.length || layer < 0 || layer > g.level[(size_t)id]) return -1;
     const int *l = g.list(id, layer);
@@ -227,6 +260,7 @@ API int hnsw_mi355x_get_out_edges(void *h, int id, int layer, int *out, int cap)
 API int hnsw_mi355x_export_levels(void *h, int *out, int cap)
 {
     if (!h || !out) return -1;
+    LOCK_INDEX(h);
     const hnsw::Graph &g = static_cast<HnswIndex *>(h)->graph();
     int n = std::min(g.length, cap);
     std::memcpy(out, g.level.data(), sizeof(int) * (size_t)n);
@@ -237,6 +271,7 @@ API int hnsw_mi355x_export_levels(void *h, int *out, int cap)
 API int hnsw_mi355x_export_edges(void *h, int layer, int *counts, int *edges, int stride, int cap)
 {
     if (!h || !counts || !edges || layer < 0) return -1;
+    LOCK_INDEX(h);
     const hnsw::Graph &g = static_cast<HnswIndex *>(h)->graph();
     int n = std::min(g.length, cap);
     for (int i = 0; i < n; ++i) {
@@ -253,6 +288,7 @@ API int hnsw_mi355x_export_edges(void *h, int layer, int *counts, int *edges, in
 API int hnsw_mi355x_serialize(void *h, const char *path_utf8)
 {
     if (!h) return 0;
+    LOCK_INDEX(h);
     std::string err;
     if (static_cast<HnswIndex *>(h)->serialize(path_utf8, err) < 0) { set_error(err); return -1; }
     return 0;
@@ -278,10 +314,16 @@ API void *hnsw_mi355x_deserialize(const char *distance_metric, const char *path_
     }
     return ix;
 }
-API uint64_t hnsw_mi355x_graph_hash(void *h) { return h ? static_cast<HnswIndex *>(h)->graph_hash() : 0; }
+API uint64_t hnsw_mi355x_graph_hash(void *h)
+{
+    if (!h) return 0;
+    LOCK_INDEX(h);
+    return static_cast<HnswIndex *>(h)->graph_hash();
+}
 API int hnsw_mi355x_get_stats(void *h, hnswdev_stats *out)
 {
     if (!h || !out) return -1;
+    LOCK_INDEX(h);
     hnsw::Device *d = static_cast<HnswIndex *>(h)->device();
     if (!d) { std::memset(out, 0, sizeof *out); return 0; }
     d->get_stats(out);
@@ -290,12 +332,14 @@ API int hnsw_mi355x_get_stats(void *h, hnswdev_stats *out)
 API int hnsw_mi355x_reset_stats(void *h)
 {
     if (!h) return -1;
+    LOCK_INDEX(h);
     if (hnsw::Device *d = static_cast<HnswIndex *>(h)->device()) d->reset_stats();
     return 0;
 }
 API int hnsw_mi355x_set_profiling(void *h, int enabled)
 {
     if (!h) return -1;
+    LOCK_INDEX(h);
     static_cast<HnswIndex *>(h)->set_profiling(enabled != 0);
     return 0;
 }
@@ -335,6 +379,16 @@ API void hnswhost_test_random_next(int seed, int n, int *out)
 {
     hnsw::DotnetRandom r(seed);
     for (int i = 0; i < n; ++i) out[i] = r.internal_sample();
+}
+// NextSingle's redraw rule on an injected stream of InternalSample() values
+API float hnswhost_test_next_single_from_samples(const int *samples, int n, int *used)
+{
+    for (int i = 0; i < n; ++i) {
+        const float f = hnsw::DotnetRandom::single_of_sample(samples[i]);
+        if (f < 1.0f) { *used = i + 1; return f; }
+    }
+    *used = n;
+    return -1.0f;
 }
 API void hnswhost_test_random_levels(int seed, double rate, int n, int *out)
 {

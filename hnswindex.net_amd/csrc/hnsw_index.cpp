@@ -910,33 +910,47 @@ bool HnswIndex::insert_batch(const std::vector<int> &bid, std::string &err)
 
 int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::string &err)
 {
+    if (failed(err)) return -1;
     if (!ensure_dim(dim, err)) return -1;
     Tick t_total(g_pt.add_total);
     double t_nodes0 = g_pt.on ? now_s() : 0;
     // GraphData.AddItem (src/HNSWIndex/GraphData.cs:79-118): one RNG draw per item, in order;
-    // vacated slots are reused first when removals are allowed (:85-91)
+    // vacated slots are reused first when removals are allowed (:85-91).
+    // Everything that can be refused is checked BEFORE the index changes: the levels are drawn on a
+    // copy of the generator and validated, and the capacity for the new slots is reserved; only then
+    // are the generator advanced and the nodes appended.  A device failure after that point leaves
+    // nodes without rows or links, so it marks the index failed (every later call reports it).
     if (p_.allow_removals && !graph_.removed_stack.empty() && !refresh_host_lists(err)) return -1; // slot reuse rewrites host rows
+    std::vector<int> lvls((size_t)count);
+    DotnetRandom rng = rng_;
+    int live = 0;
+    for (int i = 0; i < count; ++i) {
+        const int lvl = level_from_uniform(rng.next_single(), p_.distribution_rate);
+        if (lvl > 200) { err = "level draw out of range"; return -1; }
+        lvls[(size_t)i] = lvl;
+        live += lvl >= 0;
+    }
+    const int reusable = p_.allow_removals ? (int)graph_.removed_stack.size() : 0;
+    if (!ensure_capacity((long long)graph_.length + std::max(0, live - reusable), err)) return -1;
+    rng_ = rng;
     std::vector<int> ids((size_t)count), fresh; // fresh: the new nodes, in insertion order
     fresh.reserve((size_t)count);
     bool any_reused = false;
     const int first_new = graph_.length;
     graph_.reserve(graph_.length + count);
     for (int i = 0; i < count; ++i) {
-        int lvl = level_from_uniform(rng_.next_single(), p_.distribution_rate);
-        if (lvl < 0) { ids[(size_t)i] = -1; ++skipped_; continue; } // :82
-        if (lvl > 200) { err = "level draw out of range"; return -1; }
-        ids[(size_t)i] = graph_.add_node(lvl, p_.allow_removals, &any_reused);
+        if (lvls[(size_t)i] < 0) { ids[(size_t)i] = -1; ++skipped_; continue; } // :82
+        ids[(size_t)i] = graph_.add_node(lvls[(size_t)i], p_.allow_removals, &any_reused);
         fresh.push_back(ids[(size_t)i]);
     }
-    if (!ensure_capacity(graph_.length, err)) return -1;
     if (g_pt.on) { g_pt.add_nodes += now_s() - t_nodes0; t_nodes0 = now_s(); }
     if (any_reused) graph_dirty_ = true; // existing rows of the HBM mirror changed: full re-upload
     // rows -> HBM (id == row index)
     if (!any_reused && (int)fresh.size() == count) {
-        if (!dev_->upload_rows(first_new, count, vectors)) { err = get_dev_error(); return -1; }
+        if (!dev_->upload_rows(first_new, count, vectors)) return fail(get_dev_error(), err);
     } else {
         for (int i = 0; i < count; ++i)
-            if (ids[(size_t)i] >= 0 && !dev_->upload_rows(ids[(size_t)i], 1, vectors + (size_t)i * dim)) { err = get_dev_error(); return -1; }
+            if (ids[(size_t)i] >= 0 && !dev_->upload_rows(ids[(size_t)i], 1, vectors + (size_t)i * dim)) return fail(get_dev_error(), err);
     }
     if (g_pt.on) g_pt.add_upload += now_s() - t_nodes0;
     // GraphConnector.ConnectNewNode (:24-47), batched
@@ -950,7 +964,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
         bid.clear();
         bid.push_back(fresh[(size_t)p]);
         if (graph_.level[(size_t)fresh[(size_t)p]] > top) { // new entry point: alone, under the "entry point lock" (:36-41)
-            if (!insert_batch(bid, err)) return -1;
+            if (!insert_batch(bid, err)) return fail(err, err);
             graph_.entry = fresh[(size_t)p++];
             continue;
         }
@@ -958,7 +972,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
         const int b = std::min(bmax, std::max(1, linked / kBatchGrowthDiv));
         while ((int)bid.size() < b && p + (int)bid.size() < m && graph_.level[(size_t)fresh[(size_t)(p + (int)bid.size())]] <= top)
             bid.push_back(fresh[(size_t)(p + (int)bid.size())]);
-        if (!insert_batch(bid, err)) return -1;
+        if (!insert_batch(bid, err)) return fail(err, err);
         p += (int)bid.size();
     }
     if (out_ids) for (int i = 0; i < count; ++i) out_ids[i] = ids[(size_t)i];
@@ -1033,6 +1047,7 @@ int HnswIndex::knn_query_device(const float *, int count, int k, int *out_ids, f
 int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *out_ids, float *out_dists, std::string &err)
 {
     if (count <= 0) return 0;
+    if (failed(err)) return -1;
     if (k < 1 || graph_.entry < 0 || graph_.count <= 0) { // HNSWIndex.cs:109: empty result lists, padded by the export
         for (long long j = 0; j < (long long)count * std::max(k, 0); ++j) { out_ids[j] = -1; out_dists[j] = std::numeric_limits<float>::quiet_NaN(); }
         return 0;
@@ -1054,6 +1069,7 @@ int HnswIndex::knn_query_resident(int k, int *out_ids, float *out_dists, std::st
 {
     const int count = resident_queries_;
     if (count <= 0) return 0;
+    if (failed(err)) return -1;
     if (k < 1 || graph_.entry < 0 || graph_.count <= 0) {
         for (long long j = 0; j < (long long)count * std::max(k, 0); ++j) { out_ids[j] = -1; out_dists[j] = std::numeric_limits<float>::quiet_NaN(); }
         return 0;
@@ -1066,6 +1082,7 @@ int HnswIndex::knn_query_resident(int k, int *out_ids, float *out_dists, std::st
 int HnswIndex::range_query(const float *queries, int count, int dim, float range, std::vector<std::vector<NodeDist>> &out, std::string &err)
 {
     out.assign((size_t)std::max(count, 0), {});
+    if (failed(err)) return -1;
     if (count <= 0 || graph_.entry < 0) return 0; // HNSWIndex.cs:146
     if (!ensure_dim(dim, err)) return -1;
     if (!refresh_host_lists(err)) return -1;
@@ -1093,6 +1110,7 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
 {
     if (!p_.allow_removals) { err = "System.InvalidOperationException: Removals are disabled in this index instance."; return -1; } // :85-86
     if (count <= 0) return 0;
+    if (failed(err)) return -1;
     if (!refresh_host_lists(err)) return -1;
     for (int t = 0; t < count; ++t) {
         const int id = ids[t];
@@ -1177,6 +1195,7 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
 int HnswIndex::serialize(const char *path, std::string &err)
 {
     if (!path) { err = "System.ArgumentNullException: filePath"; return -1; }
+    if (failed(err)) return -1;
     if (!refresh_host_lists(err)) return -1;
     SnapshotParams sp;
     sp.max_edges = p_.max_edges;

@@ -3,6 +3,7 @@
 // gfx950 backend through the lock-step engine.
 #pragma once
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -67,8 +68,27 @@ public:
     uint64_t graph_hash();
     void set_profiling(bool on) { profiling_ = on; if (dev_) dev_->set_profiling(on); }
 
+    // One caller at a time per index: the reference promises that operations of one type may
+    // overlap on an index (/root/reference/README.md:64-65; BatchKnnQuery / Add(List) are
+    // Parallel.For, HNSWIndex.cs:70-78,129-137).  Here every call already fans out over the whole
+    // GPU, and the resident query set, the per-wave scratch and the staging buffers belong to the
+    // index, so overlapping calls on one handle are serialised: every handle-taking export holds
+    // this mutex for the duration of the call.  Calls on different handles run concurrently.
+    std::mutex &mutex() { return mu_; }
+
 private:
+    std::mutex mu_;
     HnswIndex() = default;
+    // A device failure in the middle of an Add leaves appended nodes without rows / links: the
+    // index then refuses every further call with the original message.
+    std::string failed_msg_;
+    bool failed(std::string &err) const { if (failed_msg_.empty()) return false; err = failed_msg_; return true; }
+    int fail(const std::string &why, std::string &err)
+    {
+        failed_msg_ = "HNSWIndex MI355X backend: the index is unusable after a failed Add (" + why + ")";
+        err = failed_msg_;
+        return -1;
+    }
     bool ensure_dim(int dim, std::string &err);
     bool ensure_capacity(long long need, std::string &err);
     bool insert_batch(const std::vector<int> &bid, std::string &err);

@@ -140,7 +140,16 @@ struct DotnetRandom {
         return ret;
     }
     double sample() { return internal_sample() * (1.0 / INT32_MAX); }
-    float next_single() { return (float)sample(); }
+    // NextSingle of the seeded generator: (float)Sample(), drawn again while the cast rounds up to
+    // 1.0f (samples >= 2147483583 do; the BCL rejects them so that the result stays in [0, 1)).
+    static inline float single_of_sample(int internal) { return (float)(internal * (1.0 / INT32_MAX)); }
+    float next_single()
+    {
+        for (;;) {
+            const float f = single_of_sample(internal_sample());
+            if (f < 1.0f) return f;
+        }
+    }
 };
 
 // src/HNSWIndex/GraphData.cs:211-219.  random == 0 gives +inf: reported as -1, the value the

@@ -7,12 +7,12 @@
 namespace hnsw {
 
 LockStepEngine::LockStepEngine(Device *dev, int nslots, int stride, int nthreads)
-    : dev_(dev), stride_(stride), nthreads_(std::max(1, nthreads))
+    : ctx_(dev), stride_(stride), nthreads_(std::max(1, nthreads))
 {
     half_ = std::max(1, nslots / 2);
-    sb_[0] = dev_->alloc_step(half_, stride_);
-    sb_[1] = dev_->alloc_step(half_, stride_);
-    if (!sb_[0] || !sb_[1]) return;
+    rec_stride_ = stride_ + 2; // [cnt, qidx, ids[stride]] per slot (include/hnsw_mi355x.h)
+    for (int g = 0; g < 2; ++g)
+        if (hnswdev_step_buffers(ctx_, g, half_, stride_, &rec_[g], &dist_[g]) != 0) return;
     slots_[0].resize((size_t)half_);
     slots_[1].resize((size_t)half_);
     t_evals_.assign((size_t)nthreads_, 0);
@@ -31,8 +31,7 @@ LockStepEngine::~LockStepEngine()
     }
     cv_.notify_all();
     for (auto &w : workers_) w.join();
-    if (sb_[0]) dev_->free_step(sb_[0]);
-    if (sb_[1]) dev_->free_step(sb_[1]);
+    // the step buffers belong to the context
 }
 
 void LockStepEngine::barrier()
@@ -57,13 +56,12 @@ void LockStepEngine::half_step(int t, int g)
 {
     const int lo = (int)((long long)t * used_half_ / used_threads_);
     const int hi = (int)((long long)(t + 1) * used_half_ / used_threads_);
-    StepBuffers *sb = sb_[g];
     uint64_t evals = 0;
     int active = 0, maxslot = 0;
     for (int s = lo; s < hi; ++s) {
         Slot &sl = slots_[g][(size_t)s];
-        int *rec = sb->rec + (size_t)s * sb->rec_stride;
-        SlotIO io{rec + 2, rec, rec + 1, sb->dist + (size_t)s * stride_, stride_};
+        int *rec = rec_[g] + (size_t)s * rec_stride_;
+        SlotIO io{rec + 2, rec, rec + 1, dist_[g] + (size_t)s * stride_, stride_};
         if (sl.job && sl.awaiting) {
             sl.job->consume(io, sl.scratch);
             sl.awaiting = false;
@@ -95,13 +93,19 @@ void LockStepEngine::worker_main(int t)
 {
     uint64_t seen = 0;
     for (;;) {
+        bool take_part;
         {
+            // run() publishes used_threads_ / used_half_ / src_ and every reset under mu_, together
+            // with ++run_gen_; a worker acts on exactly the generation it observes here.  run() does
+            // not return (and so cannot start the next generation) before every participating worker
+            // has left the loop below, and a non-participant touches nothing outside this block.
             std::unique_lock<std::mutex> lk(mu_);
             cv_.wait(lk, [&] { return run_gen_ != seen; });
             seen = run_gen_;
             if (shutting_down_) return;
+            take_part = t < used_threads_;
         }
-        if (t >= used_threads_) continue;
+        if (!take_part) continue;
         int g = 0;
         for (;;) {
             half_step(t, g);
@@ -118,26 +122,29 @@ bool LockStepEngine::run(JobSource &src, long long njobs_hint)
 {
     if (!ok_) return false;
     if (njobs_hint <= 0) return true;
-    if (!dev_->bind_thread()) return false;
-    src_ = &src;
-    used_half_ = (int)std::min<long long>(half_, std::max<long long>(1, (njobs_hint + 1) / 2));
-    used_threads_ = (int)std::min<long long>(nthreads_, std::max<long long>(1, njobs_hint / 48));
-    used_threads_ = std::min(used_threads_, used_half_);
-    done_.store(false, std::memory_order_release);
-    failed_.store(false, std::memory_order_release);
-    left_count_.store(0, std::memory_order_release);
-    bar_count_.store(0, std::memory_order_release);
-    for (int g = 0; g < 2; ++g) {
-        // slots beyond used_half_ stay idle with cnt == 0 from allocation/previous runs
-        for (int s = 0; s < used_half_; ++s) { slots_[g][(size_t)s].job = nullptr; slots_[g][(size_t)s].awaiting = false; }
-    }
-    if (used_threads_ > 1) {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            ++run_gen_;
+    // the sets may have been re-created since (another client of the same context grew them)
+    for (int g = 0; g < 2; ++g)
+        if (hnswdev_step_buffers(ctx_, g, half_, stride_, &rec_[g], &dist_[g]) != 0) return false;
+    const int use_half = (int)std::min<long long>(half_, std::max<long long>(1, (njobs_hint + 1) / 2));
+    int use_threads = (int)std::min<long long>(nthreads_, std::max<long long>(1, njobs_hint / 48));
+    use_threads = std::min(use_threads, use_half);
+    {
+        // the whole run descriptor is published in one critical section with the generation bump
+        std::lock_guard<std::mutex> lk(mu_);
+        src_ = &src;
+        used_half_ = use_half;
+        used_threads_ = use_threads;
+        done_.store(false, std::memory_order_release);
+        failed_.store(false, std::memory_order_release);
+        left_count_.store(0, std::memory_order_release);
+        bar_count_.store(0, std::memory_order_release);
+        for (int g = 0; g < 2; ++g) {
+            // slots beyond used_half_ stay idle with cnt == 0 from allocation/previous runs
+            for (int s = 0; s < used_half_; ++s) { slots_[g][(size_t)s].job = nullptr; slots_[g][(size_t)s].awaiting = false; }
         }
-        cv_.notify_all();
+        ++run_gen_;
     }
+    if (used_threads_ > 1) cv_.notify_all();
     bool pend[2] = {false, false};
     int active[2] = {0, 0};
     int g = 0;
@@ -154,11 +161,11 @@ bool LockStepEngine::run(JobSource &src, long long njobs_hint)
         active[g] = act;
         if (!failed_.load()) {
             if (evals > 0) {
-                if (!dev_->launch_step(sb_[g], maxslot, evals)) failed_.store(true);
+                if (hnswdev_step_submit(ctx_, g, maxslot) != 0) failed_.store(true);
                 else pend[g] = true;
             }
             if (pend[g ^ 1]) {
-                if (!dev_->wait_step(sb_[g ^ 1])) failed_.store(true);
+                if (hnswdev_step_wait(ctx_, g ^ 1) != 0) failed_.store(true);
                 pend[g ^ 1] = false;
             }
         }
@@ -172,9 +179,8 @@ bool LockStepEngine::run(JobSource &src, long long njobs_hint)
         // wait until every worker has observed done_ and left its loop
         while (left_count_.load(std::memory_order_acquire) < used_threads_ - 1) _mm_pause();
     }
-    if (pend[0]) dev_->wait_step(sb_[0]);
-    if (pend[1]) dev_->wait_step(sb_[1]);
-    src_ = nullptr;
+    if (pend[0]) (void)hnswdev_step_wait(ctx_, 0);
+    if (pend[1]) (void)hnswdev_step_wait(ctx_, 1);
     return !failed_.load();
 }
 

@@ -78,14 +78,18 @@ private:
     void half_step(int t, int g);
     void barrier();
 
-    Device *dev_;
+    // The engine reaches the GPU only through the inner C ABI (include/hnsw_mi355x.h:
+    // hnswdev_step_buffers / _submit / _wait) -- the same three calls a C# host P/Invokes.
+    void *ctx_;  // hnswdev context
     int half_;   // slots per group
     int stride_, nthreads_;
     bool ok_ = false;
-    StepBuffers *sb_[2] = {nullptr, nullptr};
+    int *rec_[2] = {nullptr, nullptr};     // the context's pinned step records, set 0 / 1
+    float *dist_[2] = {nullptr, nullptr};  // ... and distances
+    int rec_stride_ = 0;
     std::vector<Slot> slots_[2];
 
-    // per-run state
+    // per-run state; workers read the descriptor they were woken for under mu_ (run_gen_)
     JobSource *src_ = nullptr;
     int used_half_ = 0, used_threads_ = 1;
     std::vector<uint64_t> t_evals_;

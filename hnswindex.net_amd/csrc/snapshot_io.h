@@ -501,6 +501,33 @@ inline bool read_snapshot(const uint8_t *buf, size_t len, SnapshotParams &p, Gra
     if (!has_entry && g.count > 0) entry = 0; // see header: zero is never on the wire
     if (g.count > 0 && (entry < 0 || entry >= n)) return bad("EntryPointId");
     if (entry >= n) return bad("EntryPointId");
+    // Post-pass over every list, now that all levels and the active set are known (nodes are parsed
+    // in order, so an edge could not be checked against its target's level while reading it).  The
+    // traversals -- host and device -- index `pool + upper[target]` for an edge met on an upper layer
+    // and trust lists to hold live, distinct ids: a snapshot that breaks that is refused here rather
+    // than read out of bounds later.
+    for (int i = 0; i < n; ++i) {
+        if (seen[(size_t)i] && g.removed[(size_t)i]) return bad("an active node is flagged IsRemoved");
+        if (!seen[(size_t)i] && !g.removed[(size_t)i]) return bad("a node is neither in ActiveNodes nor flagged IsRemoved");
+    }
+    if (g.count > 0 && !seen[(size_t)entry]) return bad("EntryPointId names a removed node");
+    {
+        std::vector<int> stamp((size_t)n, -1);
+        int list_no = 0;
+        for (int a = 0; a < g.count; ++a) {
+            const int i = g.dense[(size_t)a];
+            for (int layer = 0; layer <= g.level[(size_t)i]; ++layer, ++list_no) {
+                const int *l = g.list(i, layer);
+                for (int e = 1; e <= l[0]; ++e) {
+                    const int t = l[e];
+                    if (g.level[(size_t)t] < layer) return bad("edge to a node that does not have that layer");
+                    if (!seen[(size_t)t]) return bad("edge from a live node to a removed node");
+                    if (stamp[(size_t)t] == list_no) return bad("duplicate id in an EdgeList");
+                    stamp[(size_t)t] = list_no;
+                }
+            }
+        }
+    }
     g.entry = entry;
     return true;
 }

@@ -1,0 +1,7 @@
+// traverse_ucos_search.hip -- instantiates graph_search_kernel for M_UCOS (every register-set count,
+// both visited-set representations).  Device code: device_kernels.h; the split exists for build time.
+#include "device_kernels.h"
+
+namespace hnsw {
+HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_SEARCH, M_UCOS)
+} // namespace hnsw

@@ -168,7 +168,9 @@ typedef struct hnswdev_stats {
     uint64_t search_repeats;      /* traversals repeated on the device with the exact two-heap variant (equal distances) */
 } hnswdev_stats;
 
-/* All return 0 on success, < 0 on error (message via hnswdev_last_error). */
+/* All return 0 on success, < 0 on error (message via hnswdev_ctx_last_error / hnswdev_last_error).
+ * Calls on ONE context are serialised by the library (a mutex per context); different contexts
+ * run concurrently. */
 
 /* Creates a context on HIP device `device` holding up to `capacity` rows of `dim` float32
  * in one contiguous row-major HBM matrix (id == row index, GraphData.cs:95-115). */
@@ -183,9 +185,38 @@ int hnswdev_upload_rows(void *ctx, int first_id, int n, const float *rows);
 /* Reads rows back (parity checks). */
 int hnswdev_download_rows(void *ctx, int first_id, int n, float *rows);
 
-/* Distance(int a, TVector b) for many (query, candidate-list) pairs at once:
+/* Uploads the query set of a batch of searches ONCE (nq x dim host floats; for cosine the norms are
+ * computed on the device); records then name a query by its row index in this set.  Replaces the
+ * previous resident set. */
+int hnswdev_set_queries(void *ctx, const float *queries, int nq);
+
+/* ---- the batched step, asynchronous and double-buffered ---------------------------------------
+ * This is what replaces the scalar delegate inside the traversal loops (GraphNavigator.cs:70,
+ * :163, :231; Heuristic.cs:34; GraphConnector.cs:233): the host advances MANY traversals together;
+ * each step every live traversal states one record -- which vector (a resident query, or a stored
+ * row) against which candidate rows -- and ONE launch evaluates all of them.
+ *
+ * The context owns two buffer sets (set = 0 | 1) in pinned host memory with an HBM mirror; they
+ * are (re)allocated only when nslots / stride grow, never per step.  Layout of set `set`:
+ *     rec [s * (stride + 2) + 0]      = cnt   number of candidate ids of slot s (0: idle slot)
+ *     rec [s * (stride + 2) + 1]      = qidx  >= 0: resident query index;  < 0: ~row_id (id<->id)
+ *     rec [s * (stride + 2) + 2 ...]  = ids   candidate row ids, cnt <= stride
+ *     dist[s * stride + c]            = metric(row[ids[c]], that vector) after hnswdev_step_wait
+ * hnswdev_step_submit enqueues ONE host->HBM copy of the used records, ONE kernel and ONE copy of
+ * the distances back, on the context's stream, and returns; hnswdev_step_wait blocks until that
+ * set's distances have landed.  While one set is in flight the host consumes / fills the other.
+ * A record naming a row or query that was never uploaded is not dereferenced: its distances come
+ * back NaN and hnswdev_step_wait returns -1. */
+int hnswdev_step_buffers(void *ctx, int set, int nslots, int stride, int **rec, float **dist);
+int hnswdev_step_submit(void *ctx, int set, int nslots_used);
+int hnswdev_step_wait(void *ctx, int set);
+
+/* Synchronous conveniences over the same two sets (nothing is allocated per call once they exist):
+ * Distance(int a, TVector b) for many (query, candidate-list) pairs at once:
  * out[j] = metric(row[cand_ids[j]], queries[i]) for cand_offsets[i] <= j < cand_offsets[i+1].
- * queries: nq x dim host floats; cand_offsets: nq+1 ints; synchronous. */
+ * queries: nq x dim host floats, uploaded as the resident set -- or NULL to use the set already
+ * resident (hnswdev_set_queries), so that a batch of searches uploads its queries once;
+ * cand_offsets: nq+1 ints. */
 int hnswdev_dist_query_batch(void *ctx, const float *queries, int nq, const int *cand_offsets, const int *cand_ids,
                              float *out);
 /* Distance(int a, int b): out[j] = metric(row[a_ids[j]], row[b_ids[j]]); synchronous. */
@@ -214,7 +245,11 @@ int hnswdev_sync(void *ctx);
 int hnswdev_set_profiling(void *ctx, int enabled);
 int hnswdev_get_stats(void *ctx, hnswdev_stats *out);
 int hnswdev_reset_stats(void *ctx);
+/* Last error, process-wide (creation failures have no context yet) ... */
 int hnswdev_last_error(char *buf, int buf_len);
+/* ... and of one context: calls on different contexts never overwrite each other's message.
+ * Both copy at most buf_len-1 bytes, NUL-terminate and return the byte count needed. */
+int hnswdev_ctx_last_error(void *ctx, char *buf, int buf_len);
 /* Number of visible HIP devices (>= 0), or < 0 on error. */
 int hnswdev_device_count(void);
 

@@ -73,6 +73,8 @@ def lib():
         L.orc_random_next_double.argtypes = [ct.c_int, ct.c_int, ct.POINTER(ct.c_double)]
         L.orc_random_next_single.argtypes = [ct.c_int, ct.c_int, _F]
         L.orc_random_levels.argtypes = [ct.c_int, ct.c_double, ct.c_int, _I]
+        L.orc_next_single_from_samples.argtypes = [_I, ct.c_int, _I]
+        L.orc_next_single_from_samples.restype = ct.c_float
         L.orc_sort_nd.argtypes = [_I, _F, ct.c_int]
         L.orc_heap_script.argtypes = [ct.c_int, _I, _F, ct.c_int, _I, _F, _I, _I]
         L.orc_search_layer.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, _F, _I, _F]

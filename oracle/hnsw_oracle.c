@@ -273,7 +273,16 @@ static int rng_internal_sample(dotnet_rng *r)
 }
 
 static double rng_sample(dotnet_rng *r) { return rng_internal_sample(r) * (1.0 / INT32_MAX); }
-static float rng_next_single(dotnet_rng *r) { return (float)rng_sample(r); }
+/* NextSingle() of the seeded generator: (float)Sample(), drawn again while the cast rounds up to
+ * 1.0f, so the result stays in [0, 1) (samples >= 2147483583 round up).  BCL behaviour, restated. */
+static float single_of_sample(int internal) { return (float)(internal * (1.0 / INT32_MAX)); }
+static float rng_next_single(dotnet_rng *r)
+{
+    for (;;) {
+        float f = single_of_sample(rng_internal_sample(r));
+        if (f < 1.0f) return f;
+    }
+}
 
 /* src/HNSWIndex/GraphData.cs:211-219: (int)(-Math.Log(random) * distRate).
  * A non-finite or out-of-range product (random == 0) is returned as -1, which is what
@@ -1329,6 +1338,17 @@ ORC_API void orc_random_next_single(int seed, int n, float *out)
     dotnet_rng r;
     rng_init(&r, seed);
     for (int i = 0; i < n; i++) out[i] = rng_next_single(&r);
+}
+/* The redraw rule on an injected stream of InternalSample() values: returns the NextSingle()
+ * result and how many samples it consumed (-1.0f when the stream ran out). */
+ORC_API float orc_next_single_from_samples(const int *samples, int n, int *used)
+{
+    for (int i = 0; i < n; i++) {
+        float f = single_of_sample(samples[i]);
+        if (f < 1.0f) { *used = i + 1; return f; }
+    }
+    *used = n;
+    return -1.0f;
 }
 ORC_API void orc_random_levels(int seed, double rate, int n, int *out)
 {

@@ -103,13 +103,82 @@ def test_rows_round_trip_and_reserve_growth(net):
         dev.upload_rows(4999, rows[:2])
 
 
-def test_bad_ids_are_rejected_on_the_host(net):
+def test_bad_ids_are_refused_not_dereferenced(net):
+    # ids are guarded inside the kernels: a bad one yields NaN and an error return, never a fault
     dev = net.DeviceBackend(16, "sq_euclid", capacity=10)
-    dev.upload_rows(0, uniform(10, 16, 1))
-    with pytest.raises(RuntimeError, match="outside uploaded rows"):
+    rows = uniform(10, 16, 1)
+    dev.upload_rows(0, rows)
+    with pytest.raises(RuntimeError, match="outside the uploaded data"):
         dev.dist_query_batch(uniform(1, 16, 2), np.array([0, 1], np.int32), np.array([10], np.int32))
     with pytest.raises(RuntimeError, match="outside uploaded rows"):
         dev.dist_pair_batch(np.array([0], np.int32), np.array([-1], np.int32))
+    # the context keeps working, and the error belongs to it alone
+    other = net.DeviceBackend(16, "sq_euclid", capacity=10)
+    assert other.last_error() == "" and "outside uploaded rows" in dev.last_error()
+    q = uniform(1, 16, 2)
+    got = dev.dist_query_batch(q, np.array([0, 3], np.int32), np.array([9, 0, 4], np.int32))
+    assert got.tobytes() == oracle.dist_query_rows("sq_euclid", rows, q[0], [9, 0, 4]).tobytes()
+
+
+@pytest.mark.parametrize("metric", METRICS)
+def test_step_api_double_buffered(net, metric):
+    # The inner boundary as a foreign host drives it: queries uploaded once, two context-owned
+    # pinned buffer sets, submit / wait, one set in flight while the other is filled.
+    n, dim, nq, stride, nslots = 4000, 96, 64, 40, 512
+    rows, q = uniform(n, dim, 21), uniform(nq, dim, 22)
+    if metric == "ucosine":
+        rows, q = normalize_f32(rows), normalize_f32(q)
+    dev = net.DeviceBackend(dim, metric, capacity=n)
+    dev.upload_rows(0, rows)
+    dev.set_queries(q)
+    rng = np.random.default_rng(5)
+    sets = [dev.step_buffers(g, nslots, stride) for g in (0, 1)]
+    addr = [(r.ctypes.data, d.ctypes.data) for r, d in sets]
+    plans = []
+    for step in range(6):
+        g = step & 1
+        rec, dist = sets[g]
+        if step >= 2:       # this set's previous step must have landed before it is refilled
+            dev.step_wait(g)
+        used = int(rng.integers(1, nslots + 1))
+        cnt = rng.integers(0, stride + 1, used).astype(np.int32)
+        qidx = rng.integers(0, nq, used).astype(np.int32)
+        pair = rng.random(used) < 0.3                      # some slots measure row <-> row (Distance(int, int))
+        qidx[pair] = ~rng.integers(0, n, int(pair.sum())).astype(np.int32)
+        ids = rng.integers(0, n, (used, stride)).astype(np.int32)
+        rec[:used, 0], rec[:used, 1], rec[:used, 2:] = cnt, qidx, ids
+        dev.step_submit(g, used)
+        plans.append((g, used, cnt.copy(), qidx.copy(), ids.copy()))
+        if step >= 1:       # verify the OTHER set's step while this one is in flight
+            pg, pused, pcnt, pq, pids = plans[step - 1]
+            dev.step_wait(pg)
+            pdist = sets[pg][1]
+            for s_ in range(0, pused, 7):
+                v = rows[~pq[s_]] if pq[s_] < 0 else q[pq[s_]]
+                want = oracle.dist_query_rows(metric, rows, v, pids[s_, :pcnt[s_]])
+                assert want.tobytes() == pdist[s_, :pcnt[s_]].tobytes()
+    dev.step_wait(0); dev.step_wait(1)
+    # nothing was reallocated: the same pinned buffers every time
+    assert [(r.ctypes.data, d.ctypes.data) for r, d in (dev.step_buffers(g, nslots, stride) for g in (0, 1))] == addr
+    # the resident query set serves dist_query_batch without a re-upload
+    off = np.arange(0, 5 * 30 + 1, 30, dtype=np.int32)
+    cid = rng.integers(0, n, 150).astype(np.int32)
+    got = dev.dist_query_batch(None, off, cid)
+    for i in range(5):
+        assert got[30 * i:30 * i + 30].tobytes() == oracle.dist_query_rows(metric, rows, q[i], cid[30 * i:30 * i + 30]).tobytes()
+    # guards: a record naming a row that was never uploaded comes back NaN, wait reports it
+    rec, dist = sets[0]
+    rec[0, 0], rec[0, 1], rec[0, 2:4] = 2, 0, [5, n + 7]
+    dev.step_submit(0, 1)
+    with pytest.raises(RuntimeError, match="outside the uploaded data"):
+        dev.step_wait(0)
+    assert np.isnan(dist[0, 1]) and dist[0, 0] == oracle.dist_query_rows(metric, rows, q[0], [5])[0]
+    rec[0, 0] = stride + 1                                  # more ids than the slot holds
+    dev.step_submit(0, 1)
+    with pytest.raises(RuntimeError):
+        dev.step_wait(0)
+    with pytest.raises(RuntimeError, match="already in flight|more slots"):
+        dev.step_submit(0, nslots + 1)
 
 
 def test_linearity_style_properties_at_full_row_size(net):

@@ -180,3 +180,35 @@ def test_malformed_snapshots_are_errors(lib, tmp_path):
     fails(tweak(entry=n), "EntryPointId")
     fails(tweak(length=n - 1), "Length")
     fails(tweak(removed=[0]), "RemovedIndexes")  # an active id cannot be vacant
+    # --- lists that would send a traversal out of bounds (post-pass over all lists) ---
+    lv = [ref.max_layer(i) for i in range(n)]
+    flat = next(i for i in range(n) if lv[i] == 0)                 # a node with layer 0 only
+    tall = next(i for i in range(n) if lv[i] >= 1)                 # a node that has layer 1
+    def nodes_with(edit):
+        nodes = [dict(id=i, out=[(ref.edges(i, l).tolist(), len(ref.edges(i, l))) for l in range(lv[i] + 1)]) for i in range(n)]
+        edit(nodes)
+        return nodes
+    def edge_to_missing_layer(nodes):                              # (tall, layer 1) -> a node without layer 1
+        e, _ = nodes[tall]["out"][1]
+        nodes[tall]["out"][1] = ([flat] + e[1:], max(1, len(e)))
+    fails(tweak(nodes=nodes_with(edge_to_missing_layer)), "does not have that layer")
+    def duplicate_edge(nodes):
+        e, c = nodes[flat]["out"][0]
+        nodes[flat]["out"][0] = ([e[0], e[0]] + e[2:], max(2, c))
+    fails(tweak(nodes=nodes_with(duplicate_edge)), "duplicate id")
+    # a live node pointing at a vacated slot; an entry point that was removed
+    victim = next(i for i in range(n) if i != ref.entry_point and i != flat)
+    def drop(nodes):
+        nodes[victim]["removed"] = True
+    live = [i for i in range(n) if i != victim]
+    assert any(victim in ref.edges(i, 0).tolist() for i in live)
+    fails(tweak(nodes=nodes_with(drop), active=live, removed=[victim], count=n - 1), "removed node")
+    ep = ref.entry_point
+    def drop_ep(nodes):
+        nodes[ep]["removed"] = True
+        for nd in nodes:
+            nd["out"] = [([x for x in e[:c] if x != ep], len([x for x in e[:c] if x != ep])) for e, c in nd["out"]]
+    fails(tweak(nodes=nodes_with(drop_ep), active=[i for i in range(n) if i != ep], removed=[ep], count=n - 1), "EntryPointId names a removed node")
+    fails(tweak(nodes=nodes_with(drop)), "flagged IsRemoved")      # flagged but still listed active
+    fails(tweak(active=live, count=n - 1), "neither in ActiveNodes nor flagged")
+
