@@ -43,7 +43,11 @@ class Stats(ct.Structure):
                 ("timed_evals", ct.c_uint64), ("kernel_ms", ct.c_double), ("row_bytes", ct.c_uint64),
                 ("search_launches", ct.c_uint64), ("search_evals", ct.c_uint64), ("search_timed_launches", ct.c_uint64),
                 ("search_timed_evals", ct.c_uint64), ("search_kernel_ms", ct.c_double), ("search_overflows", ct.c_uint64),
-                ("search_repeats", ct.c_uint64)]
+                ("search_repeats", ct.c_uint64),
+                ("insert_launches", ct.c_uint64), ("insert_evals", ct.c_uint64), ("insert_timed_launches", ct.c_uint64),
+                ("insert_timed_evals", ct.c_uint64), ("insert_kernel_ms", ct.c_double),
+                ("link_launches", ct.c_uint64), ("link_evals", ct.c_uint64), ("link_timed_launches", ct.c_uint64),
+                ("link_timed_evals", ct.c_uint64), ("link_kernel_ms", ct.c_double), ("visited_hash_launches", ct.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -142,7 +142,7 @@ public:
     // Two step-buffer sets owned by the context (pinned host + HBM mirror), (re)allocated only when
     // they grow: the host fills set A's records while the GPU works on set B.  The lock-step engine
     // of this library is a client of exactly these calls.
-    bool step_buffers(int set, int nslots, int stride, int **rec, float **dist);
+    bool step_buffers(int set, int nslots, int stride, int **rec, float **dist, bool internal = false);
     bool step_submit(int set, int nslots_used); // async: H2D, kernel, D2H on the context's stream
     bool step_wait(int set);                    // distances of that set are in its pinned array
     long long resident_queries() const { return n_queries_; }
@@ -234,7 +234,7 @@ private:
         bool busy = false, timed = false;
         int ngroups = 0;
     } lset_[2];
-    StepBuffers *abi_sb_[2] = {nullptr, nullptr}; // context-owned step-buffer sets of the C ABI
+    StepBuffers *abi_sb_[4] = {nullptr, nullptr, nullptr, nullptr}; // context-owned step-buffer sets: 0/1 handed out by hnswdev_step_buffers, 2/3 private to dist_query_batch (so it never moves buffers a caller holds)
     int *d_guard_ = nullptr;                      // guard flag of pair_distance_kernel
     int *pair_dev_ = nullptr;                     // dist_pair_batch: [a | b | out] on the device
     size_t pair_dev_cap_ = 0;

@@ -383,9 +383,9 @@ bool Device::wait_step(StepBuffers *sb)
 }
 
 // ---- step buffers of the C ABI ---------------------------------------------------------------
-bool Device::step_buffers(int set, int nslots, int stride, int **rec, float **dist)
+bool Device::step_buffers(int set, int nslots, int stride, int **rec, float **dist, bool internal)
 {
-    if (set < 0 || set > 1 || nslots <= 0 || stride <= 0 || !rec || !dist) { set_dev_error("step_buffers: bad argument"); return false; }
+    if (set < 0 || set > (internal ? 3 : 1) || nslots <= 0 || stride <= 0 || !rec || !dist) { set_dev_error("step_buffers: bad argument"); return false; }
     StepBuffers *&sb = abi_sb_[set];
     if (sb && sb->in_flight) { set_dev_error("step_buffers: the set is in flight (call hnswdev_step_wait first)"); return false; }
     if (!sb || sb->nslots < nslots || sb->stride != stride) {
@@ -701,12 +701,18 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         HIP_OK(hipStreamSynchronize(st)); // the job staging buffer is reused by the next chunk
         stats_.search_launches++;
         stats_.search_evals += *h_ev;
+        stats_.insert_launches++;
+        stats_.insert_evals += *h_ev;
+        if (vis_tab) stats_.visited_hash_launches++;
         if (timed) {
             float ms = 0.f;
             HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
             stats_.search_kernel_ms += ms;
             stats_.search_timed_launches++;
             stats_.search_timed_evals += *h_ev;
+            stats_.insert_kernel_ms += ms;
+            stats_.insert_timed_launches++;
+            stats_.insert_timed_evals += *h_ev;
         }
     }
     HIP_OK(hipMemcpyAsync(h_sel0, s_sel_, b_sel0, hipMemcpyDeviceToHost, st));
@@ -948,12 +954,17 @@ bool Device::link_batch_planned(int njobs, int n_upper, int max_edges0)
     }
     stats_.search_launches++;
     stats_.search_evals += *h_ev;
+    stats_.link_launches++;
+    stats_.link_evals += *h_ev;
     if (timed) {
         float ms = 0.f;
         HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
         stats_.search_kernel_ms += ms;
         stats_.search_timed_launches++;
         stats_.search_timed_evals += *h_ev;
+        stats_.link_kernel_ms += ms;
+        stats_.link_timed_launches++;
+        stats_.link_timed_evals += *h_ev;
     }
     return true;
 }
@@ -980,12 +991,17 @@ bool Device::link_batch_finish(int set, const int **out_lists)
     if (ls.ngroups > 0) {
         stats_.search_launches++;
         stats_.search_evals += *ls.h_ev;
+        stats_.link_launches++;
+        stats_.link_evals += *ls.h_ev;
         if (ls.timed) {
             float ms = 0.f;
             HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ls.ev_start, (hipEvent_t)ls.ev_stop));
             stats_.search_kernel_ms += ms;
             stats_.search_timed_launches++;
             stats_.search_timed_evals += *ls.h_ev;
+            stats_.link_kernel_ms += ms;
+            stats_.link_timed_launches++;
+            stats_.link_timed_evals += *ls.h_ev;
         }
     }
     return true;
@@ -1091,6 +1107,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         }
         memcpy(out_flag + off, h_flag, sizeof(int) * (size_t)nj);
         const unsigned long long ev = *h_ev;
+        if (vis_tab) stats_.visited_hash_launches++;
         stats_.search_launches++;
         stats_.search_evals += ev;
         if (timed) {
@@ -1184,15 +1201,16 @@ bool Device::dist_query_batch(const float *queries, int nq, const int *offsets, 
     else if (nq > n_queries_) { set_dev_error("dist_query_batch: queries == NULL needs a resident query set of at least nq rows (hnswdev_set_queries)"); return false; }
     const int stride = 64, NS = 8192;
     int *rec[2]; float *dist[2];
+    StepBuffers **sets = abi_sb_ + 2; // private sets: a caller's hnswdev_step_buffers pointers stay valid
     for (int g = 0; g < 2; ++g)
-        if (!step_buffers(g, NS, stride, &rec[g], &dist[g])) return false;
-    const int rec_stride = abi_sb_[0]->rec_stride;
+        if (!step_buffers(2 + g, NS, stride, &rec[g], &dist[g], true)) return false;
+    const int rec_stride = sets[0]->rec_stride;
     std::vector<std::pair<int, int>> where[2]; // (global offset, count) per slot of each set
     bool pend[2] = {false, false};
     auto collect = [&](int g) -> bool {
         if (!pend[g]) return true;
         pend[g] = false;
-        if (!wait_step(abi_sb_[g])) return false;
+        if (!wait_step(sets[g])) return false;
         for (size_t sidx = 0; sidx < where[g].size(); ++sidx)
             memcpy(out + where[g][sidx].first, dist[g] + sidx * (size_t)stride, sizeof(float) * (size_t)where[g][sidx].second);
         return true;
@@ -1220,7 +1238,7 @@ bool Device::dist_query_batch(const float *queries, int nq, const int *offsets, 
             pos += take;
         }
         if (used == 0) break;
-        ok = launch_step(abi_sb_[g], used, ev);
+        ok = launch_step(sets[g], used, ev);
         pend[g] = ok;
         g ^= 1;
     }

@@ -166,6 +166,14 @@ typedef struct hnswdev_stats {
     double search_kernel_ms;      /* HIP-event durations of the timed search launches */
     uint64_t search_overflows;    /* traversals handed back to the lock-step path */
     uint64_t search_repeats;      /* traversals repeated on the device with the exact two-heap variant (equal distances) */
+    /* Add's two halves, counted separately as well (they are also part of the search_* totals above):
+     * graph_insert_search_kernel (descent + per-layer search + RelativeNeighborPruning) and the link half
+     * (link_plan / link_offsets / link_order + graph_link_kernel: appends and PruneOverflow) */
+    uint64_t insert_launches, insert_evals, insert_timed_launches, insert_timed_evals;
+    double insert_kernel_ms;
+    uint64_t link_launches, link_evals, link_timed_launches, link_timed_evals;
+    double link_kernel_ms;
+    uint64_t visited_hash_launches; /* traversal launches whose visited sets were per-wave hash tables (graphs above 4M nodes) */
 } hnswdev_stats;
 
 /* All return 0 on success, < 0 on error (message via hnswdev_ctx_last_error / hnswdev_last_error).
@@ -197,7 +205,9 @@ int hnswdev_set_queries(void *ctx, const float *queries, int nq);
  * row) against which candidate rows -- and ONE launch evaluates all of them.
  *
  * The context owns two buffer sets (set = 0 | 1) in pinned host memory with an HBM mirror; they
- * are (re)allocated only when nslots / stride grow, never per step.  Layout of set `set`:
+ * are (re)allocated only when nslots grows or stride changes, never per step, and no other call
+ * moves them: the pointers stay valid until the next hnswdev_step_buffers for that set that asks
+ * for more (or hnswdev_destroy).  Layout of set `set`:
  *     rec [s * (stride + 2) + 0]      = cnt   number of candidate ids of slot s (0: idle slot)
  *     rec [s * (stride + 2) + 1]      = qidx  >= 0: resident query index;  < 0: ~row_id (id<->id)
  *     rec [s * (stride + 2) + 2 ...]  = ids   candidate row ids, cnt <= stride

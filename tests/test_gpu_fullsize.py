@@ -1,10 +1,17 @@
-"""GPU tier, BASELINE.json's full C2 size (1M x 128, M=16, efC=200, ef=128): properties that do not
-need a second implementation to finish in seconds at this size."""
+"""GPU tier, BASELINE.json's configurations at their full sizes: C2 (1M x 128, M=16, efC=200, ef=128),
+C3 (1M x 768 ucosine, M=32, efC=400) and the C4 index (10M x 128, queried in the 12 500-row calls each of
+the 8 ranks makes -- the hashed visited set is what runs at that size).  At these sizes the second
+implementation cannot build the graph in seconds, so each case checks (i) structure and query properties
+that need no second implementation and (ii) a bit-exact sample: the product-built graph is imported into
+the oracle (as bench.py's cpu_baseline leg does) and 2 000 queries must return the same ids and the same
+distance bits from both."""
+import gc
+
 import numpy as np
 import pytest
 
 import oracle
-from common import uniform
+from common import normalize_f32, uniform
 
 pytestmark = pytest.mark.gpu
 
@@ -60,3 +67,110 @@ def test_full_size_query_properties(built):
     hit = sid[:, 0] == np.arange(2000)
     assert hit.mean() > 0.3 and (sd[hit, 0] == 0).all() and (sd[~hit, 0] > 0).all()
     assert ix.stats()["search_overflows"] == 0
+
+
+# ------------------------------------------------------------------ C3 and C4 at full size
+def _uniform_chunked(n, dim, seed, chunk=1_000_000):
+    """uniform(n, dim, seed) filled chunk by chunk (the generator's stream is the same; no 2x peak)."""
+    rng = np.random.default_rng(seed)
+    x = np.empty((n, dim), dtype=np.float32)
+    for i in range(0, n, chunk):
+        x[i:i + chunk] = rng.random((min(chunk, n - i), dim), dtype=np.float32)
+    return x
+
+
+def _check_structure(ix, n, max_edges):
+    lv = ix.levels()
+    assert lv.size == n and ix.count == n
+    assert abs((lv >= 1).mean() - 1 / 16) < 0.002          # level law at DistributionRate 1/ln 16 (GraphData.cs:211-219)
+    assert lv[ix.entry_point] == lv.max()
+    stride = 2 * max_edges + 2
+    counts, edges = ix.export_edges(0, stride)
+    assert counts.min() >= 1 and counts.max() <= 2 * max_edges
+    step = 2_000_000                                        # the per-list checks, in slices (memory)
+    for lo in range(0, n, step):
+        c, e = counts[lo:lo + step], edges[lo:lo + step]
+        valid = np.arange(stride)[None, :] < c[:, None]
+        flat = e[valid]
+        rows = np.repeat(np.arange(lo, lo + c.size), c)
+        assert flat.min() >= 0 and flat.max() < n and (flat != rows).all()
+        srt = np.sort(np.where(valid, e, -1 - np.arange(stride)[None, :]), axis=1)
+        assert (np.diff(srt, axis=1) != 0).all()            # no duplicate edge inside a list
+    return lv
+
+
+def _oracle_sample_is_bit_exact(ix, x, q, k, metric, max_edges, ef_search, ef_construction, got_ids, got_d, sample):
+    n, dim = x.shape
+    ref = oracle.OracleIndex(dim, metric, max_edges=max_edges, min_nn=ef_search, max_candidates=ef_construction,
+                             collection_size=n, allow_removals=False, use_avx=True)
+    lv = ix.levels()
+    layers = [ix.export_edges(L, 2 * max_edges + 2 if L == 0 else max_edges + 2) for L in range(int(lv.max()) + 1)]
+    ref.import_graph(x, lv, ix.entry_point, layers)
+    del layers
+    assert ref.graph_hash() == ix.graph_hash()
+    want_ids, want_d = ref.knn_query(q[:sample], k, threads=16)
+    assert (want_ids == got_ids[:sample]).all()
+    assert want_d.tobytes() == np.ascontiguousarray(got_d[:sample]).tobytes()
+    del ref
+    gc.collect()
+
+
+def test_c3_full_size_1m_768_ucosine():
+    # BASELINE configs[2]: 1M x 768 float32, unit-norm rows, ucosine, M=32, efConstruction=400
+    import hnswindex
+    n, dim, M = 1_000_000, 768, 32
+    x = _uniform_chunked(n, dim, 65537, chunk=250_000)
+    for i in range(0, n, 250_000):                           # Utils.Normalize-style unit rows, in float32
+        x[i:i + 250_000] = normalize_f32(x[i:i + 250_000])
+    ix = hnswindex.Index(dim, "ucosine")
+    ix.set_collection_size(n); ix.set_max_edges(M); ix.set_max_candidates(400); ix.set_min_nn(128); ix.set_allow_removals(False)
+    ids = ix.add(x)
+    assert (ids == np.arange(n)).all()
+    _check_structure(ix, n, M)
+    q = normalize_f32(uniform(4000, dim, 65538))
+    ids10, d10 = ix.knn_query(q, 10)
+    ids5, d5 = ix.knn_query(q, 5)
+    assert (ids10[:, :5] == ids5).all() and d10[:, :5].tobytes() == d5.tobytes()
+    assert (ids10 >= 0).all() and (np.diff(d10, axis=1) >= 0).all()
+    assert (np.sort(ids10, axis=1)[:, 1:] != np.sort(ids10, axis=1)[:, :-1]).all()
+    for i in range(0, 4000, 100):                            # each reported distance = the metric of that stored row, bit for bit
+        assert oracle.dist_query_rows("ucosine", x, q[i], ids10[i]).tobytes() == d10[i].tobytes()
+    assert ix.stats()["search_overflows"] == 0
+    _oracle_sample_is_bit_exact(ix, x, q, 10, "ucosine", M, 128, 400, ids10, d10, 2000)
+    del ix, x
+    gc.collect()
+
+
+def test_c4_size_10m_128_in_12500_query_calls():
+    # BASELINE configs[3]: 10M x 128 float32 sq_euclid, 100k queries sharded over 8 GPUs = 12 500 per rank
+    # and call.  One GPU here plays one rank: it holds the whole index (replicated, SURVEY.md 8e) and
+    # answers shards 0 and 5 of the 8 exactly as `knn_query_sharded` would hand them over.
+    import hnswindex
+    n, dim, M = 10_000_000, 128, 16
+    x = _uniform_chunked(n, dim, 65537)
+    ix = hnswindex.Index(dim)
+    ix.set_collection_size(n); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_allow_removals(False)
+    ids = ix.add(x)                                          # default schedule (snapshot batches)
+    assert ids[0] == 0 and ids[-1] == n - 1 and (np.diff(ids) == 1).all()
+    _check_structure(ix, n, M)
+    q_all = uniform(100_000, dim, 65538)
+    lo0, hi0 = hnswindex.net_amd.distributed.shard_bounds(100_000, 8, 0)
+    lo5, hi5 = hnswindex.net_amd.distributed.shard_bounds(100_000, 8, 5)
+    assert hi0 - lo0 == 12_500 and hi5 - lo5 == 12_500
+    ix.reset_stats()
+    a_ids, a_d = ix.knn_query(q_all[lo0:hi0], 10)
+    b_ids, b_d = ix.knn_query(q_all[lo5:hi5], 10)
+    again_ids, again_d = ix.knn_query(q_all[lo0:hi0], 10)
+    assert (a_ids == again_ids).all() and a_d.tobytes() == again_d.tobytes()
+    for ids10, d10, lo in ((a_ids, a_d, lo0), (b_ids, b_d, lo5)):
+        assert (ids10 >= 0).all() and (np.diff(d10, axis=1) >= 0).all()
+        assert (np.sort(ids10, axis=1)[:, 1:] != np.sort(ids10, axis=1)[:, :-1]).all()
+        for i in range(0, 12_500, 250):
+            assert oracle.dist_query_rows("sq_euclid", x, q_all[lo + i], ids10[i]).tobytes() == d10[i].tobytes()
+    st = ix.stats()
+    assert st["search_overflows"] == 0 and st["search_launches"] == 3   # one launch per 12 500-query call
+    assert st["visited_hash_launches"] == 3                              # above 4M nodes the visited ids live in the per-wave hash tables
+    _oracle_sample_is_bit_exact(ix, x, q_all[lo0:hi0], 10, "sq_euclid", M, 128, 200, a_ids, a_d, 2000)
+    del ix, x
+    gc.collect()
+
