@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
 """
-bench.py -- BASELINE.json metric on MI355X: batched KnnQuery/sec (and Add/sec) on
-1M x 128 float32, sq_euclid, M=16, efConstruction=200, efSearch=128, k=10, recall@10.
+bench.py -- BASELINE.json metric on MI355X: batched KnnQuery/sec and Add/sec on
+1M x 128 float32, sq_euclid, M=16, efConstruction=200, efSearch=128, k=10, with recall@10.
 
-A "step" is one pass of the hot path over one batch of synthetic queries: every rank runs
-`Index.knn_query` on its shard of the batch (nq_per_gpu queries), then one all-gather of the
-per-shard top-k (RCCL) when N > 1.  The vector matrix, graph and query set are resident
-before the timed region.  Timed: exactly K steps between (barrier + cuda.synchronize) pairs,
-max over ranks.  One JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic queries: every rank runs one
+batched KnnQuery on its shard of the batch, then one all-gather of the per-shard top-k (RCCL) when
+N > 1.  Vector matrix, graph and query set are resident in HBM before the timed region (`value`);
+the same step through the reference's own `hnsw_knn_query` export, which is handed host buffers
+every call, is reported beside it (`boundary_call_queries_per_sec`).  Timed: exactly K steps between
+(barrier + cuda.synchronize) pairs, max over ranks.  One JSON line on rank 0.
 
-    python bench.py [--gpus N --steps K --warmup W] [--n 1000000 --nq 10000 ...]
+The Add half of the metric is reported four ways (all on the same 1M index):
+  add_per_sec            the build: hnsw_add of the whole set, default schedule (snapshot batches)
+  add_modes.sequential   B = 1: the reference's HNSWIndex.Add(item), one call per item
+  add_modes.bounded      B = host-core count: what a Parallel.For on that host can hold in flight
+  add_modes.batched      one large batch on the built index
+each beside the CPU restatement running the SAME schedule on the same vectors (graph hashes compared),
+plus `roofline_add` for the two build kernels.
+
+    python bench.py [--gpus N --steps K --warmup W] [--n 1000000 --nq 65536 ...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -25,6 +36,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PROFILE_ROUND = "r2"
 
 
 def parse():
@@ -35,8 +47,10 @@ def parse():
     p.add_argument("--n", "--index-size", dest="n", type=int, default=1_000_000, help="indexed vectors (BASELINE C2: 1M)")
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--metric", default="sq_euclid")
-    p.add_argument("--nq", type=int, default=65_536, help="queries per GPU per step (one batched knn_query call)")
-    p.add_argument("--small-batch", type=int, default=10_000, help="also time batches of this many queries (N=1 only; 0 = skip)")
+    p.add_argument("--nq", type=int, default=65_536, help="queries per step: per GPU (--scaling weak) or in total (--scaling strong)")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                   help="weak: --nq queries per GPU per step; strong: --nq queries per step shared by all GPUs (C4: 100000 over 8)")
+    p.add_argument("--small-batch", type=int, default=12_500, help="also time calls of this many queries (C4's per-GPU shard; N=1 only; 0 = skip)")
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--max-edges", type=int, default=16)
     p.add_argument("--ef-construction", type=int, default=200)
@@ -46,13 +60,18 @@ def parse():
     p.add_argument("--threads", type=int, default=0, help="host threads of the driver (0 = library default)")
     p.add_argument("--recall-queries", type=int, default=1000)
     p.add_argument("--cpu-queries", type=int, default=4000, help="bounded cpu_baseline sample (all-cores leg)")
-    p.add_argument("--cpu-adds", type=int, default=3000, help="bounded cpu_baseline sample of sequential inserts")
+    p.add_argument("--seq-adds", type=int, default=2000, help="sample of sequential (B=1) inserts into the built index, GPU and CPU")
+    p.add_argument("--bounded-adds", type=int, default=4096, help="sample inserted in calls of B = host cores, GPU and CPU")
+    p.add_argument("--batched-adds", type=int, default=32768, help="sample inserted as one batch, GPU and CPU (all cores)")
+    p.add_argument("--recall-study-n", type=int, default=32768, help="index size of the bounded-concurrency recall comparison (0 = skip)")
     p.add_argument("--data", choices=["uniform", "clustered"], default="uniform",
                    help="uniform: i.i.d. U[0,1) (the reference's test data, BASELINE.md); clustered: 1000-centre Gaussian "
                         "mixture, only to show recall on data that has neighbourhood structure")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-add-modes", action="store_true")
     p.add_argument("--traversal", choices=["device", "host"], default="device",
-                   help="device: graph-resident search kernel (default); host: lock-step traversal on host threads")
+                   help="device: graph-resident search kernel (default); host: the literal north-star split -- traversal on "
+                        "host threads, distances batched step by step through the inner C ABI (hnswdev_step_submit / _wait)")
     return p.parse_args()
 
 
@@ -62,9 +81,13 @@ def make_data(n, dim, seed, metric, kind="uniform"):
         centres = np.random.default_rng(4242).random((1000, dim), dtype=np.float32)
         x = centres[rng.integers(0, 1000, n)] + (0.05 * rng.standard_normal((n, dim))).astype(np.float32)
     else:
-        x = rng.random((n, dim), dtype=np.float32)  # Utils.cs:35-49: uniform [0,1)
+        x = np.empty((n, dim), dtype=np.float32)  # Utils.cs:35-49: uniform [0,1); filled in chunks (10M x 128 = 5 GB)
+        for i in range(0, n, 1_000_000):
+            x[i:i + 1_000_000] = rng.random((min(1_000_000, n - i), dim), dtype=np.float32)
     if metric == "ucosine":
-        x = (x / np.sqrt((x * x).sum(axis=1, dtype=np.float32, keepdims=True))).astype(np.float32)
+        for i in range(0, n, 250_000):
+            c = x[i:i + 250_000]
+            x[i:i + 250_000] = (c / np.sqrt((c * c).sum(axis=1, dtype=np.float32, keepdims=True))).astype(np.float32)
     return x
 
 
@@ -83,11 +106,53 @@ def brute_force_topk(x_t, q, k, metric):
     return torch.cat(out).numpy()
 
 
+def recall_of(x, q, k, metric, got_ids):
+    import torch
+    x_t = torch.from_numpy(x).cuda()
+    gt = brute_force_topk(x_t, q, k, metric)
+    del x_t
+    return float(np.mean([len(set(gt[i]) & set(got_ids[i])) / k for i in range(q.shape[0])]))
+
+
+def new_index(a, dev_index, capacity, insert_batch):
+    from hnswindex import Index
+    ix = Index(a.dim, a.metric)
+    ix.set_collection_size(capacity)       # avoid the doubling resize (GraphData.cs:98-111)
+    ix.set_max_edges(a.max_edges)
+    ix.set_max_candidates(a.ef_construction)
+    ix.set_min_nn(a.ef_search)             # ef = max(MinNN, k)  (HNSWIndex.cs:115)
+    ix.set_allow_removals(False)           # build-rate runs drop in-edge upkeep (SURVEY 8d)
+    ix.set_device(dev_index)
+    ix.set_insert_batch(insert_batch)
+    ix.set_device_traversal(a.traversal == "device")
+    if a.slots:
+        ix.set_search_slots(a.slots)
+    if a.threads:
+        ix.set_host_threads(a.threads)
+    return ix
+
+
+def relaunch_for_gpus(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes BEFORE anything
+    touches the GPU (one process per GPU over RCCL), and exit with the launcher's code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        relaunch_for_gpus(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -99,9 +164,9 @@ def main():
     torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend)  # "nccl" is RCCL on ROCm
+        kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)  # "nccl" is RCCL on ROCm
     import hnswindex
-    from hnswindex import Index
     dmod = hnswindex.net_amd.distributed
 
     def barrier():
@@ -111,19 +176,9 @@ def main():
 
     # ---------------- setup (untimed): data, index build, resident queries ----------------
     x = make_data(a.n, a.dim, 65537, a.metric, a.data)
-    ix = Index(a.dim, a.metric)
-    ix.set_collection_size(a.n)            # avoid the doubling resize (GraphData.cs:98-111)
-    ix.set_max_edges(a.max_edges)
-    ix.set_max_candidates(a.ef_construction)
-    ix.set_min_nn(a.ef_search)             # ef = max(MinNN, k)  (HNSWIndex.cs:115)
-    ix.set_allow_removals(False)           # build-rate runs drop in-edge upkeep (SURVEY 8d)
-    ix.set_device(dev_index)
-    ix.set_insert_batch(a.insert_batch)
-    ix.set_device_traversal(a.traversal == "device")
-    if a.slots:
-        ix.set_search_slots(a.slots)
-    if a.threads:
-        ix.set_host_threads(a.threads)
+    extra_total = a.seq_adds + a.bounded_adds + a.batched_adds
+    ix = new_index(a, dev_index, a.n + extra_total, a.insert_batch)
+    ix.set_profiling(True)                 # HIP events around the build kernels too (roofline_add)
     barrier()
     t0 = time.perf_counter()
     ids = ix.add(x)
@@ -131,8 +186,15 @@ def main():
     build_s = time.perf_counter() - t0
     assert ids.size == a.n
     build_stats = ix.stats()
+    ix.set_profiling(False)
+    my_hash = ix.graph_hash()
+    replicas_identical = True
+    if world > 1:  # every rank builds the same deterministic graph (replicas only): prove it
+        hs = [None] * world
+        dist.all_gather_object(hs, int(my_hash))
+        replicas_identical = len(set(hs)) == 1
 
-    nq_total = a.nq * world
+    nq_total = a.nq * world if a.scaling == "weak" else a.nq
     q_all = make_data(nq_total, a.dim, 65538, a.metric, a.data)  # queries distinct from the base vectors
 
     # this rank's shard of the query set is uploaded ONCE, before the timed region: the timed steps
@@ -145,12 +207,12 @@ def main():
     def step():
         return dmod.knn_query_sharded(lambda qs, k: ix.knn_query_resident(k), q_all, a.k, dst_rank=0, copy=False)
 
-    def step_pcie():  # same work with the queries handed over as host buffers every step
+    def step_boundary():  # the same work through hnsw_knn_query: queries handed over as host buffers every call
         return dmod.knn_query_sharded(ix.knn_query, q_all, a.k, dst_rank=0, copy=False)
 
     for _ in range(a.warmup):
         step()
-    ix.set_profiling(True)                 # HIP events around every distance-kernel launch, on its stream
+    ix.set_profiling(True)                 # HIP events around every traversal launch, on its stream
     ix.reset_stats()
     barrier()
     t0 = time.perf_counter()
@@ -162,27 +224,36 @@ def main():
         res_ids, res_d = np.array(res_ids), np.array(res_d)
     st = ix.stats()
     ix.set_profiling(False)
+    step_boundary()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(2):
-        step_pcie()
+    nb_steps = max(2, min(5, a.steps))
+    for _ in range(nb_steps):
+        step_boundary()
     barrier()
-    dt_pcie = (time.perf_counter() - t0) / 2
+    dt_boundary = (time.perf_counter() - t0) / nb_steps
     small = None
-    if world == 1 and 0 < a.small_batch < a.nq:  # the same step on a smaller batch: launch fill / tail effects
+    if world == 1 and 0 < a.small_batch < hi - lo:  # the same step on C4's per-GPU shard size: launch fill / tail effects
         ix.set_resident_queries(q_all[:a.small_batch])
         ix.knn_query_resident(a.k)
+        ix.set_profiling(True)
+        ix.reset_stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
             ix.knn_query_resident(a.k)
         torch.cuda.synchronize()
-        small = a.small_batch * 10 / (time.perf_counter() - t0)
-    ix.set_resident_queries(q_all[lo:hi])
+        dts = time.perf_counter() - t0
+        ss = ix.stats()
+        ix.set_profiling(False)
+        ev_s, ms_s = (ss["search_timed_evals"], ss["search_kernel_ms"]) if a.traversal == "device" else (ss["timed_evals"], ss["kernel_ms"])
+        small = {"queries_per_call": a.small_batch, "queries_per_sec": round(a.small_batch * 10 / dts, 1),
+                 "roofline_frac": round(ev_s * ss["row_bytes"] / (ms_s / 1e3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_s > 0 else None}
+        ix.set_resident_queries(q_all[lo:hi])
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([dt, dt_boundary], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_boundary = float(t[0].item()), float(t[1].item())
 
     if rank != 0:
         if world > 1:
@@ -190,12 +261,9 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---------------- rank 0: quality, roofline, CPU baseline ----------------
+    # ---------------- rank 0: quality, rooflines, CPU baseline, Add modes ----------------
     nrec = min(a.recall_queries, nq_total)
-    x_t = torch.from_numpy(x).cuda()
-    gt = brute_force_topk(x_t, q_all[:nrec], a.k, a.metric)
-    del x_t
-    recall = float(np.mean([len(set(gt[i]) & set(res_ids[i])) / a.k for i in range(nrec)]))
+    recall = recall_of(x, q_all[:nrec], a.k, a.metric, res_ids)
 
     if a.traversal == "device":
         kname, t_evals, t_launches, k_ms = "graph_search_kernel", st["search_timed_evals"], st["search_timed_launches"], st["search_kernel_ms"]
@@ -206,10 +274,10 @@ def main():
     traffic = None
     try:  # PMC traffic is collected in separate rocprofv3 passes (tools/run_profiles.sh); quote it only
         # for the very workload it was measured on
-        pm = json.loads((ROOT / "profiles" / "r1_pmc_traffic.json").read_text())
+        pm = json.loads((ROOT / "profiles" / f"{PROFILE_ROUND}_pmc_traffic.json").read_text())
         w = pm["workload"]
         if a.traversal == "device" and (w["n"], w["dim"], w["nq"], w["ef_search"], w["k"], w["max_edges"]) == \
-                (a.n, a.dim, a.nq, a.ef_search, a.k, a.max_edges) and a.metric == "sq_euclid":
+                (a.n, a.dim, hi - lo, a.ef_search, a.k, a.max_edges) and a.metric == "sq_euclid":
             traffic = round(pm["traffic_bytes_per_launch"])
     except Exception:
         pass
@@ -221,18 +289,46 @@ def main():
         "launches": t_launches, "avg_launch_us": round(1e3 * k_ms / max(1, t_launches), 2),
         "kernel_time_share_of_step": round(kernel_s / dt, 4),
     }
+    # the Add half: graph_insert_search_kernel (search half + heuristic) and the link half, HIP events during the build
+    bs = build_stats
+    rb = bs["row_bytes"]
+    ins_s, lnk_s = bs["insert_kernel_ms"] / 1e3, bs["link_kernel_ms"] / 1e3
+    add_evals = bs["insert_timed_evals"] + bs["link_timed_evals"]
+    roofline_add = None
+    if a.traversal == "device" and ins_s > 0:
+        in_kernel = add_evals * rb / (ins_s + lnk_s) / 1e9
+        roofline_add = {
+            "bound": "hbm", "kernels": "graph_insert_search_kernel + link half (link_plan/offsets/order + graph_link_kernel)",
+            "achieved": round(in_kernel, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(in_kernel / HBM_PEAK_GBPS, 4),
+            "traffic": None, "bytes_per_eval": rb, "evals": add_evals,
+            "insert_search": {"launches": bs["insert_timed_launches"], "seconds": round(ins_s, 4), "evals": bs["insert_timed_evals"],
+                              "frac": round(bs["insert_timed_evals"] * rb / ins_s / 1e9 / HBM_PEAK_GBPS, 4)},
+            "link_half": {"launches": bs["link_timed_launches"], "seconds": round(lnk_s, 4), "evals": bs["link_timed_evals"],
+                          "frac": round(bs["link_timed_evals"] * rb / max(lnk_s, 1e-9) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "end_to_end_frac": round(add_evals * rb / build_s / 1e9 / HBM_PEAK_GBPS, 4),
+        }
+
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    rng_x = np.random.default_rng(65539)
+    extra = rng_x.random((max(extra_total, 1), a.dim), dtype=np.float32)
+    if a.metric == "ucosine":
+        extra = (extra / np.sqrt((extra * extra).sum(axis=1, dtype=np.float32, keepdims=True))).astype(np.float32)
+    e_seq, e_bnd, e_bat = extra[:a.seq_adds], extra[a.seq_adds:a.seq_adds + a.bounded_adds], extra[a.seq_adds + a.bounded_adds:extra_total]
+    B = cores  # bounded concurrency: what a Parallel.For over T = cores items holds in flight (HNSWIndex.cs:70-78)
 
     cpu = None
+    cpu_add = {}
     if not a.no_cpu_baseline and world == 1:
         import oracle
-        cores = min(len(os.sched_getaffinity(0)), 16)
         ref = oracle.OracleIndex(a.dim, a.metric, max_edges=a.max_edges, min_nn=a.ef_search,
-                                 max_candidates=a.ef_construction, collection_size=a.n + a.cpu_adds,
+                                 max_candidates=a.ef_construction, collection_size=a.n + extra_total,
                                  allow_removals=False, use_avx=True)
         lv = ix.levels()
         layers = [ix.export_edges(L, 2 * a.max_edges + 2 if L == 0 else a.max_edges + 2) for L in range(int(lv.max()) + 1)]
         ref.import_graph(x, lv, ix.entry_point, layers)
-        same_graph = ref.graph_hash() == ix.graph_hash()
+        del layers
+        ref.rng_skip(a.n)  # the product's level generator has drawn once per node
+        same_graph = ref.graph_hash() == my_hash
         n1 = min(500, nq_total)
         t0 = time.perf_counter(); c_ids1, c_d1 = ref.knn_query(q_all[:n1], a.k, threads=1); t1 = time.perf_counter() - t0
         nm = min(a.cpu_queries, nq_total)
@@ -241,47 +337,96 @@ def main():
         cpu_evals_per_query = ref.n_eval / nm
         parity_ids = bool((c_ids == res_ids[:nm]).all())
         parity_d = bool(c_d.tobytes() == np.ascontiguousarray(res_d[:nm]).tobytes())
-        # Add baseline: sequential inserts of fresh vectors into the same 1M graph, one thread
-        extra = make_data(a.cpu_adds, a.dim, 65539, a.metric, a.data)
-        t0 = time.perf_counter(); ref.add(extra); ta = time.perf_counter() - t0
         cpu = {
             "value": round(nm / tm, 1), "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": f"{nm} of the step's queries on the product-built {a.n}-node graph imported into the C restatement "
                       f"(oracle/, AVX2+FMA, {cores} threads = Parallel.For over queries); ids/distances compared bit for bit with the GPU run",
             "single_thread_queries_per_s": round(n1 / t1, 1),
-            "single_thread_adds_per_s": round(a.cpu_adds / ta, 1),
-            "add_sample": f"{a.cpu_adds} sequential HNSWIndex.Add into the {a.n}-node graph, 1 thread",
             "evals_per_query": round(cpu_evals_per_query, 1),
             "graph_hash_equal_after_import": same_graph,
             "gpu_ids_bit_exact_vs_cpu": parity_ids, "gpu_dists_bit_identical_vs_cpu": parity_d,
         }
+        if not a.no_add_modes:
+            # the three Add schedules on the CPU, same vectors and same order as the GPU legs below
+            t0 = time.perf_counter(); ref.add(e_seq); cpu_add["sequential"] = (a.seq_adds / (time.perf_counter() - t0), 1, ref.graph_hash())
+            t0 = time.perf_counter()
+            for i in range(0, a.bounded_adds, B):
+                ref.add_batched(e_bnd[i:i + B], B, threads=cores)
+            cpu_add["bounded"] = (a.bounded_adds / (time.perf_counter() - t0), cores, ref.graph_hash())
+            t0 = time.perf_counter(); ref.add_batched(e_bat, 1 << 20, threads=cores)
+            cpu_add["batched"] = (a.batched_adds / (time.perf_counter() - t0), cores, ref.graph_hash())
+            cpu["single_thread_adds_per_s"] = round(cpu_add["sequential"][0], 1)
+        del ref
+
+    add_modes = None
+    if not a.no_add_modes and world == 1:
+        def leg(name, vecs, call, note):
+            ix.reset_stats()
+            t0 = time.perf_counter()
+            for i in range(0, vecs.shape[0], call):
+                ix.add(vecs[i:i + call])
+            dtl = time.perf_counter() - t0
+            h = ix.graph_hash()
+            d = {"schedule": note, "inserts": int(vecs.shape[0]), "adds_per_sec": round(vecs.shape[0] / dtl, 1),
+                 "ms_per_call": round(1e3 * dtl / max(1, -(-vecs.shape[0] // call)), 3)}
+            if name in cpu_add:
+                r, c, hh = cpu_add[name]
+                d.update({"cpu_adds_per_sec": round(r, 1), "cpu_threads": c, "graph_hash_equal_to_cpu_same_schedule": bool(hh == h)})
+            return d
+        add_modes = {
+            "sequential": leg("sequential", e_seq, 1, "B=1: HNSWIndex.Add(item) one at a time (HNSWIndex.cs:55-65), the reference-exact mode"),
+            "bounded": leg("bounded", e_bnd, B, f"B={B} (= host cores): batches a Parallel.For over {B} threads can hold in flight (HNSWIndex.cs:70-78)"),
+            "batched": leg("batched", e_bat, max(1, a.batched_adds), f"one snapshot batch of {a.batched_adds} into the built index"),
+        }
+        if a.recall_study_n and a.traversal == "device":
+            # does bounding the batch change the graph's quality?  Two full builds of a smaller index, same data
+            ns = min(a.recall_study_n, a.n)
+            xs, qs = x[:ns], q_all[:min(1000, nq_total)]
+            rec = {}
+            for label, call in (("default_schedule", ns), (f"B{B}", B)):
+                sub = new_index(a, dev_index, ns, 65536)
+                t0 = time.perf_counter()
+                for i in range(0, ns, call):
+                    sub.add(xs[i:i + call])
+                tb = time.perf_counter() - t0
+                got, _ = sub.knn_query(qs, a.k)
+                rec[label] = {"recall_at_10": round(recall_of(xs, qs, a.k, a.metric, got), 4), "adds_per_sec": round(ns / tb, 1)}
+                del sub
+            add_modes["bounded"]["recall_study"] = {"n": ns, **rec}
 
     qps = nq_total * a.steps / dt
     shape = (a.dim, a.metric, a.max_edges, a.ef_construction)
     cfg_name = {(128, "sq_euclid", 16, 200): "C2" if a.n <= 1_000_000 else "C4-size", (768, "ucosine", 32, 400): "C3"}.get(shape, "custom")
+    per_gpu = hi - lo
     out = {
         "metric": "knn_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if a.data == "uniform" else "synthetic (clustered)",
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic" if a.data == "uniform" else "synthetic (clustered)",
         "config": {
             "workload": f"{cfg_name}: {a.n}x{a.dim} f32 {a.metric}, M={a.max_edges} efConstruction={a.ef_construction} "
-                        f"efSearch={a.ef_search} k={a.k}; step = batched knn_query of {a.nq} queries per GPU "
+                        f"efSearch={a.ef_search} k={a.k}; step = batched KnnQuery of {per_gpu} queries per GPU, query set resident in HBM "
                         f"(query set sharded over ranks, one all-gather of top-k)",
-            "n": a.n, "dim": a.dim, "queries_per_gpu_per_step": a.nq, "k": a.k, "max_edges": a.max_edges,
+            "n": a.n, "dim": a.dim, "queries_per_gpu_per_step": per_gpu, "queries_per_step": nq_total, "k": a.k, "max_edges": a.max_edges,
             "ef_construction": a.ef_construction, "ef_search": a.ef_search,
             "add_mode": f"snapshot-batched, cap {a.insert_batch}", "parallelism": f"query-shard x{world}, index replicated",
         },
+        "boundary_call_queries_per_sec": round(nq_total / dt_boundary, 1),
+        "boundary_call_note": "the same step through the reference's export hnsw_knn_query (host buffers in and out every call: PCIe-inclusive); "
+                              "`value` is the contract's figure with the query set already resident in HBM",
         "recall_at_10": round(recall, 4),
         "recall_note": "exact brute-force ground truth; i.i.d. uniform data (the reference's test distribution) has no "
                        "neighbourhood structure at this size -- the CPU path returns the same ids (see cpu_baseline)",
-        "pcie_inclusive_queries_per_sec": round(nq_total / dt_pcie, 1),
-        "add_per_sec": round(a.n / build_s, 1), "build_seconds": round(build_s, 2),
+        "add_per_sec": round(a.n / build_s, 1), "build_seconds": round(build_s, 3),
+        "add_note": "hnsw_add of the whole set in one call: the deterministic snapshot-batched schedule (DESIGN.md 4) -- one legal outcome "
+                    "of the reference's Parallel.For Add(List), checked bit for bit against the CPU restatement of the same schedule; "
+                    "the reference-exact sequential mode and a bounded-concurrency mode are in add_modes",
         "build_evals": build_stats["evals"] + build_stats["search_evals"],
         "build_launches": build_stats["launches"] + build_stats["search_launches"],
-        "evals_per_query": round((st["search_evals"] + st["evals"]) / (a.nq * a.steps), 1),
+        "replicas_identical": replicas_identical,
+        "evals_per_query": round((st["search_evals"] + st["evals"]) / max(1, per_gpu * a.steps), 1),
         "traversal": a.traversal, "search_overflows": st["search_overflows"], "search_repeats": st["search_repeats"],
-        "small_batch": None if small is None else {"queries_per_batch": a.small_batch, "queries_per_sec": round(small, 1)},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "small_batch": small,
+        "roofline": roofline, "roofline_add": roofline_add, "add_modes": add_modes, "cpu_baseline": cpu,
     }
     print(json.dumps(out))
     if world > 1:

@@ -44,6 +44,9 @@ def lib():
         L.orc_free.restype = None
         L.orc_add.argtypes = [ct.c_void_p, _F, ct.c_int, _I]
         L.orc_add_batched.argtypes = [ct.c_void_p, _F, ct.c_int, _I, ct.c_int]
+        L.orc_add_batched_mt.argtypes = [ct.c_void_p, _F, ct.c_int, _I, ct.c_int, ct.c_int]
+        L.orc_rng_skip.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_rng_skip.restype = None
         L.orc_import_nodes.argtypes = [ct.c_void_p, _F, _I, ct.c_int, ct.c_int]
         L.orc_import_edges.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int, ct.c_int]
         L.orc_range_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_float, ct.c_int, _I, _I, _F]
@@ -196,12 +199,17 @@ class OracleIndex:
         lib().orc_add(self._h, _pf(a), a.shape[0], _pi(ids))
         return ids
 
-    def add_batched(self, vecs, max_batch=4096):
-        """The product's snapshot-batched schedule (see orc_add_batched)."""
+    def add_batched(self, vecs, max_batch=4096, threads=1):
+        """The product's snapshot-batched schedule (see orc_add_batched); threads > 1 spreads each
+        batch's searches over that many host threads (same graph)."""
         a = _f32(vecs).reshape(-1, self.dim)
         ids = np.empty(a.shape[0], dtype=np.int32)
-        lib().orc_add_batched(self._h, _pf(a), a.shape[0], _pi(ids), int(max_batch))
+        lib().orc_add_batched_mt(self._h, _pf(a), a.shape[0], _pi(ids), int(max_batch), int(threads))
         return ids
+
+    def rng_skip(self, n):
+        """Advance the level generator by n draws (after import_graph: one per imported node)."""
+        lib().orc_rng_skip(self._h, int(n))
 
     def import_graph(self, items, levels, entry, layers):
         """layers: list of (counts[n], edges[n, stride]) per layer 0.. as produced by the

@@ -941,6 +941,138 @@ ORC_API int orc_add_batched(void *h, const float *v, int n, int *out_ids, int ma
     return n;
 }
 
+/* The same schedule with the search half of every batch spread over `threads` host threads (one
+ * visited list each) -- what a T-core host running this schedule does; the link half stays
+ * sequential.  Same graph as orc_add_batched whatever the thread count (the searches of a batch
+ * read the graph as it stands before the batch and write nothing).  bench.py's cpu_baseline leg
+ * times it beside the GPU's batched Add. */
+typedef struct {
+    index_t *ix; visited_t *vis; const int *ids; edges_t **sels; int nb;
+    volatile int *next; uint64_t n_eval;
+} bjob_t;
+static void *batch_search_worker(void *arg)
+{
+    bjob_t *j = (bjob_t *)arg;
+    sctx_t c = {j->ix, j->vis, 0};
+    for (;;) {
+        int i = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+        if (i >= j->nb) break;
+        batch_search(&c, j->ids[i], j->sels[i]);
+    }
+    j->n_eval = c.n_eval;
+    return NULL;
+}
+typedef struct { index_t *ix; const int *ids; int nb, top, t, nthreads; uint64_t n_eval; } ljob_t;
+static void *batch_link_worker(void *arg)
+{
+    ljob_t *j = (ljob_t *)arg;
+    index_t *ix = j->ix;
+    sctx_t c = {ix, NULL, 0};
+    for (int i = 0; i < j->nb; i++) {
+        int id = j->ids[i], lvl = ix->nodes[id].max_layer;
+        for (int layer = lvl < j->top ? lvl : j->top; layer >= 0; --layer) {
+            const edges_t *sel = &ix->nodes[id].out[layer]; /* this item's own list: nobody appends to it during the batch */
+            for (int e = 0; e < sel->count; ++e) {
+                int nb_id = sel->buf[e];
+                if (nb_id % j->nthreads != j->t) continue;
+                node_t *nbn = &ix->nodes[nb_id];
+                edges_add(&nbn->out[layer], id);
+                if (nbn->out[layer].count > max_edges_at(ix, layer)) prune_overflow(&c, nb_id, layer);
+            }
+        }
+    }
+    j->n_eval = c.n_eval;
+    return NULL;
+}
+ORC_API int orc_add_batched_mt(void *h, const float *v, int n, int *out_ids, int max_batch, int threads)
+{
+    index_t *ix = (index_t *)h;
+    if (!ix || !v || n <= 0) return 0;
+    if (threads <= 1) return orc_add_batched(h, v, n, out_ids, max_batch);
+    if (threads > 256) threads = 256;
+    if (max_batch < 1) max_batch = 1;
+    sctx_t c = {ix, &ix->vis, 0};
+    int *ids = (int *)malloc(sizeof(int) * (size_t)n);
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        int id = alloc_node(ix, v + (size_t)i * (size_t)ix->dim);
+        if (out_ids) out_ids[i] = id;
+        if (id >= 0) ids[m++] = id;
+    }
+    visited_t *vis = (visited_t *)malloc(sizeof(visited_t) * (size_t)threads);
+    for (int t = 0; t < threads; t++) visited_init(&vis[t], ix->capacity);
+    int p = 0;
+    while (p < m) {
+        if (ix->entry < 0) { ix->entry = ids[p++]; continue; }
+        int top = ix->nodes[ix->entry].max_layer;
+        int nb = 1, new_ep = 0;
+        if (ix->nodes[ids[p]].max_layer > top) {
+            new_ep = 1;
+        } else {
+            int linked = ix->count - (m - p);
+            int b = linked / 16;
+            if (b < 1) b = 1;
+            if (b > max_batch) b = max_batch;
+            while (nb < b && p + nb < m && ix->nodes[ids[p + nb]].max_layer <= top) nb++;
+        }
+        edges_t **sels = (edges_t **)malloc(sizeof(edges_t *) * (size_t)nb);
+        for (int i = 0; i < nb; i++) sels[i] = (edges_t *)calloc((size_t)ix->nodes[ids[p + i]].max_layer + 1, sizeof(edges_t));
+        int used = nb < threads ? nb : threads;
+        if (used <= 1) {
+            for (int i = 0; i < nb; i++) batch_search(&c, ids[p + i], sels[i]);
+        } else {
+            pthread_t th[256];
+            bjob_t jobs[256];
+            volatile int next = 0;
+            for (int t = 0; t < used; t++) {
+                jobs[t] = (bjob_t){ix, &vis[t], ids + p, sels, nb, &next, 0};
+                pthread_create(&th[t], NULL, batch_search_worker, &jobs[t]);
+            }
+            for (int t = 0; t < used; t++) { pthread_join(th[t], NULL); c.n_eval += jobs[t].n_eval; }
+        }
+        if (used <= 1 || ix->allow_removals) { /* in-edge upkeep touches other nodes' lists: sequential */
+            for (int i = 0; i < nb; i++) batch_link(&c, ids[p + i], sels[i]);
+        } else {
+            /* link half by target list: OutEdges = selected for every item, then each thread applies, in
+             * item order, the back-edge appends (and overflow prunes) of the lists it owns (nb % threads).
+             * Lists are independent, so this is the sequential outcome. */
+            for (int i = 0; i < nb; i++) {
+                int id = ids[p + i], lvl = ix->nodes[id].max_layer;
+                for (int layer = lvl < top ? lvl : top; layer >= 0; --layer) {
+                    free(ix->nodes[id].out[layer].buf);
+                    ix->nodes[id].out[layer] = sels[i][layer];
+                }
+            }
+            pthread_t th[256];
+            ljob_t jobs[256];
+            for (int t = 0; t < used; t++) {
+                jobs[t] = (ljob_t){ix, ids + p, nb, top, t, used, 0};
+                pthread_create(&th[t], NULL, batch_link_worker, &jobs[t]);
+            }
+            for (int t = 0; t < used; t++) { pthread_join(th[t], NULL); c.n_eval += jobs[t].n_eval; }
+        }
+        for (int i = 0; i < nb; i++) free(sels[i]);
+        free(sels);
+        if (new_ep) ix->entry = ids[p];
+        p += nb;
+    }
+    for (int t = 0; t < threads; t++) visited_free(&vis[t]);
+    free(vis);
+    free(ids);
+    ix->n_eval += c.n_eval;
+    return n;
+}
+
+/* Advances the level generator by n draws without inserting anything: after orc_import_nodes the
+ * generator stands at its seed, while the index the graph came from has drawn one level per node
+ * (GraphData.cs:211-219).  With the draws skipped, Adds on the imported graph continue exactly as
+ * they would on the original. */
+ORC_API void orc_rng_skip(void *h, int n)
+{
+    index_t *ix = (index_t *)h;
+    for (int i = 0; ix && i < n; i++) (void)rng_next_single(&ix->rng);
+}
+
 /* ------------------------------------------------------------------------------------
  * Removal: HNSWIndex.Remove (src/HNSWIndex/HNSWIndex.cs:83-102) ->
  * GraphConnector.RemoveNodeConnections (GraphConnector.cs:53-167), single-threaded (the region

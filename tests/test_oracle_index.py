@@ -204,3 +204,45 @@ def test_remove_all_then_rebuild_and_disabled_removals():
     iy.add(x)
     with pytest.raises(RuntimeError):
         iy.remove([0])
+
+
+def test_threaded_batched_add_builds_the_same_graph():
+    # bench.py's like-for-like CPU baseline: the batched schedule with searches and per-list link work spread
+    # over host threads must end in the very graph the single-thread restatement builds
+    x = uniform(6000, 24, 77)
+    hashes = set()
+    for threads, removals in ((1, False), (4, False), (7, False), (4, True)):
+        ix = oracle.OracleIndex(24, max_candidates=60, collection_size=6000, allow_removals=removals)
+        ix.add_batched(x, 65536, threads=threads)
+        hashes.add(ix.graph_hash())
+    assert len(hashes) == 1
+    # bounded batches: B = 16 per call, threaded == single-thread == one call with max_batch 16 (no new entry point inside)
+    a = oracle.OracleIndex(24, max_candidates=60, collection_size=6000, allow_removals=False)
+    b = oracle.OracleIndex(24, max_candidates=60, collection_size=6000, allow_removals=False)
+    for i in range(0, 3000, 16):
+        a.add_batched(x[i:i + 16], 16, threads=4)
+        b.add_batched(x[i:i + 16], 16, threads=1)
+    assert a.graph_hash() == b.graph_hash()
+
+
+def test_rng_skip_continues_an_imported_graph_exactly():
+    x, more = uniform(3000, 16, 5), uniform(200, 16, 6)
+    a = oracle.OracleIndex(16, collection_size=3200, allow_removals=False)
+    a.add(x)
+    lv = a.levels()
+    layers = []
+    for L in range(int(lv.max()) + 1):
+        cnt = np.full(lv.size, -1, np.int32)
+        ed = np.zeros((lv.size, 34), np.int32)
+        for i in np.nonzero(lv >= L)[0]:
+            e = a.edges(int(i), L)
+            cnt[i] = e.size
+            ed[i, :e.size] = e
+        layers.append((cnt, ed))
+    b = oracle.OracleIndex(16, collection_size=3200, allow_removals=False)
+    b.import_graph(x, lv, a.entry_point, layers)
+    assert b.graph_hash() == a.graph_hash()
+    b.rng_skip(3000)
+    a.add(more); b.add(more)
+    assert b.graph_hash() == a.graph_hash()
+
