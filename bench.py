@@ -98,7 +98,7 @@ def brute_force_topk(x_t, q, k, metric):
     out = []
     for i in range(0, qt.shape[0], 256):
         qc = qt[i:i + 256]
-        if metric == "sq_euclid":
+        if metric in ("sq_euclid", "sq_euclid_i8"):  # int8: the ground truth is the float vectors' (what quantisation costs shows in recall)
             d = (x_t * x_t).sum(1, keepdim=True) - 2.0 * (x_t @ qc.T) + (qc * qc).sum(1)[None, :]
         else:
             d = 1.0 - (x_t @ qc.T) / (x_t.norm(dim=1, keepdim=True) * qc.norm(dim=1)[None, :])
@@ -396,14 +396,15 @@ def main():
 
     qps = nq_total * a.steps / dt
     shape = (a.dim, a.metric, a.max_edges, a.ef_construction)
-    cfg_name = {(128, "sq_euclid", 16, 200): "C2" if a.n <= 1_000_000 else "C4-size", (768, "ucosine", 32, 400): "C3"}.get(shape, "custom")
+    cfg_name = {(128, "sq_euclid", 16, 200): "C2" if a.n <= 1_000_000 else "C4-size", (768, "ucosine", 32, 400): "C3",
+                (96, "sq_euclid_i8", 16, 200): "C5-size"}.get(shape, "custom")
     per_gpu = hi - lo
     out = {
         "metric": "knn_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic" if a.data == "uniform" else "synthetic (clustered)",
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "i8 (int32 dot, f64 epilogue)" if a.metric == "sq_euclid_i8" else "f32", "data": "synthetic" if a.data == "uniform" else "synthetic (clustered)",
         "config": {
-            "workload": f"{cfg_name}: {a.n}x{a.dim} f32 {a.metric}, M={a.max_edges} efConstruction={a.ef_construction} "
+            "workload": f"{cfg_name}: {a.n}x{a.dim} {'int8+scale' if a.metric == 'sq_euclid_i8' else 'f32'} {a.metric}, M={a.max_edges} efConstruction={a.ef_construction} "
                         f"efSearch={a.ef_search} k={a.k}; step = batched KnnQuery of {per_gpu} queries per GPU, query set resident in HBM "
                         f"(query set sharded over ranks, one all-gather of top-k)",
             "n": a.n, "dim": a.dim, "queries_per_gpu_per_step": per_gpu, "queries_per_step": nq_total, "k": a.k, "max_edges": a.max_edges,

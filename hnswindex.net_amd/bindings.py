@@ -139,7 +139,7 @@ lib.hnswdev_step_submit.argtypes = [ct.c_void_p, ct.c_int, ct.c_int]
 lib.hnswdev_step_wait.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnswdev_test_sqrt_rn.argtypes = [ct.c_int, ct.POINTER(ct.c_double), ct.POINTER(ct.c_double), ct.c_int]
 
-METRICS = {"sq_euclid": 0, "cosine": 1, "ucosine": 2}
+METRICS = {"sq_euclid": 0, "cosine": 1, "ucosine": 2, "sq_euclid_i8": 3}
 
 
 def last_error() -> str:

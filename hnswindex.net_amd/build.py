@@ -12,7 +12,7 @@ LIB = PKG / "artifacts" / "native" / "linux-x64" / "HNSWIndex.Native.so"
 # device_backend.hip: host side + the small kernels; traverse_<metric>_<kernel>.hip: the instantiations of the two
 # big traversal kernel templates (device code in device_kernels.h) -- separate units so that they
 # compile in parallel (one unit took two minutes).
-SOURCES = ["device_backend.hip", *[f"traverse_{m}_{k}.hip" for m in ("sq", "cos", "ucos") for k in ("insert", "search")],
+SOURCES = ["device_backend.hip", *[f"traverse_{m}_{k}.hip" for m in ("sq", "cos", "ucos", "i8") for k in ("insert", "search")],
            "search_engine.cpp", "hnsw_index.cpp", "exports.cpp"]
 # -ffp-contract=off: the kernels fuse a*b+c only where __builtin_fmaf is written -- the
 # reference's AVX path fuses in sq_euclid (Fma.MultiplyAdd) and nowhere else.

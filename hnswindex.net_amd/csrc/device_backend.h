@@ -173,6 +173,9 @@ private:
     std::string err_;
     bool bind();
     int device_ = 0, dim_ = 0, metric_ = 0;
+    int pitch_ = 0; // 32-bit words per stored row / resident query (== dim_ for the float metrics; the int8 record otherwise)
+    float *q_stage_ = nullptr; // int8: float staging area on the device (quantise on upload, dequantise on download)
+    size_t q_stage_cap_ = 0;
     long long capacity_ = 0;
     long long n_rows_hw_ = 0; // high-water mark of uploaded rows (id validation)
     float *d_rows_ = nullptr;

@@ -77,15 +77,28 @@ std::string get_dev_error()
         }                                                                                         \
     } while (0)
 
+template <class T>
+static bool grow_dev(T **p, size_t *cap, size_t need)
+{
+    if (need <= *cap) return true;
+    if (*p) HIP_OK(hipFree(*p));
+    *p = nullptr;
+    HIP_OK(hipMalloc(p, sizeof(T) * need));
+    *cap = need;
+    return true;
+}
+
 #ifdef HNSW_SINGLE_TU
 // one translation unit (diagnostic builds: the phase-clock counters are per-unit device globals)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_TRAVERSAL, M_SQ)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_TRAVERSAL, M_COS)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_TRAVERSAL, M_UCOS)
+HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_TRAVERSAL, M_I8)
 #else
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DECLARE_TRAVERSAL, M_SQ)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DECLARE_TRAVERSAL, M_COS)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DECLARE_TRAVERSAL, M_UCOS)
+HNSW_FOR_EACH_TRAVERSAL(HNSW_DECLARE_TRAVERSAL, M_I8)
 #endif
 
 // ------------------------------------------------------------------------------------
@@ -108,7 +121,7 @@ bool Device::bind()
 
 Device *Device::create(int device, int dim, int metric, long long capacity)
 {
-    if (dim <= 0 || metric < 0 || metric > 2 || capacity < 0) {
+    if (dim <= 0 || metric < 0 || metric > 3 || capacity < 0) {
         set_dev_error("hnswdev_create: bad argument");
         return nullptr;
     }
@@ -126,8 +139,12 @@ Device *Device::create(int device, int dim, int metric, long long capacity)
     Device *d = new Device();
     d->device_ = device;
     d->dim_ = dim;
+    // words per stored row: the floats themselves, or the int8 record (data words + scale + sumsq, a
+    // multiple of 16 words = 64 B; device_kernels.h "int8 rows")
+    d->pitch_ = metric == M_I8 ? (((dim + 3) / 4 + 2 + 15) & ~15) : dim;
     d->metric_ = metric;
-    d->stats_.row_bytes = (uint64_t)dim * sizeof(float);
+    // algorithmic bytes per evaluation: the row's elements, plus the 4-byte scale for int8
+    d->stats_.row_bytes = metric == M_I8 ? (uint64_t)dim + 4u : (uint64_t)dim * sizeof(float);
     auto fail = [&]() -> Device * { delete d; return nullptr; };
     if (hipSetDevice(device) != hipSuccess) { set_dev_error("hipSetDevice failed"); return fail(); }
     hipStream_t st;
@@ -147,6 +164,7 @@ Device::~Device()
     if (stream_) { (void)hipStreamSynchronize(S(stream_)); (void)hipStreamDestroy(S(stream_)); }
     for (StepBuffers *&sb : abi_sb_) { if (sb) free_step(sb); sb = nullptr; }
     if (d_guard_) (void)hipFree(d_guard_);
+    if (q_stage_) (void)hipFree(q_stage_);
     if (pair_dev_) (void)hipFree(pair_dev_);
     if (d_rows_) (void)hipFree(d_rows_);
     if (d_row_sn_) (void)hipFree(d_row_sn_);
@@ -192,10 +210,10 @@ bool Device::reserve(long long capacity)
     if (!bind()) return false;
     float *nr = nullptr;
     double *nsn = nullptr;
-    HIP_OK(hipMalloc(&nr, (size_t)capacity * dim_ * sizeof(float)));
+    HIP_OK(hipMalloc(&nr, (size_t)capacity * pitch_ * sizeof(float)));
     if (metric_ == M_COS) HIP_OK(hipMalloc(&nsn, (size_t)capacity * sizeof(double)));
     if (d_rows_) {
-        HIP_OK(hipMemcpyAsync(nr, d_rows_, (size_t)capacity_ * dim_ * sizeof(float), hipMemcpyDeviceToDevice, S(stream_)));
+        HIP_OK(hipMemcpyAsync(nr, d_rows_, (size_t)capacity_ * pitch_ * sizeof(float), hipMemcpyDeviceToDevice, S(stream_)));
         if (nsn) HIP_OK(hipMemcpyAsync(nsn, d_row_sn_, (size_t)capacity_ * sizeof(double), hipMemcpyDeviceToDevice, S(stream_)));
         HIP_OK(hipStreamSynchronize(S(stream_)));
         HIP_OK(hipFree(d_rows_));
@@ -215,21 +233,30 @@ bool Device::upload_rows(int first_id, int n, const float *rows)
         return false;
     }
     if (!bind()) return false;
-    {   // pageable -> pinned bounce buffer -> HBM, 64 MiB at a time
+    {   // pageable -> pinned bounce buffer -> HBM, 64 MiB at a time (int8: through a float staging area on the
+        // device, quantised into records there)
         const size_t row_bytes = (size_t)dim_ * sizeof(float);
         const size_t chunk_rows = std::max<size_t>(1, (64u << 20) / row_bytes);
         char *hs = static_cast<char *>(pinned_stage(std::min<size_t>((size_t)n, chunk_rows) * row_bytes));
         if (!hs) return false;
+        if (metric_ == M_I8 && !grow_dev(&q_stage_, &q_stage_cap_, std::min<size_t>((size_t)n, chunk_rows) * (size_t)dim_)) return false;
         for (size_t r0 = 0; r0 < (size_t)n; r0 += chunk_rows) {
             const size_t nr = std::min(chunk_rows, (size_t)n - r0);
             memcpy(hs, rows + r0 * dim_, nr * row_bytes);
-            HIP_OK(hipMemcpyAsync(d_rows_ + ((size_t)first_id + r0) * dim_, hs, nr * row_bytes, hipMemcpyHostToDevice, S(stream_)));
+            if (metric_ == M_I8) {
+                HIP_OK(hipMemcpyAsync(q_stage_, hs, nr * row_bytes, hipMemcpyHostToDevice, S(stream_)));
+                hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)((nr + 3) / 4)), dim3(256), 0, S(stream_), q_stage_, dim_, (int)nr, d_rows_,
+                                   (long long)first_id + (long long)r0, pitch_);
+                HIP_OK(hipGetLastError());
+            } else {
+                HIP_OK(hipMemcpyAsync(d_rows_ + ((size_t)first_id + r0) * pitch_, hs, nr * row_bytes, hipMemcpyHostToDevice, S(stream_)));
+            }
             HIP_OK(hipStreamSynchronize(S(stream_))); // the bounce buffer is reused
         }
     }
     if (metric_ == M_COS) {
         int blocks = (int)(((long long)n * 8 + 255) / 256);
-        hipLaunchKernelGGL(row_sqrtnorm_kernel, dim3(blocks), dim3(256), 0, S(stream_), d_rows_, dim_, (long long)first_id, n, d_row_sn_);
+        hipLaunchKernelGGL(row_sqrtnorm_kernel, dim3(blocks), dim3(256), 0, S(stream_), d_rows_, pitch_, (long long)first_id, n, d_row_sn_);
         HIP_OK(hipGetLastError());
     }
     HIP_OK(hipStreamSynchronize(S(stream_))); // `rows` is borrowed only for this call
@@ -245,7 +272,15 @@ bool Device::download_rows(int first_id, int n, float *rows)
         return false;
     }
     if (!bind()) return false;
-    HIP_OK(hipMemcpyAsync(rows, d_rows_ + (size_t)first_id * dim_, (size_t)n * dim_ * sizeof(float), hipMemcpyDeviceToHost, S(stream_)));
+    if (metric_ == M_I8) { // the dequantised rows q_i * scale
+        if (!grow_dev(&q_stage_, &q_stage_cap_, (size_t)n * (size_t)dim_)) return false;
+        hipLaunchKernelGGL(dequantize_rows_kernel, dim3((unsigned)(((long long)n * dim_ + 255) / 256)), dim3(256), 0, S(stream_), d_rows_, pitch_,
+                           (long long)first_id, n, dim_, q_stage_);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipMemcpyAsync(rows, q_stage_, (size_t)n * dim_ * sizeof(float), hipMemcpyDeviceToHost, S(stream_)));
+    } else {
+        HIP_OK(hipMemcpyAsync(rows, d_rows_ + (size_t)first_id * pitch_, (size_t)n * dim_ * sizeof(float), hipMemcpyDeviceToHost, S(stream_)));
+    }
     HIP_OK(hipStreamSynchronize(S(stream_)));
     return true;
 }
@@ -259,7 +294,7 @@ bool Device::set_queries(const float *queries, int nq)
         if (d_q_sn_) HIP_OK(hipFree(d_q_sn_));
         d_queries_ = nullptr; d_q_sn_ = nullptr;
         long long cap = std::max<long long>(nq, 1024);
-        HIP_OK(hipMalloc(&d_queries_, (size_t)cap * dim_ * sizeof(float)));
+        HIP_OK(hipMalloc(&d_queries_, (size_t)cap * pitch_ * sizeof(float)));
         if (metric_ == M_COS) HIP_OK(hipMalloc(&d_q_sn_, (size_t)cap * sizeof(double)));
         q_capacity_ = cap;
     }
@@ -268,12 +303,21 @@ bool Device::set_queries(const float *queries, int nq)
     {
         const size_t bytes = (size_t)nq * dim_ * sizeof(float);
         void *hs = bytes <= (256u << 20) ? pinned_stage(bytes) : nullptr;
-        if (hs) { memcpy(hs, queries, bytes); HIP_OK(hipMemcpyAsync(d_queries_, hs, bytes, hipMemcpyHostToDevice, S(stream_))); }
-        else HIP_OK(hipMemcpyAsync(d_queries_, queries, bytes, hipMemcpyHostToDevice, S(stream_)));
+        float *dst = d_queries_;
+        if (metric_ == M_I8) { // floats to the staging area, quantised into the resident records
+            if (!grow_dev(&q_stage_, &q_stage_cap_, (size_t)nq * (size_t)dim_)) return false;
+            dst = q_stage_;
+        }
+        if (hs) { memcpy(hs, queries, bytes); HIP_OK(hipMemcpyAsync(dst, hs, bytes, hipMemcpyHostToDevice, S(stream_))); }
+        else HIP_OK(hipMemcpyAsync(dst, queries, bytes, hipMemcpyHostToDevice, S(stream_)));
+        if (metric_ == M_I8) {
+            hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, S(stream_), q_stage_, dim_, nq, d_queries_, 0LL, pitch_);
+            HIP_OK(hipGetLastError());
+        }
     }
     if (metric_ == M_COS) {
         int blocks = (int)(((long long)nq * 8 + 255) / 256);
-        hipLaunchKernelGGL(row_sqrtnorm_kernel, dim3(blocks), dim3(256), 0, S(stream_), d_queries_, dim_, 0LL, nq, d_q_sn_);
+        hipLaunchKernelGGL(row_sqrtnorm_kernel, dim3(blocks), dim3(256), 0, S(stream_), d_queries_, pitch_, 0LL, nq, d_q_sn_);
         HIP_OK(hipGetLastError());
     }
     HIP_OK(hipStreamSynchronize(S(stream_)));
@@ -339,11 +383,12 @@ bool Device::launch_step(StepBuffers *sb, int nslots_used, uint64_t evals)
     if (sb->timed) HIP_OK(hipEventRecord((hipEvent_t)sb->t0, st));
     dim3 grid((nslots_used + 3) / 4), block(256);
 #define LAUNCH(M)                                                                                          \
-    hipLaunchKernelGGL(slot_distance_kernel<M>, grid, block, 0, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
+    hipLaunchKernelGGL(slot_distance_kernel<M>, grid, block, 0, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        sb->d_rec, sb->d_dist + StepBuffers::kHeader, sb->stride, sb->rec_stride, nslots_used,  \
                        n_rows_hw_, n_queries_, reinterpret_cast<int *>(sb->d_dist))
     if (metric_ == M_SQ) LAUNCH(M_SQ);
     else if (metric_ == M_COS) LAUNCH(M_COS);
+    else if (metric_ == M_I8) LAUNCH(M_I8);
     else LAUNCH(M_UCOS);
 #undef LAUNCH
     HIP_OK(hipGetLastError());
@@ -521,16 +566,6 @@ static int spill_cap_for_tests()
     return kSpillCap;
 }
 
-template <class T>
-static bool grow_dev(T **p, size_t *cap, size_t need)
-{
-    if (need <= *cap) return true;
-    if (*p) HIP_OK(hipFree(*p));
-    *p = nullptr;
-    HIP_OK(hipMalloc(p, sizeof(T) * need));
-    *cap = need;
-    return true;
-}
 
 // Row loads overlapped with the visited atomics in launches that do not fill the chip
 // (HNSW_MI355X_OVERLAP=0 disables, =2 forces it for every launch: tests).
@@ -621,8 +656,8 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         if (j.search_layer > 0 && (j.aux < 0 || j.aux + j.search_layer > n_upper)) { set_dev_error("insert_search_batch: upper-layer slot out of range"); return false; }
     }
     if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("insert_search_batch: job outside the uploaded graph / rows"); return false; }
-    const int cand_cap = cand_lds_cap(k, dim_, true, nbcap());
-    const size_t lds = search_lds_bytes(k, cand_cap, dim_, true, nbcap());
+    const int cand_cap = cand_lds_cap(k, pitch_, true, nbcap());
+    const size_t lds = search_lds_bytes(k, cand_cap, pitch_, true, nbcap());
     if (lds > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
     const int ns = g_n_ < kSortedTopMaxNodes ? sorted_top_sets(k) : 0;
     if (!bind()) return false;
@@ -669,7 +704,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     do { \
         const int slots_ = std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_>, LDS, num_cu_)); \
         hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
-                       dim3(64), LDS, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_, \
+                       dim3(64), LDS, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
                        sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0); \
@@ -678,6 +713,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     do {                                                                                                                   \
         if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, H_, GRID, LDS, CAP);                                                  \
         else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, H_, GRID, LDS, CAP);                                           \
+        else if (metric_ == M_I8) LAUNCH2(M_I8, NS_, H_, GRID, LDS, CAP);                                             \
         else LAUNCH2(M_UCOS, NS_, H_, GRID, LDS, CAP);                                                                \
     } while (0)
 #define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
@@ -738,8 +774,8 @@ bool Device::traversal_fits(int k, bool with_heuristic, int max_edges) const
 {
     if (k < 1 || 2 * max_edges + 1 > 128) return false;
     const int nb = std::max(8, (2 * max_edges + 1 + 7) & ~7);
-    const int cap = cand_lds_cap(k, dim_, with_heuristic, nb);
-    return search_lds_bytes(k, cap, dim_, with_heuristic, nb) <= 64 * 1024 && search_lds_bytes(nb, 0, dim_, true, nb) <= 64 * 1024;
+    const int cap = cand_lds_cap(k, pitch_, with_heuristic, nb);
+    return search_lds_bytes(k, cap, pitch_, with_heuristic, nb) <= 64 * 1024 && search_lds_bytes(nb, 0, pitch_, true, nb) <= 64 * 1024;
 }
 
 bool Device::graph_append_nodes(long long first, long long n, const int *level, const int64_t *upper, const int *pool,
@@ -854,13 +890,14 @@ bool Device::link_batch_begin(int set, const int *rows, int nrows, int row_strid
         ls.timed = profiling_;
         if (ls.timed) HIP_OK(hipEventRecord((hipEvent_t)ls.ev_start, st));
         const int k_cap = nbcap();
-        const size_t lds = ((search_lds_bytes(k_cap, 0, dim_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
+        const size_t lds = ((search_lds_bytes(k_cap, 0, pitch_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
 #define LAUNCH(M)                                                                                                          \
-    hipLaunchKernelGGL(graph_link_kernel<M>, dim3(ngroups), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_,  \
+    hipLaunchKernelGGL(graph_link_kernel<M>, dim3(ngroups), dim3(64), lds, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_,  \
                        g_upper_, g_pool_, g_strideU_, s_lk_[1], s_lk_[1] + ngroups, s_lk_[2], (const int *)nullptr, s_lk_[3], max_edges0, k_cap, \
                        s_lk_[4], list_stride, s_evals_, nbcap(), g_tested0_, g_testedU_)
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
+        else if (metric_ == M_I8) LAUNCH(M_I8);
         else LAUNCH(M_UCOS);
 #undef LAUNCH
         HIP_OK(hipGetLastError());
@@ -933,13 +970,14 @@ bool Device::link_batch_planned(int njobs, int n_upper, int max_edges0)
         hipLaunchKernelGGL(link_order_kernel, dim3(G), dim3(64), 0, st, s_jobs_, g_upper_, g_strideU_, lp_grp_[5], P);
         HIP_OK(hipGetLastError());
             const int k_cap = nbcap();
-        const size_t lds = ((search_lds_bytes(k_cap, 0, dim_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
+        const size_t lds = ((search_lds_bytes(k_cap, 0, pitch_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
 #define LAUNCH(M)                                                                                                          \
-    hipLaunchKernelGGL(graph_link_kernel<M>, dim3(G), dim3(64), lds, st, d_rows_, d_row_sn_, dim_, g_adj0_, g_stride0_,       \
+    hipLaunchKernelGGL(graph_link_kernel<M>, dim3(G), dim3(64), lds, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_,       \
                        g_upper_, g_pool_, g_strideU_, lp_grp_[0], lp_grp_[1], lp_grp_[2], lp_grp_[3], lp_grp_[5], max_edges0, k_cap, \
                        (int *)nullptr, 0, s_evals_, nbcap(), g_tested0_, g_testedU_)
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
+        else if (metric_ == M_I8) LAUNCH(M_I8);
         else LAUNCH(M_UCOS);
 #undef LAUNCH
         HIP_OK(hipGetLastError());
@@ -1031,8 +1069,8 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     if (!jobs || !out_ids || !out_d || !out_flag || k < 1 || k_out < 1) { set_dev_error("search_batch: bad argument"); return false; }
     if (g_n_ <= 0) { set_dev_error("search_batch: no graph uploaded"); return false; }
     if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("search_batch: job outside the uploaded graph / rows / queries"); return false; }
-    const int cand_cap = cand_lds_cap(k, dim_, false, nbcap());
-    const size_t lds = search_lds_bytes(k, cand_cap, dim_, false, nbcap());
+    const int cand_cap = cand_lds_cap(k, pitch_, false, nbcap());
+    const size_t lds = search_lds_bytes(k, cand_cap, pitch_, false, nbcap());
     if (lds > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
     const int ns = g_n_ < kSortedTopMaxNodes ? sorted_top_sets(k) : 0;
     if (!bind()) return false;
@@ -1068,7 +1106,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     do { \
         const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_>, LDS, num_cu_)); \
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
-                       dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, dim_, \
+                       dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
                        spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0); \
     } while (0)
@@ -1076,6 +1114,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     do {                                                                                                                   \
         if (metric_ == M_SQ) LAUNCH2(M_SQ, NS_, H_, GRID, LDS, CAP);                                                  \
         else if (metric_ == M_COS) LAUNCH2(M_COS, NS_, H_, GRID, LDS, CAP);                                           \
+        else if (metric_ == M_I8) LAUNCH2(M_I8, NS_, H_, GRID, LDS, CAP);                                             \
         else LAUNCH2(M_UCOS, NS_, H_, GRID, LDS, CAP);                                                                \
     } while (0)
 #define LAUNCH(NS_, GRID, LDS, CAP)                                                                                   \
@@ -1263,9 +1302,10 @@ bool Device::dist_pair_batch(const int *a, const int *b, int n, float *out)
     float *dout = reinterpret_cast<float *>(pair_dev_ + 2 * (size_t)n);
     HIP_OK(hipMemcpyAsync(da, hs, sizeof(int) * 2 * (size_t)n, hipMemcpyHostToDevice, st));
     dim3 grid((unsigned)(((long long)n * 8 + 255) / 256)), block(256);
-#define LAUNCH(M) hipLaunchKernelGGL(pair_distance_kernel<M>, grid, block, 0, st, d_rows_, d_row_sn_, dim_, da, db, dout, n, n_rows_hw_, d_guard_)
+#define LAUNCH(M) hipLaunchKernelGGL(pair_distance_kernel<M>, grid, block, 0, st, d_rows_, d_row_sn_, pitch_, da, db, dout, n, n_rows_hw_, d_guard_)
     if (metric_ == M_SQ) LAUNCH(M_SQ);
     else if (metric_ == M_COS) LAUNCH(M_COS);
+    else if (metric_ == M_I8) LAUNCH(M_I8);
     else LAUNCH(M_UCOS);
 #undef LAUNCH
     HIP_OK(hipGetLastError());

@@ -14,7 +14,40 @@ namespace hnsw {
 // ------------------------------------------------------------------------------------
 // device code
 // ------------------------------------------------------------------------------------
-enum { M_SQ = HNSWDEV_SQ_EUCLID, M_COS = HNSWDEV_COSINE, M_UCOS = HNSWDEV_UCOSINE };
+enum { M_SQ = HNSWDEV_SQ_EUCLID, M_COS = HNSWDEV_COSINE, M_UCOS = HNSWDEV_UCOSINE, M_I8 = HNSWDEV_SQ_EUCLID_I8 };
+
+// ---- int8 rows (BASELINE config 5; no reference counterpart: the reference is generic over TDistance,
+// src/HNSWIndex/HNSWIndex.cs:6, and ships float metrics only) ----------------------------------------
+// A stored row (and a resident query) is one RECORD of `pitch` 32-bit words, pitch a multiple of 16
+// (64 bytes: whole fetch sectors; 128 B for dim 96):
+//     words [0, pitch-2)   the quantised elements, four int8 per word, zero padded
+//     word  pitch-2        scale  (float)   = max|x| / 127
+//     word  pitch-1        sumsq  (int32)   = sum of q_i^2
+// with q_i = clamp(rint(x_i / scale), -127, 127) (IEEE float division, round-half-even; q = 0 when the
+// scale is not positive).  The kernels address records exactly like float rows of `pitch` floats, so the
+// traversals, the heuristic and the link kernel are the float code; only the measure passes differ.
+// Distance of records a, b -- the squared Euclidean distance of the DEQUANTISED vectors, from exact
+// integers and one fixed sequence of IEEE double operations (never contracted: -ffp-contract=off):
+//     dot = sum q_a q_b (int32, v_dot4_i32_i8: exact, any order)
+//     A = (sa*sa)*na,  B = (sb*sb)*nb,  C = (sa*sb)*dot      (doubles; the scale products are exact)
+//     d = (float)((A + B) - 2*C)
+// The CPU restatement (oracle/hnsw_oracle.c, sq_euclid_i8) does the same, so ids are bit-exact.
+__device__ __forceinline__ float i8_epilogue(float sa, int na, float sb, int nb, int dot)
+{
+    const double A = ((double)sa * (double)sa) * (double)na;
+    const double B = ((double)sb * (double)sb) * (double)nb;
+    const double C = ((double)sa * (double)sb) * (double)dot;
+    return (float)((A + B) - 2.0 * C);
+}
+__device__ __forceinline__ int dot4_i8(int a, int b, int acc) { return __builtin_amdgcn_sdot4(a, b, acc, false); }
+// sum of an int over the 8 lanes of a group (every lane gets it)
+__device__ __forceinline__ int group_sum_i32(int v)
+{
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
 
 __device__ __forceinline__ float lane_xor_add(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
 
@@ -99,6 +132,20 @@ template <int METRIC>
 __device__ __forceinline__ float group_metric(const float *__restrict__ a, const float *__restrict__ b, int dim, int j,
                                               double sa, double sb)
 {
+    if constexpr (METRIC == M_I8) { // dim = record pitch in words; the last block's lanes 6 / 7 hold scale / sumsq
+        const int *ia = reinterpret_cast<const int *>(a), *ib = reinterpret_cast<const int *>(b);
+        const int nblk = dim >> 3, lane = threadIdx.x & 63;
+        int acc = 0, ta = 0, tb = 0;
+        for (int k = 0; k < nblk; ++k) {
+            const int wa = ia[8 * k + j], wb = ib[8 * k + j];
+            if (k == nblk - 1 && j >= 6) { ta = wa; tb = wb; }
+            else acc = dot4_i8(wa, wb, acc);
+        }
+        const int dot = group_sum_i32(acc);
+        const int g6 = (lane & ~7) | 6, g7 = (lane & ~7) | 7;
+        return i8_epilogue(__int_as_float(__shfl(ta, g6, 64)), __shfl(ta, g7, 64), __int_as_float(__shfl(tb, g6, 64)), __shfl(tb, g7, 64), dot);
+    }
+    else {
     float p = lane_chain<METRIC>(a, b, dim, j);
     float s = (METRIC == M_SQ) ? collapse_l2(p) : collapse_cos(p);
     if (dim & 7) s = scalar_tail<METRIC>(s, a, b, dim);
@@ -107,6 +154,7 @@ __device__ __forceinline__ float group_metric(const float *__restrict__ a, const
     float denom = (float)(sa * sb);        // :88  (float)(Math.Sqrt(nA) * Math.Sqrt(nB))
     if (denom < 1e-30f) return 1.0f;       // :89-90
     return 1.0f - s / denom;               // :91
+    }
 }
 
 // One wave per search slot; inputs are the packed per-slot records (device_backend.h).
@@ -396,16 +444,96 @@ __device__ __forceinline__ void measure_pass(const float *__restrict__ rows, con
     }
 }
 
+// int8 records: NP candidates per lane group, every load of the pass issued before any arithmetic (one
+// memory round trip for up to 8 * NP records); qs = the query's record staged in LDS.
+template <int NP, int NB>
+__device__ __forceinline__ void measure_pass_i8(const float *__restrict__ rows, int pitch, const float *qs, const int *nbuf, float *dbuf,
+                                                int p0, int m, int lane)
+{
+    const int grp = lane >> 3, j = lane & 7;
+    const int *a[NP];
+    int cidx[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int c = p0 + grp + 8 * p;
+        cidx[p] = c;
+        const int id = nbuf[c < m ? c : p0]; // idle groups shadow a valid record
+        a[p] = reinterpret_cast<const int *>(rows + (size_t)id * pitch);
+    }
+    const int *iq = reinterpret_cast<const int *>(qs);
+    const int nblk = NB > 0 ? NB : (pitch >> 3);
+    int acc[NP], tr[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { acc[p] = 0; tr[p] = 0; }
+    if constexpr (NB > 0) {
+        int w[NP][NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) w[p][k] = a[p][8 * k + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int y = iq[8 * k + j];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (k == NB - 1) { if (j >= 6) tr[p] = w[p][k]; else acc[p] = dot4_i8(w[p][k], y, acc[p]); }
+                else acc[p] = dot4_i8(w[p][k], y, acc[p]);
+            }
+        }
+    } else {
+        for (int k = 0; k < nblk; ++k) {
+            const int y = iq[8 * k + j];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int wv = a[p][8 * k + j];
+                if (k == nblk - 1 && j >= 6) tr[p] = wv;
+                else acc[p] = dot4_i8(wv, y, acc[p]);
+            }
+        }
+    }
+    const float sq = __int_as_float(iq[pitch - 2]);
+    const int nq = iq[pitch - 1];
+    const int g6 = (lane & ~7) | 6, g7 = (lane & ~7) | 7;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int dot = group_sum_i32(acc[p]);
+        const float sa = __int_as_float(__shfl(tr[p], g6, 64));
+        const int na = __shfl(tr[p], g7, 64);
+        const float r = i8_epilogue(sa, na, sq, nq, dot);
+        if (j == 0 && cidx[p] < m) dbuf[cidx[p]] = r;
+    }
+}
+template <int NP>
+__device__ __forceinline__ void measure_pass_i8_any(const float *rows, int pitch, const float *qs, const int *nbuf, float *dbuf, int p0, int m, int lane)
+{
+    // the common record sizes keep their words in registers: 128 B (dim <= 120), 192 B, 256 B
+    if (pitch == 32) measure_pass_i8<NP, 4>(rows, pitch, qs, nbuf, dbuf, p0, m, lane);
+    else if (pitch == 48) measure_pass_i8<NP, 6>(rows, pitch, qs, nbuf, dbuf, p0, m, lane);
+    else if (pitch == 16) measure_pass_i8<NP, 2>(rows, pitch, qs, nbuf, dbuf, p0, m, lane);
+    else measure_pass_i8<NP, 0>(rows, pitch, qs, nbuf, dbuf, p0, m, lane);
+}
+
 template <int METRIC>
 __device__ __forceinline__ void measure_all(const float *rows, const double *row_sn, int dim, const float *qs, double sb,
                                             const int *nbuf, float *dbuf, int m, int lane)
 {
+    if constexpr (METRIC == M_I8) {
+        for (int p0 = 0; p0 < m; p0 += 32) {
+            const int left = m - p0;
+            if (left > 24) measure_pass_i8_any<4>(rows, dim, qs, nbuf, dbuf, p0, m, lane);
+            else if (left > 16) measure_pass_i8_any<3>(rows, dim, qs, nbuf, dbuf, p0, m, lane);
+            else if (left > 8) measure_pass_i8_any<2>(rows, dim, qs, nbuf, dbuf, p0, m, lane);
+            else measure_pass_i8_any<1>(rows, dim, qs, nbuf, dbuf, p0, m, lane);
+        }
+    } else {
     for (int p0 = 0; p0 < m; p0 += 32) {
         int left = m - p0;
         if (left > 24) measure_pass<METRIC, 4>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
         else if (left > 16) measure_pass<METRIC, 3>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
         else if (left > 8) measure_pass<METRIC, 2>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
         else measure_pass<METRIC, 1>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
+    }
     }
 }
 
@@ -1724,6 +1852,55 @@ row_sqrtnorm_kernel(const float *__restrict__ rows, int dim, long long first, in
 #endif
 
 // exposed for tests: sqrt_rn over an array
+#ifdef HNSW_HOST_TU
+// float rows -> int8 records (see the layout above): one wave per row; lane l owns elements 4l .. 4l+3 of
+// each 256-element stretch.  max and the integer sum are exact in any order.
+__global__ void __launch_bounds__(256)
+quantize_rows_kernel(const float *__restrict__ src, int dim, int n, float *__restrict__ dst, long long first, int pitch)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float *x = src + (size_t)r * dim;
+    int *rec = reinterpret_cast<int *>(dst + (size_t)(first + r) * pitch);
+    float m = 0.0f;
+    for (int i = lane; i < dim; i += 64) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float scale = m / 127.0f;
+    int sumsq = 0;
+    const int nwords = pitch - 2;
+    for (int w = lane; w < nwords; w += 64) {
+        unsigned packed = 0u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * w + t;
+            int q = 0;
+            if (i < dim && scale > 0.0f) {
+                const float v = __builtin_rintf(x[i] / scale);
+                q = (int)fminf(fmaxf(v, -127.0f), 127.0f);
+            }
+            sumsq += q * q;
+            packed |= (unsigned)(q & 0xff) << (8 * t);
+        }
+        rec[w] = (int)packed;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sumsq += __shfl_xor(sumsq, o, 64);
+    if (lane == 0) { rec[pitch - 2] = __float_as_int(scale); rec[pitch - 1] = sumsq; }
+}
+// records -> the dequantised float rows q_i * scale (hnswdev_download_rows on an int8 context)
+__global__ void __launch_bounds__(256)
+dequantize_rows_kernel(const float *__restrict__ recs, int pitch, long long first, int n, int dim, float *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n * dim) return;
+    const int r = (int)(t / dim), i = (int)(t % dim);
+    const int *rec = reinterpret_cast<const int *>(recs + (size_t)(first + r) * pitch);
+    const int q = (int)(signed char)((rec[i >> 2] >> (8 * (i & 3))) & 0xff);
+    out[t] = (float)q * __int_as_float(rec[pitch - 2]);
+}
+#endif
 #ifdef HNSW_HOST_TU // non-template kernels: only the unit that launches them defines them
 __global__ void sqrt_rn_kernel(const double *in, double *out, int n)
 {

@@ -53,6 +53,7 @@ static int parse_metric(const char *distance_metric) // :47-60
     if (!std::strcmp(distance_metric, "sq_euclid")) return HNSWDEV_SQ_EUCLID;
     if (!std::strcmp(distance_metric, "cosine")) return HNSWDEV_COSINE;
     if (!std::strcmp(distance_metric, "ucosine")) return HNSWDEV_UCOSINE;
+    if (!std::strcmp(distance_metric, "sq_euclid_i8")) return HNSWDEV_SQ_EUCLID_I8; // not in the reference: int8 rows (BASELINE config 5)
     return -1;
 }
 

@@ -601,7 +601,7 @@ struct Tick {
 // ------------------------------------------------------------------------------------
 HnswIndex *HnswIndex::create(int metric, const Params &p, std::string &err)
 {
-    if (metric < 0 || metric > 2) { err = "Unsupported distance metric"; return nullptr; }
+    if (metric < 0 || metric > 3) { err = "Unsupported distance metric"; return nullptr; }
     int ndev = hnswdev_device_count();
     if (ndev <= 0) {
         err = "HNSWIndex MI355X backend: no HIP device available (" + get_dev_error() +
@@ -1196,6 +1196,7 @@ int HnswIndex::serialize(const char *path, std::string &err)
 {
     if (!path) { err = "System.ArgumentNullException: filePath"; return -1; }
     if (failed(err)) return -1;
+    if (metric_ == HNSWDEV_SQ_EUCLID_I8) { err = "System.NotSupportedException: Serialize: the snapshot format stores float items; an int8 index keeps quantised records only"; return -1; }
     if (!refresh_host_lists(err)) return -1;
     SnapshotParams sp;
     sp.max_edges = p_.max_edges;
@@ -1214,6 +1215,7 @@ int HnswIndex::serialize(const char *path, std::string &err)
 HnswIndex *HnswIndex::deserialize(int metric, const Params &backend, const char *path, std::string &err)
 {
     if (!path) { err = "System.ArgumentNullException: filePath"; return nullptr; }
+    if (metric == HNSWDEV_SQ_EUCLID_I8) { err = "System.NotSupportedException: Deserialize: not available for the int8 metric"; return nullptr; }
     const int fd = ::open(path, O_RDONLY);
     if (fd < 0) { err = std::string("System.IO.FileNotFoundException: Could not find file '") + path + "'"; return nullptr; }
     struct stat st;

@@ -1,0 +1,7 @@
+// traverse_i8_search.hip -- instantiates graph_search_kernel for M_I8 (int8 records, every register-set count,
+// both visited-set representations).  Device code: device_kernels.h; the split exists for build time.
+#include "device_kernels.h"
+
+namespace hnsw {
+HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_SEARCH, M_I8)
+} // namespace hnsw

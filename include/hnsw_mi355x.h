@@ -149,7 +149,12 @@ int hnsw_mi355x_set_profiling(void *handle, int enabled);
  *     (src/HNSWIndex/GraphData.cs:255-277) at the 14 call sites of SURVEY.md 8a.
  * ===================================================================================== */
 
-enum { HNSWDEV_SQ_EUCLID = 0, HNSWDEV_COSINE = 1, HNSWDEV_UCOSINE = 2 };
+/* 0-2: the reference's three float metrics (HNSWIndexExports.cs:47-60).  3: squared Euclidean distance on
+ * int8-quantised rows with one float scale per row (BASELINE config 5; no reference counterpart) -- rows and
+ * queries still cross the boundary as float32 and are quantised on the device, q = rint(x / scale), scale =
+ * max|x| / 127; the distance is that of the dequantised vectors, computed from the exact int32 dot product
+ * (metric name "sq_euclid_i8" for hnsw_create). */
+enum { HNSWDEV_SQ_EUCLID = 0, HNSWDEV_COSINE = 1, HNSWDEV_UCOSINE = 2, HNSWDEV_SQ_EUCLID_I8 = 3 };
 
 typedef struct hnswdev_stats {
     uint64_t launches;      /* distance-kernel launches */

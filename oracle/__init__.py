@@ -15,7 +15,7 @@ import numpy as np
 _DIR = Path(__file__).resolve().parent
 _SO = _DIR / "_build" / "libhnsw_oracle.so"
 
-METRICS = {"sq_euclid": 0, "cosine": 1, "ucosine": 2}
+METRICS = {"sq_euclid": 0, "cosine": 1, "ucosine": 2, "sq_euclid_i8": 3}
 
 _F = ct.POINTER(ct.c_float)
 _I = ct.POINTER(ct.c_int)
@@ -45,6 +45,9 @@ def lib():
         L.orc_add.argtypes = [ct.c_void_p, _F, ct.c_int, _I]
         L.orc_add_batched.argtypes = [ct.c_void_p, _F, ct.c_int, _I, ct.c_int]
         L.orc_add_batched_mt.argtypes = [ct.c_void_p, _F, ct.c_int, _I, ct.c_int, ct.c_int]
+        L.orc_i8_pitch.argtypes = [ct.c_int]
+        L.orc_i8_quantize.argtypes = [_F, ct.c_int, _I]
+        L.orc_i8_quantize.restype = None
         L.orc_rng_skip.argtypes = [ct.c_void_p, ct.c_int]
         L.orc_rng_skip.restype = None
         L.orc_import_nodes.argtypes = [ct.c_void_p, _F, _I, ct.c_int, ct.c_int]
@@ -122,6 +125,19 @@ def dist_pairs(name, rows, a, b, use_avx=False):
     out = np.empty(a.size, dtype=np.float32)
     lib().orc_dist_pairs(METRICS[name], _pf(rows), rows.shape[1], _pi(a), _pi(b), a.size, _pf(out), int(use_avx))
     return out
+
+
+def i8_quantize(x):
+    """The int8 record of each row of x (see oracle/hnsw_oracle.c "int8 rows"): (q int8 [n, dim], scale float32 [n],
+    sumsq int32 [n])."""
+    x = _f32(x).reshape(-1, np.shape(x)[-1])
+    n, dim = x.shape
+    pitch = lib().orc_i8_pitch(dim)
+    rec = np.empty((n, pitch), dtype=np.int32)
+    for i in range(n):
+        lib().orc_i8_quantize(_pf(x[i]), dim, _pi(rec[i]))
+    q = rec[:, :pitch - 2].copy().view(np.int8)[:, :dim]
+    return q, rec[:, pitch - 2].copy().view(np.float32), rec[:, pitch - 1].copy()
 
 
 def dotnet_random_next(seed, n):

@@ -41,7 +41,7 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
-enum { ORC_SQ_EUCLID = 0, ORC_COSINE = 1, ORC_UCOSINE = 2 };
+enum { ORC_SQ_EUCLID = 0, ORC_COSINE = 1, ORC_UCOSINE = 2, ORC_SQ_EUCLID_I8 = 3 };
 
 typedef struct { int id; float dist; } nd_t; /* src/HNSWIndex/NodeDistance.cs:5-14 */
 
@@ -201,6 +201,61 @@ static float cosine_avx(const float *a, const float *b, int n)
 
 typedef float (*metric_fn)(const float *, const float *, int);
 
+/* ------------------------------------------------------------------------------------
+ * int8 rows with one float scale per row (BASELINE config 5).  NO reference counterpart: the
+ * reference is generic over TDistance (src/HNSWIndex/HNSWIndex.cs:6) and ships float metrics only,
+ * so this metric is the BUILDER'S OWN definition, stated here and implemented identically by the
+ * HIP kernels (hnswindex.net_amd/csrc/device_kernels.h "int8 rows"); what the tests hold is
+ * product == this restatement, bit for bit.
+ *   record of `pitch` 32-bit words (a multiple of 16): [pitch-2 words: the elements, four int8 per
+ *   word, little endian, zero padded | scale (float) | sumsq (int32)]
+ *   scale = max|x| / 127 (float division); q_i = clamp(rintf(x_i / scale), -127, 127), 0 when the
+ *   scale is not positive; sumsq = sum q_i^2
+ *   distance(a, b) = (float)((A + B) - 2*C),  A = (sa*sa)*na, B = (sb*sb)*nb, C = (sa*sb)*dot in
+ *   double, dot = sum q_a q_b in int32 -- the squared Euclidean distance of the dequantised vectors.
+ * Inside the oracle an int8 index keeps ix->dim = pitch (records are addressed like float rows);
+ * vectors arrive at the API as `udim` floats and are quantised on entry.
+ * ---------------------------------------------------------------------------------- */
+static int i8_pitch(int udim) { return (((udim + 3) / 4 + 2) + 15) & ~15; }
+static void i8_quantize(const float *x, int udim, float *rec, int pitch)
+{
+    float m = 0.0f;
+    for (int i = 0; i < udim; i++) m = fmaxf(m, fabsf(x[i]));
+    const float scale = m / 127.0f;
+    int32_t *w = (int32_t *)rec;
+    int sumsq = 0;
+    for (int k = 0; k < pitch - 2; k++) {
+        uint32_t packed = 0;
+        for (int t = 0; t < 4; t++) {
+            int i = 4 * k + t, q = 0;
+            if (i < udim && scale > 0.0f) {
+                float v = rintf(x[i] / scale);
+                v = fminf(fmaxf(v, -127.0f), 127.0f);
+                q = (int)v;
+            }
+            sumsq += q * q;
+            packed |= (uint32_t)(q & 0xff) << (8 * t);
+        }
+        w[k] = (int32_t)packed;
+    }
+    memcpy(&w[pitch - 2], &scale, 4);
+    w[pitch - 1] = sumsq;
+}
+static float sq_euclid_i8(const float *a, const float *b, int pitch)
+{
+    const int8_t *qa = (const int8_t *)a, *qb = (const int8_t *)b;
+    const int32_t *wa = (const int32_t *)a, *wb = (const int32_t *)b;
+    int32_t dot = 0;
+    for (int i = 0; i < 4 * (pitch - 2); i++) dot += (int32_t)qa[i] * (int32_t)qb[i];
+    float sa, sb;
+    memcpy(&sa, &wa[pitch - 2], 4);
+    memcpy(&sb, &wb[pitch - 2], 4);
+    const double A = ((double)sa * (double)sa) * (double)wa[pitch - 1];
+    const double B = ((double)sb * (double)sb) * (double)wb[pitch - 1];
+    const double C = ((double)sa * (double)sb) * (double)dot;
+    return (float)((A + B) - 2.0 * C);
+}
+
 static int cpu_has_avx2_fma(void)
 {
 #if ORC_HAVE_AVX2
@@ -212,6 +267,7 @@ static int cpu_has_avx2_fma(void)
 
 static metric_fn pick_metric(int metric, int want_avx)
 {
+    if (metric == ORC_SQ_EUCLID_I8) return sq_euclid_i8; /* integer arithmetic: one form */
 #if ORC_HAVE_AVX2
     if (want_avx && cpu_has_avx2_fma()) {
         if (metric == ORC_SQ_EUCLID) return sq_euclid_avx;
@@ -514,7 +570,8 @@ typedef struct {
 } visited_t;
 
 typedef struct {
-    int dim, metric;
+    int dim, metric; /* dim: floats per stored row (int8: the record pitch) */
+    int udim;        /* elements per vector as the caller sees them */
     int max_edges, min_nn, max_candidates, seed, allow_removals, remove_max_candidates;
     double dist_rate;
     int capacity, length, count, entry;
@@ -530,6 +587,19 @@ typedef struct {
 } index_t;
 
 typedef struct { index_t *ix; visited_t *vis; uint64_t n_eval; } sctx_t;
+
+/* Vectors as they arrive at the API (n x udim floats) -> what the index stores and measures (n x dim):
+ * themselves, or their int8 records.  *tmp must be freed by the caller (NULL when nothing was made). */
+static const float *incoming(const index_t *ix, const float *v, int n, float **tmp)
+{
+    *tmp = NULL;
+    if (ix->metric != ORC_SQ_EUCLID_I8 || !v || n <= 0) return v;
+    float *r = (float *)malloc(sizeof(float) * (size_t)n * (size_t)ix->dim);
+    for (int i = 0; i < n; i++) i8_quantize(v + (size_t)i * (size_t)ix->udim, ix->udim, r + (size_t)i * (size_t)ix->dim, ix->dim);
+    *tmp = r;
+    return r;
+}
+
 
 static void visited_init(visited_t *v, int n) { v->ver = (uint16_t *)calloc((size_t)(n > 0 ? n : 1), 2); v->len = n > 0 ? n : 1; v->cur = 0; }
 static void visited_free(visited_t *v) { free(v->ver); v->ver = NULL; }
@@ -904,11 +974,14 @@ ORC_API int orc_add_batched(void *h, const float *v, int n, int *out_ids, int ma
     sctx_t c = {ix, &ix->vis, 0};
     int *ids = (int *)malloc(sizeof(int) * (size_t)n);
     int m = 0;
+    float *tmp;
+    v = incoming(ix, v, n, &tmp);
     for (int i = 0; i < n; i++) {
         int id = alloc_node(ix, v + (size_t)i * (size_t)ix->dim);
         if (out_ids) out_ids[i] = id;
         if (id >= 0) ids[m++] = id;
     }
+    free(tmp);
     int p = 0;
     while (p < m) {
         if (ix->entry < 0) { ix->entry = ids[p++]; continue; }
@@ -994,11 +1067,14 @@ ORC_API int orc_add_batched_mt(void *h, const float *v, int n, int *out_ids, int
     sctx_t c = {ix, &ix->vis, 0};
     int *ids = (int *)malloc(sizeof(int) * (size_t)n);
     int m = 0;
+    float *tmp;
+    v = incoming(ix, v, n, &tmp);
     for (int i = 0; i < n; i++) {
         int id = alloc_node(ix, v + (size_t)i * (size_t)ix->dim);
         if (out_ids) out_ids[i] = id;
         if (id >= 0) ids[m++] = id;
     }
+    free(tmp);
     visited_t *vis = (visited_t *)malloc(sizeof(visited_t) * (size_t)threads);
     for (int t = 0; t < threads; t++) visited_init(&vis[t], ix->capacity);
     int p = 0;
@@ -1201,8 +1277,10 @@ ORC_API int orc_length(void *h) { return ((index_t *)h)->length; }
 ORC_API void *orc_create(int dim, int metric, int max_edges, double dist_rate, int min_nn, int max_candidates,
                          int collection_size, int seed, int allow_removals, int use_avx)
 {
-    if (dim <= 0 || metric < 0 || metric > 2) return NULL;
+    if (dim <= 0 || metric < 0 || metric > 3) return NULL;
     index_t *ix = (index_t *)calloc(1, sizeof(index_t));
+    ix->udim = dim;
+    if (metric == ORC_SQ_EUCLID_I8) dim = i8_pitch(dim);
     ix->dim = dim; ix->metric = metric; ix->max_edges = max_edges; ix->dist_rate = dist_rate;
     ix->min_nn = min_nn; ix->max_candidates = max_candidates; ix->seed = seed; ix->allow_removals = allow_removals;
     ix->capacity = collection_size > 0 ? collection_size : 1;
@@ -1239,12 +1317,15 @@ ORC_API int orc_add(void *h, const float *v, int n, int *out_ids)
 {
     index_t *ix = (index_t *)h;
     if (!ix || !v || n <= 0) return 0;
+    float *tmp;
+    v = incoming(ix, v, n, &tmp);
     sctx_t c = {ix, &ix->vis, 0};
     for (int i = 0; i < n; i++) {
         int id = add_one(&c, v + (size_t)i * (size_t)ix->dim);
         if (out_ids) out_ids[i] = id;
     }
     ix->n_eval += c.n_eval;
+    free(tmp);
     return n;
 }
 
@@ -1305,11 +1386,14 @@ ORC_API int orc_knn_query(void *h, const float *q, int n, int k, int *out_ids, f
     index_t *ix = (index_t *)h;
     if (!ix) return 0;
     if (n <= 0 || k <= 0) return 0;
+    float *tmp;
+    q = incoming(ix, q, n, &tmp);
     if (threads <= 1) {
         sctx_t c = {ix, &ix->vis, 0};
         for (int i = 0; i < n; i++)
             knn_one(&c, q + (size_t)i * (size_t)ix->dim, k, out_ids + (size_t)i * (size_t)k, out_d + (size_t)i * (size_t)k);
         ix->n_eval += c.n_eval;
+        free(tmp);
         return 0;
     }
     if (threads > 256) threads = 256;
@@ -1324,6 +1408,7 @@ ORC_API int orc_knn_query(void *h, const float *q, int n, int k, int *out_ids, f
         pthread_join(th[t], NULL);
         ix->n_eval += jobs[t].n_eval;
     }
+    free(tmp);
     return 0;
 }
 
@@ -1334,6 +1419,8 @@ ORC_API int orc_range_query(void *h, const float *q, int n, float range, int cap
 {
     index_t *ix = (index_t *)h;
     if (!ix) return -1;
+    float *tmp;
+    q = incoming(ix, q, n, &tmp);
     sctx_t c = {ix, &ix->vis, 0};
     for (int i = 0; i < n; i++) {
         out_cnt[i] = 0;
@@ -1348,12 +1435,13 @@ ORC_API int orc_range_query(void *h, const float *q, int n, float range, int cap
             while (j >= 0 && float_compare_to(t.dist, res[j].dist) < 0) { res[j + 1] = res[j]; j--; }
             res[j + 1] = t;
         }
-        if (m > cap) { free(res); return -1; }
+        if (m > cap) { free(res); free(tmp); return -1; }
         for (int a = 0; a < m; a++) { out_ids[(size_t)i * cap + a] = res[a].id; out_d[(size_t)i * cap + a] = res[a].dist; }
         out_cnt[i] = m;
         free(res);
     }
     ix->n_eval += c.n_eval;
+    free(tmp);
     return 0;
 }
 
@@ -1365,6 +1453,9 @@ ORC_API int orc_import_nodes(void *h, const float *items, const int *levels, int
     index_t *ix = (index_t *)h;
     if (!ix || ix->length != 0 || n <= 0) return -1;
     while (ix->capacity < n) grow(ix);
+    if (ix->metric == ORC_SQ_EUCLID_I8) { /* quantised straight into the item array */
+        for (int i = 0; i < n; i++) i8_quantize(items + (size_t)i * (size_t)ix->udim, ix->udim, ix->items + (size_t)i * (size_t)ix->dim, ix->dim);
+    } else
     memcpy(ix->items, items, sizeof(float) * (size_t)n * (size_t)ix->dim);
     for (int i = 0; i < n; i++) { node_init(ix, &ix->nodes[i], levels[i]); ix->dense[i] = i; ix->sparse[i] = i; }
     ix->length = n;
@@ -1434,8 +1525,20 @@ ORC_API uint64_t orc_graph_hash(void *h)
 /* --- unit pieces --- */
 ORC_API float orc_metric(int metric, const float *a, const float *b, int n, int use_avx)
 {
+    if (metric == ORC_SQ_EUCLID_I8) { /* a, b: n floats each, quantised here */
+        int pitch = i8_pitch(n);
+        float *ra = (float *)malloc(sizeof(float) * 2 * (size_t)pitch), *rb = ra + pitch;
+        i8_quantize(a, n, ra, pitch);
+        i8_quantize(b, n, rb, pitch);
+        float d = sq_euclid_i8(ra, rb, pitch);
+        free(ra);
+        return d;
+    }
     return pick_metric(metric, use_avx)(a, b, n);
 }
+/* the int8 record of one vector (pitch words, see the layout above) and the record size for a dimension */
+ORC_API int orc_i8_pitch(int dim) { return i8_pitch(dim); }
+ORC_API void orc_i8_quantize(const float *x, int dim, int32_t *record) { i8_quantize(x, dim, (float *)record, i8_pitch(dim)); }
 ORC_API int orc_has_avx2(void) { return cpu_has_avx2_fma(); }
 
 /* one query vs many rows: out[i] = metric(rows[ids[i]], q) -- the checker for the HIP
@@ -1443,12 +1546,20 @@ ORC_API int orc_has_avx2(void) { return cpu_has_avx2_fma(); }
 ORC_API void orc_dist_query_rows(int metric, const float *rows, int dim, const float *q, const int *ids, int n,
                                  float *out, int use_avx)
 {
+    if (metric == ORC_SQ_EUCLID_I8) {
+        for (int i = 0; i < n; i++) out[i] = orc_metric(metric, rows + (size_t)ids[i] * (size_t)dim, q, dim, 0);
+        return;
+    }
     metric_fn f = pick_metric(metric, use_avx);
     for (int i = 0; i < n; i++) out[i] = f(rows + (size_t)ids[i] * (size_t)dim, q, dim);
 }
 ORC_API void orc_dist_pairs(int metric, const float *rows, int dim, const int *a, const int *b, int n, float *out,
                             int use_avx)
 {
+    if (metric == ORC_SQ_EUCLID_I8) {
+        for (int i = 0; i < n; i++) out[i] = orc_metric(metric, rows + (size_t)a[i] * (size_t)dim, rows + (size_t)b[i] * (size_t)dim, dim, 0);
+        return;
+    }
     metric_fn f = pick_metric(metric, use_avx);
     for (int i = 0; i < n; i++) out[i] = f(rows + (size_t)a[i] * (size_t)dim, rows + (size_t)b[i] * (size_t)dim, dim);
 }
@@ -1521,9 +1632,12 @@ ORC_API int orc_search_layer(void *h, int entry_id, int layer, int k, const floa
     index_t *ix = (index_t *)h;
     sctx_t c = {ix, &ix->vis, 0};
     nd_t *res;
+    float *tmp;
+    q = incoming(ix, q, 1, &tmp);
     int n = search_layer(&c, entry_id, layer, k, q, &res);
     for (int i = 0; i < n; i++) { out_ids[i] = res[i].id; out_d[i] = res[i].dist; }
     free(res);
+    free(tmp);
     ix->n_eval += c.n_eval;
     return n;
 }
@@ -1531,7 +1645,10 @@ ORC_API int orc_find_entry_point(void *h, int dst_layer, const float *q)
 {
     index_t *ix = (index_t *)h;
     sctx_t c = {ix, &ix->vis, 0};
+    float *tmp;
+    q = incoming(ix, q, 1, &tmp);
     int r = find_entry_point(&c, dst_layer, q);
+    free(tmp);
     ix->n_eval += c.n_eval;
     return r;
 }

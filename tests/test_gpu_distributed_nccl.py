@@ -3,8 +3,12 @@ one HIP runtime.  A single-GPU box cannot run two NCCL ranks on one card, so thi
 world_size-1 group: it exercises process-group creation, the packed all-gather of
 hnswindex.net_amd.distributed on CUDA tensors and the library's own stream side by side; the
 2-rank logic itself is covered on gloo in tests/test_distributed_gloo.py."""
+import json
 import os
 import socket
+import subprocess
+import sys
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -57,3 +61,23 @@ def test_nccl_group_and_library_coexist():
         assert (ref.knn_query(q, 10)[0] == ids).all()
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_gpu_with_the_product_searcher(tmp_path):
+    # The sharded KnnQuery with the PRODUCT as every rank's local searcher: two ranks (gloo -- two NCCL ranks
+    # cannot share one card) on this one GPU, started as child processes of a launcher.  Each builds its
+    # replica, answers its shard, and the gathered result must equal one rank answering everything.
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "tests" / "dist_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for rank in (0, 1):
+        res = json.loads((tmp_path / f"rank{rank}.json").read_text())
+        assert res["replicas_identical"] and res["dstNone"] and res["dst0"] and res["shard_calls"], res
+        assert res["native_lib"].endswith("HNSWIndex.Native.so")
+

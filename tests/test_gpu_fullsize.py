@@ -174,3 +174,33 @@ def test_c4_size_10m_128_in_12500_query_calls():
     del ix, x
     gc.collect()
 
+
+def test_c5_size_10m_96_int8():
+    # BASELINE configs[4]: 10M x 96 int8-quantised vectors with one float scale each, squared Euclidean
+    # distance from the exact integer dot product; ids bit-exact against the CPU restatement of the same
+    # definition (tests/test_int8.py holds the definition itself).  Queried in the 12 500-row calls of one
+    # of 8 ranks, like C4.
+    import hnswindex
+    n, dim, M = 10_000_000, 96, 16
+    x = _uniform_chunked(n, dim, 65537)
+    ix = hnswindex.Index(dim, "sq_euclid_i8")
+    ix.set_collection_size(n); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_allow_removals(False)
+    ids = ix.add(x)
+    assert ids[0] == 0 and ids[-1] == n - 1 and (np.diff(ids) == 1).all()
+    _check_structure(ix, n, M)
+    q_all = uniform(100_000, dim, 65538)
+    lo, hi = hnswindex.net_amd.distributed.shard_bounds(100_000, 8, 3)
+    ix.reset_stats()
+    ids10, d10 = ix.knn_query(q_all[lo:hi], 10)
+    again_ids, again_d = ix.knn_query(q_all[lo:hi], 10)
+    assert (ids10 == again_ids).all() and d10.tobytes() == again_d.tobytes()
+    assert (ids10 >= 0).all() and (np.diff(d10, axis=1) >= 0).all()
+    assert (np.sort(ids10, axis=1)[:, 1:] != np.sort(ids10, axis=1)[:, :-1]).all()
+    for i in range(0, 12_500, 250):
+        assert oracle.dist_query_rows("sq_euclid_i8", x, q_all[lo + i], ids10[i]).tobytes() == d10[i].tobytes()
+    st = ix.stats()
+    assert st["search_overflows"] == 0 and st["visited_hash_launches"] == 2 and st["row_bytes"] == 100
+    _oracle_sample_is_bit_exact(ix, x, q_all[lo:hi], 10, "sq_euclid_i8", M, 128, 200, ids10, d10, 2000)
+    del ix, x
+    gc.collect()
+
