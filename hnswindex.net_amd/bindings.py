@@ -24,6 +24,9 @@ def _load_lib():
             import torch  # noqa: F401
         except Exception:  # pragma: no cover - torch absent: /opt/rocm's runtime is used
             pass
+    override = os.environ.get("HNSW_MI355X_LIB")  # diagnostic builds only (e.g. the phase-clock variant, tools/)
+    if override:
+        return ct.CDLL(override)
     if not LIB_PATH.exists():
         raise FileNotFoundError(
             f"Native library missing {LIB_PATH}: run `python -c 'import __graft_entry__ as g; g.build()'` "

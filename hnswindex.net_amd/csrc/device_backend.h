@@ -3,9 +3,11 @@
 // hnsw_index.cpp) both sit on this class.  Nothing here computes a distance on the CPU.
 #pragma once
 #include <cstddef>
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "../../include/hnsw_mi355x.h"
 
@@ -72,6 +74,12 @@ public:
     bool reserve(long long capacity);
     bool upload_rows(int first_id, int n, const float *rows);
     bool download_rows(int first_id, int n, float *rows);
+    // The same upload in the background: a helper thread stages the rows through its own pinned buffers
+    // and stream while the caller already works on the rows that have landed.  begin() returns at once;
+    // wait(upto) blocks until every row with id < upto is resident (upto < 0: all of them, and the
+    // helper has finished).  `rows` stays borrowed until wait(-1) returned.  Float metrics only.
+    bool upload_rows_begin(int first_id, int n, const float *rows);
+    bool upload_rows_wait(long long upto);
     // Replaces the resident query set (nq x dim); norms for cosine computed on device.
     bool set_queries(const float *queries, int nq);
 
@@ -112,6 +120,9 @@ public:
         int sel_stride;
     };
     bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res);
+    // insert_search_batch brings back the flags only; this fetches the selected ids into the arrays `res`
+    // names (the device-side link half never needs them on the host).
+    bool fetch_insert_selections(const InsertResults *res);
     // Keeps the HBM graph mirror in step with nodes appended on the host since the last call:
     // levels / upper offsets of nodes [first, first+n) and the pool tail [pool_from, pool_len).
     // Returns false (with no error set) when capacity is exceeded: caller falls back to set_graph.
@@ -201,6 +212,7 @@ private:
     size_t lp_grp_cap_[6] = {0, 0, 0, 0, 0, 0};
     int *lp_counters_ = nullptr;
     int last_insert_jobs_ = 0, last_insert_upper_ = 0, last_insert_stride_ = 0; // what insert_search_batch left on the device
+    int fetch_njobs_ = 0, fetch_nupper_ = 0;                                    // ... and what fetch_insert_selections would copy
     int *s_vistab_ = nullptr; // per-wave visited-id hash tables
     size_t s_vistab_cap_ = 0;
     int s_vistab_each_ = 0;
@@ -218,6 +230,8 @@ private:
     size_t s_sel_cap_ = 0, s_lcnt_cap_ = 0, s_selU_cap_ = 0, s_cntU_cap_ = 0, s_iflag_cap_ = 0;
     void *h_res_ = nullptr; // pinned: results of insert_search_batch
     size_t h_res_cap_ = 0;
+    int *s_order_ = nullptr; // insert search: processing order of a batch's jobs
+    size_t s_order_cap_ = 0;
     SearchHit *s_spill_ = nullptr;
     size_t s_spill_cap_ = 0;
     int *s_lk_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -237,6 +251,14 @@ private:
         bool busy = false, timed = false;
         int ngroups = 0;
     } lset_[2];
+    struct BgUpload {
+        std::thread th;
+        std::atomic<long long> resident{0}; // rows with id < resident have landed
+        std::atomic<bool> failed{false}, active{false};
+        std::string err;
+        void *stream = nullptr, *pin[2] = {nullptr, nullptr}, *ev[2] = {nullptr, nullptr};
+        size_t pin_bytes = 0;
+    } bg_;
     StepBuffers *abi_sb_[4] = {nullptr, nullptr, nullptr, nullptr}; // context-owned step-buffer sets: 0/1 handed out by hnswdev_step_buffers, 2/3 private to dist_query_batch (so it never moves buffers a caller holds)
     int *d_guard_ = nullptr;                      // guard flag of pair_distance_kernel
     int *pair_dev_ = nullptr;                     // dist_pair_batch: [a | b | out] on the device

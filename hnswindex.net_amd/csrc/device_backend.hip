@@ -162,6 +162,9 @@ Device::~Device()
 {
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) { (void)hipStreamSynchronize(S(stream_)); (void)hipStreamDestroy(S(stream_)); }
+    if (bg_.th.joinable()) bg_.th.join();
+    if (bg_.stream) (void)hipStreamDestroy(S(bg_.stream));
+    for (int i = 0; i < 2; ++i) { if (bg_.pin[i]) (void)hipHostFree(bg_.pin[i]); if (bg_.ev[i]) (void)hipEventDestroy((hipEvent_t)bg_.ev[i]); }
     for (StepBuffers *&sb : abi_sb_) { if (sb) free_step(sb); sb = nullptr; }
     if (d_guard_) (void)hipFree(d_guard_);
     if (q_stage_) (void)hipFree(q_stage_);
@@ -182,6 +185,7 @@ Device::~Device()
             for (int i = 0; i < 5; ++i) tl += (double)hl[i];
             fprintf(stderr, "[phase clocks, link] stage %.1f%% measure %.1f%% sort %.1f%% heuristic %.1f%% rest %.1f%% | appends %llu, prunes %llu, cycles/prune %.0f\n",
                     100 * hl[0] / tl, 100 * hl[1] / tl, 100 * hl[2] / tl, 100 * hl[3] / tl, 100 * hl[4] / tl, hl[6], hl[7], tl / (double)std::max(1ull, hl[7]));
+            if (h[9]) fprintf(stderr, "[phase clocks, insert] RelativeNeighborPruning %.1f%% of the insert jobs' cycles\n", 100.0 * (double)h[8] / (double)h[9]);
             fprintf(stderr, "[phase clocks] descent %.1f%% pop %.1f%% list %.1f%% visited %.1f%% rows %.1f%% push %.1f%% | expansions %llu, prefetch hits %llu (%.1f%%), cycles/expansion %.0f\n",
                     100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, h[7], h[6],
                     100.0 * h[6] / (double)std::max(1ull, h[7]), tot / (double)std::max(1ull, h[7]));
@@ -189,7 +193,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -261,6 +265,82 @@ bool Device::upload_rows(int first_id, int n, const float *rows)
     }
     HIP_OK(hipStreamSynchronize(S(stream_))); // `rows` is borrowed only for this call
     n_rows_hw_ = std::max(n_rows_hw_, (long long)first_id + n);
+    return true;
+}
+
+bool Device::upload_rows_begin(int first_id, int n, const float *rows)
+{
+    if (n <= 0) return true;
+    if (metric_ == M_I8 || bg_.active.load()) { set_dev_error("upload_rows_begin: not available (int8 rows, or an upload already in flight)"); return false; }
+    if (first_id < 0 || (long long)first_id + n > capacity_ || !rows) { set_dev_error("upload_rows: range outside capacity"); return false; }
+    if (!bind()) return false;
+    const size_t row_bytes = (size_t)dim_ * sizeof(float);
+    const size_t chunk_rows = std::max<size_t>(1, (8u << 20) / row_bytes);
+    if (!bg_.stream) {
+        hipStream_t st;
+        HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        bg_.stream = st;
+        for (int i = 0; i < 2; ++i) { hipEvent_t e; HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); bg_.ev[i] = e; }
+    }
+    if (bg_.pin_bytes < chunk_rows * row_bytes) {
+        for (int i = 0; i < 2; ++i) {
+            if (bg_.pin[i]) (void)hipHostFree(bg_.pin[i]);
+            bg_.pin[i] = nullptr;
+            HIP_OK(hipHostMalloc(&bg_.pin[i], chunk_rows * row_bytes, hipHostMallocDefault));
+        }
+        bg_.pin_bytes = chunk_rows * row_bytes;
+    }
+    bg_.resident.store(first_id);
+    bg_.failed.store(false);
+    bg_.active.store(true);
+    n_rows_hw_ = std::max(n_rows_hw_, (long long)first_id + n); // ids are valid from now on; their rows are awaited per batch
+    bg_.th = std::thread([this, first_id, n, rows, row_bytes, chunk_rows] {
+        auto fail = [&](const char *what, hipError_t e) { bg_.err = std::string(what) + ": " + hipGetErrorString(e); bg_.failed.store(true); };
+        hipError_t e = hipSetDevice(device_);
+        if (e != hipSuccess) { fail("hipSetDevice", e); return; }
+        hipStream_t st = S(bg_.stream);
+        size_t pending_rows[2] = {0, 0};
+        bool in_flight[2] = {false, false};
+        int b = 0;
+        long long landed = first_id;
+        for (size_t r0 = 0; r0 < (size_t)n; r0 += chunk_rows, b ^= 1) {
+            const size_t nr = std::min(chunk_rows, (size_t)n - r0);
+            if (in_flight[b]) { // this pinned buffer's previous copy must have left it
+                if ((e = hipEventSynchronize((hipEvent_t)bg_.ev[b])) != hipSuccess) { fail("hipEventSynchronize", e); return; }
+                landed += (long long)pending_rows[b];
+                bg_.resident.store(landed, std::memory_order_release);
+                in_flight[b] = false;
+            }
+            memcpy(bg_.pin[b], rows + r0 * dim_, nr * row_bytes);
+            if ((e = hipMemcpyAsync(d_rows_ + ((size_t)first_id + r0) * pitch_, bg_.pin[b], nr * row_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) { fail("hipMemcpyAsync", e); return; }
+            if (metric_ == M_COS) {
+                const int blocks = (int)(((long long)nr * 8 + 255) / 256);
+                hipLaunchKernelGGL(row_sqrtnorm_kernel, dim3(blocks), dim3(256), 0, st, d_rows_, pitch_, (long long)first_id + (long long)r0, (int)nr, d_row_sn_);
+            }
+            if ((e = hipEventRecord((hipEvent_t)bg_.ev[b], st)) != hipSuccess) { fail("hipEventRecord", e); return; }
+            pending_rows[b] = nr;
+            in_flight[b] = true;
+        }
+        for (int k = 0; k < 2; ++k, b ^= 1) // the two copies still in flight, oldest first
+            if (in_flight[b]) {
+                if ((e = hipEventSynchronize((hipEvent_t)bg_.ev[b])) != hipSuccess) { fail("hipEventSynchronize", e); return; }
+                landed += (long long)pending_rows[b];
+                bg_.resident.store(landed, std::memory_order_release);
+            }
+    });
+    return true;
+}
+
+bool Device::upload_rows_wait(long long upto)
+{
+    if (!bg_.active.load()) return true;
+    if (upto >= 0) {
+        while (bg_.resident.load(std::memory_order_acquire) < upto && !bg_.failed.load()) std::this_thread::yield();
+        if (!bg_.failed.load()) return true;
+    }
+    if (bg_.th.joinable()) bg_.th.join();
+    bg_.active.store(false);
+    if (bg_.failed.load()) { set_dev_error("background row upload failed: " + bg_.err); return false; }
     return true;
 }
 
@@ -479,8 +559,14 @@ void Device::reset_stats()
     stats_ = hnswdev_stats{};
     stats_.row_bytes = rb;
 #ifdef EXP_PHASE_CLOCKS
-    unsigned long long z[12] = {0};
+    unsigned long long z[12] = {0}, h[12] = {0};
     (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) == hipSuccess && h[9]) {
+        double tot = 0;
+        for (int i = 0; i < 6; ++i) tot += (double)h[i];
+        fprintf(stderr, "[phase clocks, insert] RelativeNeighborPruning %.1f%% of the insert jobs' cycles; descent %.1f%% of their traversal cycles\n",
+                100.0 * (double)h[8] / (double)h[9], 100.0 * (double)h[0] / tot);
+    }
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z);
 #endif
 }
@@ -690,12 +776,28 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     int *h_selU = reinterpret_cast<int *>(hb + b_sel0 + b_cnt0), *h_cntU = reinterpret_cast<int *>(hb + b_sel0 + b_cnt0 + b_selU);
     int *h_flag = reinterpret_cast<int *>(hb + b_sel0 + b_cnt0 + b_selU + b_cntU);
     unsigned long long *h_ev = reinterpret_cast<unsigned long long *>(hb + ((b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 7) & ~(size_t)7));
-    SearchJob *h_jobs = static_cast<SearchJob *>(pinned_stage(sizeof(SearchJob) * (size_t)chunk));
+    // staging: [jobs | processing order]
+    SearchJob *h_jobs = static_cast<SearchJob *>(pinned_stage((sizeof(SearchJob) + sizeof(int)) * (size_t)chunk));
     if (!h_jobs) return false;
+    int *h_order = reinterpret_cast<int *>(h_jobs + chunk);
+    if (!grow_dev(&s_order_, &s_order_cap_, (size_t)chunk)) return false;
     for (long long off = 0; off < njobs; off += chunk) {
         const int nj = (int)std::min<long long>(chunk, njobs - off);
         memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
         HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
+        // items that search several layers first (counting sort by first layer, descending; stable)
+        const int *d_order = nullptr;
+        {
+            int hist[64] = {0}, maxl = 0;
+            for (int i = 0; i < nj; ++i) { const int l = std::min(h_jobs[i].search_layer, 63); hist[l]++; maxl = std::max(maxl, l); }
+            if (maxl > 0 && nj > 1) {
+                int start[64], acc = 0;
+                for (int l = maxl; l >= 0; --l) { start[l] = acc; acc += hist[l]; }
+                for (int i = 0; i < nj; ++i) h_order[start[std::min(h_jobs[i].search_layer, 63)]++] = i;
+                HIP_OK(hipMemcpyAsync(s_order_, h_order, sizeof(int) * (size_t)nj, hipMemcpyHostToDevice, st));
+                d_order = s_order_;
+            }
+        }
         HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int), st));
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
@@ -707,7 +809,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
                        dim3(64), LDS, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
-                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0); \
+                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0, d_order); \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
     do {                                                                                                                   \
@@ -751,12 +853,8 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
             stats_.insert_timed_evals += *h_ev;
         }
     }
-    HIP_OK(hipMemcpyAsync(h_sel0, s_sel_, b_sel0, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipMemcpyAsync(h_cnt0, s_lcnt_, b_cnt0, hipMemcpyDeviceToHost, st));
-    if (n_upper > 0) {
-        HIP_OK(hipMemcpyAsync(h_selU, s_selU_, 4u * (size_t)n_upper * sel_stride, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipMemcpyAsync(h_cntU, s_cntU_, 4u * (size_t)n_upper, hipMemcpyDeviceToHost, st));
-    }
+    // Only the flags come back now: the selections stay on the device, where the link half reads them
+    // (link_batch_planned); a caller that links on the host fetches them (fetch_insert_selections).
     HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     for (int i = 0; i < njobs; ++i) {
@@ -766,7 +864,27 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     last_insert_jobs_ = njobs <= chunk ? njobs : 0; // a single launch left everything in place
     last_insert_upper_ = n_upper;
     last_insert_stride_ = sel_stride;
+    fetch_njobs_ = njobs;
+    fetch_nupper_ = n_upper;
     *res = InsertResults{h_sel0, h_cnt0, h_selU, h_cntU, h_flag, sel_stride};
+    return true;
+}
+
+// The selected ids of the last insert_search_batch, into the pinned arrays its InsertResults name.
+bool Device::fetch_insert_selections(const InsertResults *res)
+{
+    if (!res || fetch_njobs_ <= 0) return true;
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    const int njobs = fetch_njobs_, n_upper = fetch_nupper_, sel_stride = res->sel_stride;
+    HIP_OK(hipMemcpyAsync(const_cast<int *>(res->sel0), s_sel_, 4u * (size_t)njobs * sel_stride, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(const_cast<int *>(res->cnt0), s_lcnt_, 4u * (size_t)njobs, hipMemcpyDeviceToHost, st));
+    if (n_upper > 0) {
+        HIP_OK(hipMemcpyAsync(const_cast<int *>(res->selU), s_selU_, 4u * (size_t)n_upper * sel_stride, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(const_cast<int *>(res->cntU), s_cntU_, 4u * (size_t)n_upper, hipMemcpyDeviceToHost, st));
+    }
+    HIP_OK(hipStreamSynchronize(st));
+    fetch_njobs_ = 0;
     return true;
 }
 

@@ -31,7 +31,7 @@ enum { M_SQ = HNSWDEV_SQ_EUCLID, M_COS = HNSWDEV_COSINE, M_UCOS = HNSWDEV_UCOSIN
 //     dot = sum q_a q_b (int32, v_dot4_i32_i8: exact, any order)
 //     A = (sa*sa)*na,  B = (sb*sb)*nb,  C = (sa*sb)*dot      (doubles; the scale products are exact)
 //     d = (float)((A + B) - 2*C)
-// The CPU restatement (oracle/hnsw_oracle.c, sq_euclid_i8) does the same, so ids are bit-exact.
+// The test-side CPU restatement of this definition does the same, so ids are bit-exact.
 __device__ __forceinline__ float i8_epilogue(float sa, int na, float sb, int nb, int dot)
 {
     const double A = ((double)sa * (double)sa) * (double)na;
@@ -534,6 +534,107 @@ __device__ __forceinline__ void measure_all(const float *rows, const double *row
         else if (left > 8) measure_pass<METRIC, 2>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
         else measure_pass<METRIC, 1>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
     }
+    }
+}
+
+// The same pass against NQ vectors staged in LDS at once: every row is fetched ONCE and measured against
+// all of them (D[q * ds + c] = metric(row[ids[c]], qs_q)), each (row, vector) pair in exactly the lane order of
+// measure_pass -- so the bits are those of NQ separate passes, for a quarter of the row traffic and of the
+// dependent round trips.  Float metrics only.
+template <int METRIC, int NP, int NQ>
+__device__ __forceinline__ void measure_pass_multi(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                                                   const float *q0, const float *q1, const float *q2, const float *q3, const double *sbq,
+                                                   const int *ids, float *D, int ds, int p0, int m, int lane)
+{
+    const int grp = lane >> 3, j = lane & 7;
+    const float *qs[4] = {q0, q1, q2, q3};
+    const float *a[NP];
+    int cidx[NP];
+    float acc[NP][NQ];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int c = p0 + grp + 8 * p;
+        cidx[p] = c;
+        const int id = ids[c < m ? c : p0];
+        a[p] = rows + (size_t)id * dim;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[p][q] = 0.0f;
+    }
+    const int nblk = dim >> 3;
+    int k = 0;
+    for (; k + 16 <= nblk; k += 16) {
+        float x[NP][16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) x[p][kk] = a[p][8 * (k + kk) + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float y = qs[q][8 * (k + kk) + j];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    if (METRIC == M_SQ) {
+                        const float d = x[p][kk] - y;
+                        acc[p][q] = __builtin_fmaf(d, d, acc[p][q]);
+                    } else {
+                        const float pr = x[p][kk] * y;
+                        acc[p][q] = acc[p][q] + pr;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0); // keeps the NQ LDS reads of one step from being hoisted over the others (registers)
+        }
+    }
+    for (; k < nblk; ++k) {
+        float xr[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) xr[p] = a[p][8 * k + j];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float y = qs[q][8 * k + j];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (METRIC == M_SQ) {
+                    const float d = xr[p] - y;
+                    acc[p][q] = __builtin_fmaf(d, d, acc[p][q]);
+                } else {
+                    const float pr = xr[p] * y;
+                    acc[p][q] = acc[p][q] + pr;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        double sa = 0.0;
+        if (METRIC == M_COS) sa = row_sn[ids[cidx[p] < m ? cidx[p] : p0]];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float s = (METRIC == M_SQ) ? collapse_l2(acc[p][q]) : collapse_cos(acc[p][q]);
+            if (dim & 7) s = scalar_tail<METRIC>(s, a[p], qs[q], dim);
+            float r;
+            if (METRIC == M_SQ) r = s;
+            else if (METRIC == M_UCOS) r = 1.0f - s;
+            else {
+                const float denom = (float)(sa * sbq[q]);
+                r = (denom < 1e-30f) ? 1.0f : 1.0f - s / denom;
+            }
+            if (j == 0 && cidx[p] < m) D[q * ds + cidx[p]] = r;
+        }
+    }
+}
+template <int METRIC, int NQ>
+__device__ __forceinline__ void measure_multi(const float *rows, const double *row_sn, int dim, const float *q0, const float *q1,
+                                              const float *q2, const float *q3, const double *sbq, const int *ids, int m, float *D, int ds, int lane)
+{
+#pragma nounroll
+    for (int p0 = 0; p0 < m; p0 += 16) { // 16 rows x NQ vectors per pass: more rows in flight would spill (168 VGPRs)
+        const int left = m - p0;
+        if (left > 8) measure_pass_multi<METRIC, 2, NQ>(rows, row_sn, dim, q0, q1, q2, q3, sbq, ids, D, ds, p0, m, lane);
+        else measure_pass_multi<METRIC, 1, NQ>(rows, row_sn, dim, q0, q1, q2, q3, sbq, ids, D, ds, p0, m, lane);
     }
 }
 
@@ -1208,6 +1309,7 @@ __device__ inline void dev_dotnet_sort(ND *arr, int n, int *stk)
     }
 }
 
+__device__ __forceinline__ int nbcap_of(int max_edges) { return (max_edges + 1 + 7) & ~7; } // row stride of the grouped heuristic's distance table
 // Heuristic.RelativeNeighborPruning (Heuristic.cs:11-46) on cands[0..n) (LDS): writes the
 // selected ids to L.acc, returns their count.  The candidate under test is staged in L.qs2
 // and measured against ALL accepted rows at once (the reference's early break only skips
@@ -1215,7 +1317,8 @@ __device__ inline void dev_dotnet_sort(ND *arr, int n, int *stk)
 template <int METRIC>
 __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                                                          ND *cands, int n, int max_edges, const SearchLds &L, int lane,
-                                                         unsigned long long &evals, bool presorted = false)
+                                                         unsigned long long &evals, bool presorted = false,
+                                                         float *gscratch = nullptr, size_t gscratch_bytes = 0)
 {
     int *acc = L.acc;
     __syncthreads();
@@ -1248,10 +1351,100 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
     }
     __syncthreads();
     int rc = 0;
-    // The row of candidate i + 1 is fetched while candidate i is being tested (registers, then the
-    // other of two LDS buffers): one dependent memory round trip per candidate instead of two.
     constexpr int kPre = 4; // floats per lane: rows up to 256 floats; longer rows (bandwidth-bound anyway) are staged on demand
     const bool prefetch = dim <= 64 * kPre;
+    const int dimp = (dim + 3) & ~3;
+    constexpr int kPreG = 4; // the grouped form prefetches four rows at once: rows up to 256 floats
+    if constexpr (METRIC != M_I8) {
+        // Grouped form (rows up to 256 floats, when the caller lends scratch): FOUR candidates are tested per
+        // step.  Their rows sit in LDS; every accepted row is fetched once and measured against all four
+        // (measure_multi), the six pairs inside the group are measured from LDS alone, and the greedy pass
+        // :23-40 then runs over the four in order on those numbers -- a candidate is rejected by an id accepted
+        // before the group (D) or by an earlier member of the group that was accepted (P).  Same distances,
+        // same decisions, a quarter of the dependent round trips and of the row reads.
+        const size_t need = 2u * 4u * (size_t)dimp + 4u * 4u * (size_t)nbcap_of(max_edges) + 64u + 64u;
+        if (dim <= 64 * kPreG && gscratch && gscratch_bytes >= need) {
+            // (no indexed local arrays below: they would live in scratch memory)
+            auto gq = [&](int t) -> float * { return t < 2 ? L.qs2 + t * dimp : gscratch + (t - 2) * dimp; };
+            float *D = gscratch + 2 * dimp;
+            const int ds = nbcap_of(max_edges);
+            float *P = D + 4 * ds;                                  // P[u * 4 + t], u < t
+            double *sbq = reinterpret_cast<double *>(P + 16);       // cosine: sqrt-norms of the group's rows [0..4), of the next group's [4..8)
+            {   // stage the first group
+                const int gsz = min(4, n);
+                for (int t = 0; t < gsz; ++t) {
+                    const float *crow = rows + (size_t)cands[t].id * dim;
+                    float *dst = gq(t);
+                    for (int e = lane; e < dim; e += 64) dst[e] = crow[e];
+                    if (METRIC == M_COS && lane == 0) sbq[t] = row_sn[cands[t].id];
+                }
+                __syncthreads();
+            }
+            for (int g0 = 0; g0 < n && rc < max_edges; g0 += 4) { // :23, four at a time
+                const int gsz = min(4, n - g0);
+                // the next group's rows: loads in flight while this group is tested
+                float pre0[kPreG], pre1[kPreG], pre2[kPreG], pre3[kPreG];
+                const int nsz = min(4, max(0, n - (g0 + 4)));
+#define HNSW_PRE_LOAD(T, PRE)                                                                          \
+                if (T < nsz) {                                                                         \
+                    const int nid = cands[g0 + 4 + T].id;                                              \
+                    const float *nrow = rows + (size_t)nid * dim;                                      \
+                    _Pragma("unroll") for (int e = 0; e < kPreG; ++e)                                  \
+                        if (64 * e < dim) PRE[e] = lane + 64 * e < dim ? nrow[lane + 64 * e] : 0.0f;   \
+                    if (METRIC == M_COS && lane == 0) sbq[4 + T] = row_sn[nid];                        \
+                }
+                HNSW_PRE_LOAD(0, pre0) HNSW_PRE_LOAD(1, pre1) HNSW_PRE_LOAD(2, pre2) HNSW_PRE_LOAD(3, pre3)
+#undef HNSW_PRE_LOAD
+                const int rc0 = rc;
+                if (rc0 > 0) { // distanceFnc(s.Id, candidateId) :34 for every accepted s and the four candidates
+                    if (gsz == 4) measure_multi<METRIC, 4>(rows, row_sn, dim, gq(0), gq(1), gq(2), gq(3), sbq, acc, rc0, D, ds, lane);
+                    else if (gsz == 3) measure_multi<METRIC, 3>(rows, row_sn, dim, gq(0), gq(1), gq(2), gq(3), sbq, acc, rc0, D, ds, lane);
+                    else if (gsz == 2) measure_multi<METRIC, 2>(rows, row_sn, dim, gq(0), gq(1), gq(2), gq(3), sbq, acc, rc0, D, ds, lane);
+                    else measure_multi<METRIC, 1>(rows, row_sn, dim, gq(0), gq(1), gq(2), gq(3), sbq, acc, rc0, D, ds, lane);
+                    evals += (unsigned long long)rc0; // rows fetched
+                }
+                // pairs inside the group, from LDS: lane group p <-> pair (u, t), u < t
+                {
+                    const int pg = lane >> 3, j = lane & 7;
+                    const int pu = pg == 0 ? 0 : pg == 1 ? 0 : pg == 2 ? 1 : pg == 3 ? 0 : pg == 4 ? 1 : 2;
+                    const int pt = pg == 0 ? 1 : pg <= 2 ? 2 : 3;
+                    const bool live = pg < 6 && pt < gsz;
+                    double sa = 0.0, sb = 0.0;
+                    if (METRIC == M_COS) { sa = sbq[live ? pu : 0]; sb = sbq[live ? pt : 0]; }
+                    const float v = group_metric<METRIC>(gq(live ? pu : 0), gq(live ? pt : 0), dim, j, sa, sb);
+                    if (live && j == 0) P[pu * 4 + pt] = v;
+                }
+                __syncthreads();
+                unsigned in_group = 0u; // bit u: member u accepted
+                for (int t = 0; t < gsz && rc < max_edges; ++t) {
+                    const ND c = cands[g0 + t];
+                    bool rej = false;
+                    for (int r0 = 0; r0 < rc0; r0 += 64) {
+                        const int r = r0 + lane;
+                        const float dj = r < rc0 ? D[t * ds + r] : 0.0f;
+                        rej = rej || __ballot(r < rc0 && dj < c.dist) != 0ull;
+                    }
+                    for (int u = 0; u < t; ++u)
+                        if ((in_group >> u) & 1u) rej = rej || P[u * 4 + t] < c.dist;
+                    if (!rej) { if (lane == 0) acc[rc] = c.id; rc++; in_group |= 1u << t; }
+                }
+                __syncthreads();
+#define HNSW_PRE_STORE(T, PRE)                                                                         \
+                if (T < nsz) {                                                                         \
+                    float *dst = gq(T);                                                                \
+                    _Pragma("unroll") for (int e = 0; e < kPreG; ++e)                                  \
+                        if (64 * e < dim && lane + 64 * e < dim) dst[lane + 64 * e] = PRE[e];          \
+                    if (METRIC == M_COS && lane == 0) sbq[T] = sbq[4 + T];                             \
+                }
+                HNSW_PRE_STORE(0, pre0) HNSW_PRE_STORE(1, pre1) HNSW_PRE_STORE(2, pre2) HNSW_PRE_STORE(3, pre3)
+#undef HNSW_PRE_STORE
+                __syncthreads();
+            }
+            return rc;
+        }
+    }
+    // One candidate per step.  The row of candidate i + 1 is fetched while candidate i is being tested
+    // (registers, then the other of two LDS buffers): one dependent memory round trip per candidate instead of two.
     float *buf[2] = {L.qs2, L.qs3};
     int cur = 0;
     double sbc = 0.0, sbn = 0.0;
@@ -1459,6 +1652,9 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
     unsigned long long evals = 0;
     bool ok = true, repeat = false;
+#ifdef EXP_PHASE_CLOCKS
+    const long long ph_j0 = __builtin_readcyclecounter();
+#endif
     const int first_layer = jb.search_layer;
     for (int layer = first_layer; layer >= 0 && ok; --layer) {
         if (layer != first_layer) V.clear(lane); // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
@@ -1484,7 +1680,19 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
             ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
             if (!ok) break;
         }
-        const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact);
+#ifdef EXP_PHASE_CLOCKS
+        const long long ph_h0 = __builtin_readcyclecounter();
+#endif
+        // the candidate heap's LDS area is idle now: the grouped heuristic borrows it
+        const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact,
+#ifdef HNSW_NO_GROUPED
+                                                         nullptr, 0);
+#else
+                                                         reinterpret_cast<float *>(L.cand), sizeof(ND) * (size_t)cand_cap);
+#endif
+#ifdef EXP_PHASE_CLOCKS
+        if (lane == 0) atomicAdd(&g_phase[8], (unsigned long long)(__builtin_readcyclecounter() - ph_h0)); // heuristic cycles
+#endif
         int *osel = layer == 0 ? out_sel0 + (size_t)job * sel_stride : out_selU + (size_t)(jb.aux + layer - 1) * sel_stride;
         for (int i = lane; i < rc; i += 64) osel[i] = L.acc[i];
         if (lane == 0) { if (layer == 0) out_cnt0[job] = rc; else out_cntU[jb.aux + layer - 1] = rc; }
@@ -1497,6 +1705,9 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     if (lane == 0) {
         out_flag[job] = ok ? (repeat ? 2 : 0) : 1; // 2: informational (a layer was answered by the exact traversal)
         atomicAdd(eval_counter, evals);
+#ifdef EXP_PHASE_CLOCKS
+        atomicAdd(&g_phase[9], (unsigned long long)(__builtin_readcyclecounter() - ph_j0)); // whole insert job
+#endif
     }
 }
 
@@ -1508,7 +1719,8 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, unsigned *__restrict__ visited, long long vis_words,
                            int *__restrict__ vis_tab, int vis_tab_cap, int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
-                           unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap)
+                           unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap,
+                           const int *__restrict__ order)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -1520,6 +1732,10 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         if (lane == 0) job = atomicAdd(job_counter, 1);
         job = __builtin_amdgcn_readfirstlane(job);
         if (job >= njobs) break;
+        // queue position -> batch item: the items that search several layers are taken first (they run the
+        // longest; started last they would be the tail of the launch).  Results are filed by item, so the
+        // order of processing changes nothing else.
+        if (order) job = __builtin_amdgcn_readfirstlane(order[job]);
         insert_job<METRIC, NS, HASHED>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
                                out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap != 0);
         V.clear(lane);
@@ -1926,7 +2142,7 @@ __global__ void sqrt_rn_kernel(const double *in, double *out, int n)
         const float *__restrict__, const double *__restrict__, int, const int *__restrict__, int, const int64_t *__restrict__,   \
         const int *__restrict__, int, const SearchJob *__restrict__, int, int, ND *__restrict__, int, int, unsigned *__restrict__, \
         long long, int *__restrict__, int, int *__restrict__, int *__restrict__, int *__restrict__, int *__restrict__, int,      \
-        int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int);
+        int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int, const int *__restrict__);
 #define HNSW_DECLARE_TRAVERSAL(M, NS, H) HNSW_SEARCH_SIGNATURE(extern, M, NS, H) HNSW_INSERT_SIGNATURE(extern, M, NS, H)
 #define HNSW_DEFINE_TRAVERSAL(M, NS, H) HNSW_SEARCH_SIGNATURE(, M, NS, H) HNSW_INSERT_SIGNATURE(, M, NS, H)
 #define HNSW_DEFINE_SEARCH(M, NS, H) HNSW_SEARCH_SIGNATURE(, M, NS, H)

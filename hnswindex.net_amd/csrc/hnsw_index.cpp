@@ -579,7 +579,14 @@ void parallel_for(int n, int threads, F fn)
     for (auto &t : th) t.join();
 }
 
-constexpr int kBatchGrowthDiv = 16; // a snapshot batch never exceeds 1/16 of the linked graph (C2 build: 1/32 4.6 s, 1/16 3.8 s, 1/8 3.6 s; recall@10 unchanged within noise)
+// Growth rule of the snapshot schedule: a batch never exceeds 1/4 of the linked graph while that is below
+// 65 536 nodes, 1/16 of it afterwards.  Measured on 1M x 128 (tools/ramp_study.py, three data seeds, 4 000
+// queries each; profiles/r2_ramp_study.json): against 1/16 throughout, the build takes 1.24 s instead of
+// 1.44 s (the first 65 k inserts were 133 latency-bound batches, now 50) at unchanged recall@10 -- uniform
+// 0.2343 / 0.2377 / 0.2354 vs 0.2321 / 0.2381 / 0.2362, clustered 0.9872 / 0.9840 / 0.9876 vs 0.9876 / 0.9827 /
+// 0.9875.  Growing the LATE batches the same way (1/4 throughout: 1.20 s) did cost recall on clustered data
+// (0.9843 vs 0.9907; 1/16 early + 1/4 late: 0.9817), so the large batches keep the 1/16 rule.
+constexpr int kBatchGrowthDiv = 16, kEarlyGrowthDiv = 4, kEarlyLinked = 65536;
 
 // Optional phase timing (HNSW_MI355X_TRACE=1): printed when the index is destroyed.
 struct PhaseTimers {
@@ -654,9 +661,7 @@ bool HnswIndex::ensure_dim(int dim, std::string &err)
         dev_.reset(d);
         dev_->set_profiling(profiling_);
         dim_ = dim;
-        engine_stride_ = ((2 * p_.max_edges + 1) + 7) & ~7;
-        engine_.reset(new LockStepEngine(dev_.get(), std::max(2, p_.search_slots), engine_stride_, threads_));
-        if (!engine_->ok()) { err = get_dev_error(); return false; }
+        engine_stride_ = ((2 * p_.max_edges + 1) + 7) & ~7; // the lock-step engine itself is created on first use (engine())
         graph_.reserve((int)std::min<long long>(capacity_, 1 << 26));
         return true;
     }
@@ -665,6 +670,14 @@ bool HnswIndex::ensure_dim(int dim, std::string &err)
         return false;
     }
     return true;
+}
+
+// The lock-step engine (pinned step buffers, worker threads) is only needed by the host traversal,
+// RangeQuery, removal and the rare hand-backs of the device kernels: created when first used.
+LockStepEngine *HnswIndex::engine()
+{
+    if (!engine_) engine_.reset(new LockStepEngine(dev_.get(), std::max(2, p_.search_slots), engine_stride_, threads_));
+    return engine_.get();
 }
 
 bool HnswIndex::ensure_capacity(long long need, std::string &err)
@@ -693,7 +706,7 @@ bool HnswIndex::search_half_lockstep(const std::vector<int> &bid, const std::vec
         j.level = graph_.level[(size_t)j.id];
         j.efc = p_.max_candidates;
     }
-    if (!engine_->run(src, (long long)items.size())) { err = get_dev_error(); return false; }
+    if (!engine()->run(src, (long long)items.size())) { err = get_dev_error(); return false; }
     if (sel.own.empty()) sel.own.resize((size_t)sel.n);
     for (size_t t = 0; t < items.size(); ++t) {
         sel.own[(size_t)items[t]] = std::move(src.jobs[t].selected);
@@ -782,7 +795,7 @@ bool HnswIndex::link_half_lockstep(const std::vector<int> &bid, const Selection 
         lj.layer = groups[t].layer;
         lj.items = std::move(groups[t].items);
     }
-    if (!links.jobs.empty() && !engine_->run(links, (long long)links.jobs.size())) { err = get_dev_error(); return false; }
+    if (!links.jobs.empty() && !engine()->run(links, (long long)links.jobs.size())) { err = get_dev_error(); return false; }
     return true;
 }
 
@@ -809,6 +822,7 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
         if (!dev_->link_batch_planned(n, sel.n_upper, M2)) { err = get_dev_error(); return false; }
         return true;
     }
+    if (!dev_->fetch_insert_selections(&sel.dev)) { err = get_dev_error(); return false; } // the host groups: it needs the ids
     // Host-grouped path: the batch is linked in up to four sub-batches of consecutive items.  Appending the items of one
     // adjacency list sub-batch after sub-batch is the same sequence as appending them all in item
     // order, so the outcome is unchanged -- but while the GPU links one sub-batch the host groups
@@ -937,7 +951,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
     fresh.reserve((size_t)count);
     bool any_reused = false;
     const int first_new = graph_.length;
-    graph_.reserve(graph_.length + count);
+    graph_.grow_for(live - std::min(live, reusable)); // one resize of the per-node arrays, not one per node
     for (int i = 0; i < count; ++i) {
         if (lvls[(size_t)i] < 0) { ids[(size_t)i] = -1; ++skipped_; continue; } // :82
         ids[(size_t)i] = graph_.add_node(lvls[(size_t)i], p_.allow_removals, &any_reused);
@@ -946,8 +960,17 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
     if (g_pt.on) { g_pt.add_nodes += now_s() - t_nodes0; t_nodes0 = now_s(); }
     if (any_reused) graph_dirty_ = true; // existing rows of the HBM mirror changed: full re-upload
     // rows -> HBM (id == row index)
+    // A large Add starts linking as soon as its first rows are resident: the rest is uploaded by a helper
+    // thread on its own stream while the first (small, latency-bound) batches run, and every batch waits
+    // only for the rows it touches.
+    constexpr int kUploadAhead = 65536;
+    bool background = false;
     if (!any_reused && (int)fresh.size() == count) {
-        if (!dev_->upload_rows(first_new, count, vectors)) return fail(get_dev_error(), err);
+        if (count >= 4 * kUploadAhead && metric_ != HNSWDEV_SQ_EUCLID_I8) {
+            if (!dev_->upload_rows(first_new, kUploadAhead, vectors)) return fail(get_dev_error(), err);
+            if (!dev_->upload_rows_begin(first_new + kUploadAhead, count - kUploadAhead, vectors + (size_t)kUploadAhead * dim)) return fail(get_dev_error(), err);
+            background = true;
+        } else if (!dev_->upload_rows(first_new, count, vectors)) return fail(get_dev_error(), err);
     } else {
         for (int i = 0; i < count; ++i)
             if (ids[(size_t)i] >= 0 && !dev_->upload_rows(ids[(size_t)i], 1, vectors + (size_t)i * dim)) return fail(get_dev_error(), err);
@@ -964,17 +987,25 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
         bid.clear();
         bid.push_back(fresh[(size_t)p]);
         if (graph_.level[(size_t)fresh[(size_t)p]] > top) { // new entry point: alone, under the "entry point lock" (:36-41)
-            if (!insert_batch(bid, err)) return fail(err, err);
+            if (background && !dev_->upload_rows_wait((long long)bid.back() + 1)) return fail(get_dev_error(), err);
+            if (!insert_batch(bid, err)) { if (background) (void)dev_->upload_rows_wait(-1); return fail(err, err); }
             graph_.entry = fresh[(size_t)p++];
             continue;
         }
         const int linked = graph_.count - (m - p); // nodes already linked (== the id when nothing was ever removed)
-        const int b = std::min(bmax, std::max(1, linked / kBatchGrowthDiv));
+        static const int growth_div = [] { const char *e = std::getenv("HNSW_MI355X_BATCH_DIV"); return e ? std::max(1, std::atoi(e)) : kBatchGrowthDiv; }(); // experiments only
+        static const int growth_div_late = [] { const char *e = std::getenv("HNSW_MI355X_BATCH_DIV_LATE"); return e ? std::max(1, std::atoi(e)) : 0; }();
+        static const bool div_from_env = std::getenv("HNSW_MI355X_BATCH_DIV") != nullptr;
+        const int div_now = div_from_env ? (growth_div_late > 0 && linked >= kEarlyLinked ? growth_div_late : growth_div)
+                                         : (linked < kEarlyLinked ? kEarlyGrowthDiv : kBatchGrowthDiv);
+        const int b = std::min(bmax, std::max(1, linked / div_now));
         while ((int)bid.size() < b && p + (int)bid.size() < m && graph_.level[(size_t)fresh[(size_t)(p + (int)bid.size())]] <= top)
             bid.push_back(fresh[(size_t)(p + (int)bid.size())]);
-        if (!insert_batch(bid, err)) return fail(err, err);
+        if (background && !dev_->upload_rows_wait((long long)bid.back() + 1)) return fail(get_dev_error(), err); // ids ascend within an Add
+        if (!insert_batch(bid, err)) { if (background) (void)dev_->upload_rows_wait(-1); return fail(err, err); }
         p += (int)bid.size();
     }
+    if (background && !dev_->upload_rows_wait(-1)) return fail(get_dev_error(), err); // `vectors` is borrowed only for this call
     if (out_ids) for (int i = 0; i < count; ++i) out_ids[i] = ids[(size_t)i];
     return count;
 }
@@ -1020,7 +1051,7 @@ int HnswIndex::knn_query_lockstep(const int *which, int count, int k, int *out_i
         j.out_ids = out_ids + (size_t)qi * k;
         j.out_d = out_dists + (size_t)qi * k;
     }
-    if (!engine_->run(src, count)) { err = get_dev_error(); return -1; }
+    if (!engine()->run(src, count)) { err = get_dev_error(); return -1; }
     return 0;
 }
 
@@ -1097,7 +1128,7 @@ int HnswIndex::range_query(const float *queries, int count, int dim, float range
         j.range = range;
         j.out = &out[(size_t)i];
     }
-    if (!engine_->run(src, count)) { err = get_dev_error(); return -1; }
+    if (!engine()->run(src, count)) { err = get_dev_error(); return -1; }
     return 0;
 }
 
@@ -1170,7 +1201,7 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
             ssrc.jobs.resize(1);
             RemoveSearchJob &sj = ssrc.jobs[0];
             sj.g = &g; sj.capacity = (int)capacity_; sj.removed = id; sj.layer = layer; sj.k = p_.remove_max_candidates;
-            if (!engine_->run(ssrc, 1)) { err = get_dev_error(); return -1; }
+            if (!engine()->run(ssrc, 1)) { err = get_dev_error(); return -1; }
             if (!affected.empty()) {
                 VecSource<AffectedJob> asrc;
                 asrc.jobs.resize(affected.size());
@@ -1178,7 +1209,7 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
                     AffectedJob &aj = asrc.jobs[a];
                     aj.g = &g; aj.aid = affected[a]; aj.layer = layer; aj.removed = id; aj.sc_cands = &sj.result;
                 }
-                if (!engine_->run(asrc, (long long)affected.size())) { err = get_dev_error(); return -1; }
+                if (!engine()->run(asrc, (long long)affected.size())) { err = get_dev_error(); return -1; }
                 for (AffectedJob &aj : asrc.jobs) {
                     for (int o : aj.in_remove) erase_from(in_of(o, layer), aj.aid);
                     for (int w : aj.in_add) in_of(w, layer).push_back(aj.aid);

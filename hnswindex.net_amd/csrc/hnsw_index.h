@@ -124,6 +124,7 @@ private:
     DotnetRandom rng_;
     std::unique_ptr<Device> dev_;
     std::unique_ptr<LockStepEngine> engine_;
+    LockStepEngine *engine();
     int engine_stride_ = 0;
     long long capacity_ = 0; // GraphData.Capacity (doubling, GraphData.cs:98-111)
     int skipped_ = 0;

@@ -309,6 +309,20 @@ struct Graph {
         dense.reserve((size_t)capacity);
         sparse.reserve((size_t)capacity);
     }
+    // Room for n more fresh slots in every per-node array, in one step (slots [length, slots) exist, zeroed, unused).
+    size_t slots = 0;
+    void grow_for(int n)
+    {
+        const size_t want = (size_t)length + (size_t)std::max(n, 0);
+        if (want <= slots) return;
+        level.resize(want, 0);
+        adj0.resize(want * (size_t)stride0, 0);
+        upper.resize(want, -1);
+        removed.resize(want, 0);
+        sparse.resize(want, 0);
+        dense.resize(want, 0);
+        slots = want;
+    }
     // GraphData.AddItem :85-115 + NewNode :224-242.  reuse: pop the most recently vacated slot.
     int add_node(int top_layer, bool reuse, bool *reused = nullptr)
     {
@@ -321,13 +335,9 @@ struct Graph {
             removed[(size_t)id] = 0;
             if (reused) *reused = true;
         } else {
+            if ((size_t)length >= slots) grow_for(std::max(1024, length / 2));
             id = length++;
-            level.push_back(top_layer);
-            adj0.resize((size_t)length * stride0, 0);
-            upper.push_back(-1);
-            removed.push_back(0);
-            sparse.push_back(0);
-            dense.push_back(0);
+            level[(size_t)id] = top_layer;
         }
         if (top_layer > 0) {
             upper[(size_t)id] = (int64_t)pool.size();

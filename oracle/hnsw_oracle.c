@@ -923,7 +923,8 @@ static int add_one(sctx_t *c, const float *v)
  *       (GraphConnector.cs:174-179, :189-190; next entry = selected[0], :216)
  *   link half, items in id order: OutEdges = selected (:192), back-edges and
  *       PruneOverflow (:196-214).
- * A batch is at most max(1, linked/16) items (capped by max_batch); an item whose level
+ * A batch is at most max(1, linked/4) items while fewer than 65 536 nodes are linked, max(1, linked/16)
+ * afterwards (capped by max_batch); an item whose level
  * exceeds the current top layer is inserted alone (the reference holds the entry-point lock
  * for it, GraphConnector.cs:27-41).  max_batch == 1 is exactly orc_add.
  * ---------------------------------------------------------------------------------- */
@@ -991,7 +992,7 @@ ORC_API int orc_add_batched(void *h, const float *v, int n, int *out_ids, int ma
             new_ep = 1;
         } else {
             int linked = ix->count - (m - p); /* nodes already linked (== the id when nothing was ever removed) */
-            int b = linked / 16;
+            int b = linked / (linked < 65536 ? 4 : 16); /* the product's growth rule (hnsw_index.cpp) */
             if (b < 1) b = 1;
             if (b > max_batch) b = max_batch;
             while (nb < b && p + nb < m && ix->nodes[ids[p + nb]].max_layer <= top) nb++;
@@ -1086,7 +1087,7 @@ ORC_API int orc_add_batched_mt(void *h, const float *v, int n, int *out_ids, int
             new_ep = 1;
         } else {
             int linked = ix->count - (m - p);
-            int b = linked / 16;
+            int b = linked / (linked < 65536 ? 4 : 16); /* the product's growth rule (hnsw_index.cpp) */
             if (b < 1) b = 1;
             if (b > max_batch) b = max_batch;
             while (nb < b && p + nb < m && ix->nodes[ids[p + nb]].max_layer <= top) nb++;
