@@ -661,6 +661,14 @@ static int overlap_mode()
     return e ? std::atoi(e) : 1;
 }
 
+// The MFMA Gram-block prefilter of RelativeNeighborPruning (device_kernels.h): on by default where it applies
+// (cosine family, dim % 8 == 0); HNSW_MI355X_MFMA=0 keeps the exact-only forms (the tests run both).
+static bool mfma_heuristic()
+{
+    const char *e = std::getenv("HNSW_MI355X_MFMA");
+    return !e || std::atoi(e) != 0;
+}
+
 // The per-wave visited-id hash tables (VisitedSet): capacity a power of two, >= 16384 and >= 64 per
 // beam entry (a traversal visits roughly 35 ids per beam entry), all entries -1 between jobs.
 // HNSW_MI355X_VIS_HASH=1/0 forces / forbids them; HNSW_MI355X_VIS_HASH_CAP overrides the capacity (tests).
@@ -809,7 +817,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
                        dim3(64), LDS, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
-                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0, d_order); \
+                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && GRID <= slots_)) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order); \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
     do {                                                                                                                   \

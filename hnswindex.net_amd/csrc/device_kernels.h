@@ -1309,6 +1309,56 @@ __device__ inline void dev_dotnet_sort(ND *arr, int n, int *stk)
     }
 }
 
+// ---- MFMA Gram block: the dense contraction inside RelativeNeighborPruning ----------------------
+// Heuristic.cs:23-40 tests every candidate c against every id s accepted so far: dist(s, c) < c.Dist.  Over
+// a block of candidates that is a dense C x C (and accepted x C) block of pair distances -- dot products of
+// stored rows -- the one place on this path where a matrix core applies.  v_mfma_f32_32x32x2_f32 (f32 in,
+// f32 accumulate; exact products, the sum in the unit's own order) gives a 32 x 32 tile of dots per pass over
+// the rows; it CANNOT reproduce the lane-ordered sums bit for bit, so it never stands in for a distance: it
+// only PREFILTERS the comparison.  |mfma - lane-ordered| <= 2 K u sum|a_k b_k| (u = 2^-24, K = dim) for any
+// order of summation; with E = 16 K u (eight times that bound for unit-length rows; cosine divides by the
+// norms first) a pair whose approximate distance is further than E from the threshold has the same outcome
+// as the exact test, and a pair within E is evaluated again with the exact kernels (measure_all).  Ids are
+// therefore decided by exact fp32 distances or by a margin no rounding can cross; the graph hashes of the
+// parity tests (oracle: scalar CPU code) hold this at every size.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+// D[i][j] = dot(row idA of lane (i = lane % 32 as A operand), row idB (j = lane % 32 as B operand)); result layout,
+// measured (tools/mfma_probe.hip): lane l, register v hold j = l % 32, i = 8 (v / 4) + 4 (l / 32) + v % 4.
+// Lane (r, h) streams floats [8 t + 4 h, 8 t + 4 h + 4) of its row: which k meets which MFMA step is free as long as
+// both operands agree.  dim % 8 == 0.
+__device__ __forceinline__ floatx16 gram_tile(const float *__restrict__ rows, int dim, int idA, int idB, int lane)
+{
+    const int h = lane >> 5;
+    const float4 *pa = reinterpret_cast<const float4 *>(rows + (size_t)idA * dim) + h;
+    const float4 *pb = reinterpret_cast<const float4 *>(rows + (size_t)idB * dim) + h;
+    floatx16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    const int nt = dim >> 3;
+    constexpr int U = 8;
+    int t = 0;
+    for (; t + U <= nt; t += U) {
+        float4 a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[u] = pa[2 * (t + u)]; b[u] = pb[2 * (t + u)]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+        }
+    }
+    for (; t < nt; ++t) {
+        const float4 a = pa[2 * t], b = pb[2 * t];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 __device__ __forceinline__ int nbcap_of(int max_edges) { return (max_edges + 1 + 7) & ~7; } // row stride of the grouped heuristic's distance table
 // Heuristic.RelativeNeighborPruning (Heuristic.cs:11-46) on cands[0..n) (LDS): writes the
 // selected ids to L.acc, returns their count.  The candidate under test is staged in L.qs2
@@ -1318,7 +1368,7 @@ template <int METRIC>
 __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                                                          ND *cands, int n, int max_edges, const SearchLds &L, int lane,
                                                          unsigned long long &evals, bool presorted = false,
-                                                         float *gscratch = nullptr, size_t gscratch_bytes = 0)
+                                                         float *gscratch = nullptr, size_t gscratch_bytes = 0, bool mfma_ok = false)
 {
     int *acc = L.acc;
     __syncthreads();
@@ -1355,6 +1405,100 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
     const bool prefetch = dim <= 64 * kPre;
     const int dimp = (dim + 3) & ~3;
     constexpr int kPreG = 4; // the grouped form prefetches four rows at once: rows up to 256 floats
+    if constexpr (METRIC == M_UCOS || METRIC == M_COS) {
+        // MFMA-prefiltered form (cosine family, rows of a multiple of 8 floats): candidates in blocks of 32.
+        // Per block: one tile per 32 accepted ids (accepted x block) and one block x block tile give the
+        // approximate distance of every pair the greedy pass can ask for; the pass then walks the 32 in order
+        // on those numbers, and only a pair within E of its threshold is measured exactly.
+        const size_t need_sn = METRIC == M_COS ? 8u * (size_t)nbcap_of(max_edges) : 0u;
+        if ((dim & 7) == 0 && dim >= 64 && mfma_ok && (METRIC != M_COS || (gscratch && gscratch_bytes >= need_sn))) {
+            const float E = fmaxf(1e-4f, 16.0f * (float)dim * 5.9604645e-8f);
+            double *snacc = reinterpret_cast<double *>(gscratch); // cosine: sqrt-norms of the accepted rows, by position
+            const int r = lane & 31, h = lane >> 5;
+            float *qbuf = L.qs2;
+            for (int b0 = 0; b0 < n && rc < max_edges; b0 += 32) { // :23, thirty-two at a time
+                const int bsz = min(32, n - b0);
+                const ND mine = cands[b0 + (r < bsz ? r : 0)]; // column j = r of this block
+                const float thr = mine.dist;
+                double sn_j = 0.0;
+                if (METRIC == M_COS) sn_j = row_sn[mine.id];
+                const int rc0 = rc;
+                bool def_r = false, unc_r = false; // column j against the ids accepted before the block
+                for (int a0 = 0; a0 < rc0; a0 += 32) {
+                    const int na = min(32, rc0 - a0);
+                    const floatx16 D = gram_tile(rows, dim, acc[a0 + (r < na ? r : 0)], mine.id, lane);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+                        float d;
+                        if (METRIC == M_UCOS) d = 1.0f - D[v];
+                        else {
+                            const float denom = (float)(snacc[a0 + (i < na ? i : 0)] * sn_j);
+                            d = denom < 1e-30f ? 1.0f : 1.0f - D[v] / denom;
+                        }
+                        const bool valid = i < na && r < bsz;
+                        def_r = def_r || (valid && d < thr - E);
+                        unc_r = unc_r || (valid && !(d < thr - E) && !(d > thr + E)); // also catches NaN
+                    }
+                }
+                const floatx16 S = gram_tile(rows, dim, mine.id, mine.id, lane); // block x block
+                float sd[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    if (METRIC == M_UCOS) sd[v] = 1.0f - S[v];
+                    else {
+                        const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+                        const double sn_i = __shfl(sn_j, i, 64); // row i of the block = column i's own norm
+                        const float denom = (float)(sn_i * sn_j);
+                        sd[v] = denom < 1e-30f ? 1.0f : 1.0f - S[v] / denom;
+                    }
+                }
+                unsigned in_block = 0u; // bit u: member u of the block accepted (uniform)
+                for (int j = 0; j < bsz && rc < max_edges; ++j) {
+                    bool def = r == j && def_r, unc = r == j && unc_r;
+                    if (r == j) {
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) {
+                            const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+                            const bool live = ((in_block >> i) & 1u) != 0u; // accepted members all precede j
+                            def = def || (live && sd[v] < thr - E);
+                            unc = unc || (live && !(sd[v] < thr - E) && !(sd[v] > thr + E));
+                        }
+                    }
+                    const bool any_def = __ballot(def) != 0ull, any_unc = __ballot(unc) != 0ull;
+                    const ND c = cands[b0 + j];
+                    bool rejected = any_def;
+                    if (!any_def && any_unc) { // too close to call: the exact test (Heuristic.cs:31-35) on the exact kernels
+                        const float *crow = rows + (size_t)c.id * dim;
+                        __syncthreads();
+                        for (int e = lane; e < dim; e += 64) qbuf[e] = crow[e];
+                        double sbc = 0.0;
+                        if (METRIC == M_COS) sbc = row_sn[c.id];
+                        __syncthreads();
+                        bool ok = true;
+                        for (int a0 = 0; a0 < rc && ok; a0 += 32) {
+                            const int an = min(32, rc - a0);
+                            measure_all<METRIC>(rows, row_sn, dim, qbuf, sbc, acc + a0, L.dbuf, an, lane);
+                            __syncthreads();
+                            evals += (unsigned long long)an;
+                            const float dj = lane < an ? L.dbuf[lane] : 0.0f;
+                            ok = __ballot(lane < an && dj < c.dist) == 0ull;
+                            __syncthreads();
+                        }
+                        rejected = !ok;
+                    }
+                    if (!rejected) {
+                        if (lane == 0) { acc[rc] = c.id; if (METRIC == M_COS) snacc[rc] = row_sn[c.id]; }
+                        rc++;
+                        in_block |= 1u << j;
+                    }
+                }
+                evals += (unsigned long long)(rc0 + bsz); // rows streamed by the tiles of this block (each once per tile)
+                __syncthreads(); // acc / snacc written by lane 0 are read by the next block's tiles
+            }
+            return rc;
+        }
+    }
     if constexpr (METRIC != M_I8) {
         // Grouped form (rows up to 256 floats, when the caller lends scratch): FOUR candidates are tested per
         // step.  Their rows sit in LDS; every accepted row is fetched once and measured against all four
@@ -1639,10 +1783,11 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, VisitedSet<HASHED> &V,
                            int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
-                           unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, bool overlap)
+                           unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap_and_flags)
 {
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
+    const bool overlap = (overlap_and_flags & 1) != 0; // bit 1: the MFMA-prefiltered heuristic is allowed
     SearchJob jb = jobs[job];
     const GraphView G{adj0, stride0, upper, pool, strideU};
     const int item = ~jb.qref;
@@ -1688,7 +1833,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
 #ifdef HNSW_NO_GROUPED
                                                          nullptr, 0);
 #else
-                                                         reinterpret_cast<float *>(L.cand), sizeof(ND) * (size_t)cand_cap);
+                                                         reinterpret_cast<float *>(L.cand), sizeof(ND) * (size_t)cand_cap, (overlap_and_flags & 2) != 0);
 #endif
 #ifdef EXP_PHASE_CLOCKS
         if (lane == 0) atomicAdd(&g_phase[8], (unsigned long long)(__builtin_readcyclecounter() - ph_h0)); // heuristic cycles
@@ -1737,7 +1882,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         // order of processing changes nothing else.
         if (order) job = __builtin_amdgcn_readfirstlane(order[job]);
         insert_job<METRIC, NS, HASHED>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
-                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap != 0);
+                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap);
         V.clear(lane);
     }
 }

@@ -93,8 +93,8 @@ int hnsw_set_allow_removals(bool allow_removals);        /* :268 */
  * HNSW_MI355X_DEVICE environment variable, else 0). */
 int hnsw_mi355x_set_device(int device);
 /* Pending: cap on the snapshot batch of hnsw_add (1 = strictly sequential inserts;
- * default 65536; a batch also never exceeds 1/4 of the linked graph below 65 536 linked nodes, 1/16 of
- * it above).  See DESIGN.md "Add". */
+ * default 65536; a batch also never exceeds 1/16 of the linked graph -- 1/4 of it during the first
+ * min(65 536, final count / 16) inserts).  See DESIGN.md "Add". */
 int hnsw_mi355x_set_insert_batch(int max_batch);
 /* Pending: number of concurrent search slots of the lock-step driver (default 16384) and
  * host worker threads (default: min(hardware threads, 16)). */

@@ -583,6 +583,8 @@ typedef struct {
     int *dense, *sparse, *removed_stack;
     int n_removed_stack;
     visited_t vis;          /* used by the single-threaded paths */
+    visited_t *vis_pool;    /* per-thread lists of the threaded batched Add, kept across calls */
+    int n_vis_pool;
     uint64_t n_eval;        /* distance evaluations (SURVEY 8d N_eval) */
 } index_t;
 
@@ -923,8 +925,8 @@ static int add_one(sctx_t *c, const float *v)
  *       (GraphConnector.cs:174-179, :189-190; next entry = selected[0], :216)
  *   link half, items in id order: OutEdges = selected (:192), back-edges and
  *       PruneOverflow (:196-214).
- * A batch is at most max(1, linked/4) items while fewer than 65 536 nodes are linked, max(1, linked/16)
- * afterwards (capped by max_batch); an item whose level
+ * A batch is at most max(1, linked/4) items while fewer than min(65 536, count after the call / 16) nodes
+ * are linked, max(1, linked/16) afterwards (capped by max_batch); an item whose level
  * exceeds the current top layer is inserted alone (the reference holds the entry-point lock
  * for it, GraphConnector.cs:27-41).  max_batch == 1 is exactly orc_add.
  * ---------------------------------------------------------------------------------- */
@@ -992,7 +994,8 @@ ORC_API int orc_add_batched(void *h, const float *v, int n, int *out_ids, int ma
             new_ep = 1;
         } else {
             int linked = ix->count - (m - p); /* nodes already linked (== the id when nothing was ever removed) */
-            int b = linked / (linked < 65536 ? 4 : 16); /* the product's growth rule (hnsw_index.cpp) */
+            int early = ix->count / 16 < 65536 ? ix->count / 16 : 65536; /* the product's growth rule (hnsw_index.cpp) */
+            int b = linked / (linked < early ? 4 : 16);
             if (b < 1) b = 1;
             if (b > max_batch) b = max_batch;
             while (nb < b && p + nb < m && ix->nodes[ids[p + nb]].max_layer <= top) nb++;
@@ -1076,8 +1079,12 @@ ORC_API int orc_add_batched_mt(void *h, const float *v, int n, int *out_ids, int
         if (id >= 0) ids[m++] = id;
     }
     free(tmp);
-    visited_t *vis = (visited_t *)malloc(sizeof(visited_t) * (size_t)threads);
-    for (int t = 0; t < threads; t++) visited_init(&vis[t], ix->capacity);
+    if (ix->n_vis_pool < threads) { /* allocated once: a 16-item call must not pay for 16 fresh lists of `capacity` entries */
+        ix->vis_pool = (visited_t *)realloc(ix->vis_pool, sizeof(visited_t) * (size_t)threads);
+        for (int t = ix->n_vis_pool; t < threads; t++) visited_init(&ix->vis_pool[t], ix->capacity);
+        ix->n_vis_pool = threads;
+    }
+    visited_t *vis = ix->vis_pool;
     int p = 0;
     while (p < m) {
         if (ix->entry < 0) { ix->entry = ids[p++]; continue; }
@@ -1087,7 +1094,8 @@ ORC_API int orc_add_batched_mt(void *h, const float *v, int n, int *out_ids, int
             new_ep = 1;
         } else {
             int linked = ix->count - (m - p);
-            int b = linked / (linked < 65536 ? 4 : 16); /* the product's growth rule (hnsw_index.cpp) */
+            int early = ix->count / 16 < 65536 ? ix->count / 16 : 65536; /* the product's growth rule (hnsw_index.cpp) */
+            int b = linked / (linked < early ? 4 : 16);
             if (b < 1) b = 1;
             if (b > max_batch) b = max_batch;
             while (nb < b && p + nb < m && ix->nodes[ids[p + nb]].max_layer <= top) nb++;
@@ -1133,8 +1141,6 @@ ORC_API int orc_add_batched_mt(void *h, const float *v, int n, int *out_ids, int
         if (new_ep) ix->entry = ids[p];
         p += nb;
     }
-    for (int t = 0; t < threads; t++) visited_free(&vis[t]);
-    free(vis);
     free(ids);
     ix->n_eval += c.n_eval;
     return n;
@@ -1309,6 +1315,8 @@ ORC_API void orc_free(void *h)
     free(ix->dense); free(ix->sparse); free(ix->removed_stack);
     free(ix->items);
     visited_free(&ix->vis);
+    for (int t = 0; t < ix->n_vis_pool; t++) visited_free(&ix->vis_pool[t]);
+    free(ix->vis_pool);
     free(ix);
 }
 
