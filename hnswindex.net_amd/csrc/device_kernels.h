@@ -1313,14 +1313,18 @@ __device__ inline void dev_dotnet_sort(ND *arr, int n, int *stk)
 // Heuristic.cs:23-40 tests every candidate c against every id s accepted so far: dist(s, c) < c.Dist.  Over
 // a block of candidates that is a dense C x C (and accepted x C) block of pair distances -- dot products of
 // stored rows -- the one place on this path where a matrix core applies.  v_mfma_f32_32x32x2_f32 (f32 in,
-// f32 accumulate; exact products, the sum in the unit's own order) gives a 32 x 32 tile of dots per pass over
-// the rows; it CANNOT reproduce the lane-ordered sums bit for bit, so it never stands in for a distance: it
-// only PREFILTERS the comparison.  |mfma - lane-ordered| <= 2 K u sum|a_k b_k| (u = 2^-24, K = dim) for any
-// order of summation; with E = 16 K u (eight times that bound for unit-length rows; cosine divides by the
-// norms first) a pair whose approximate distance is further than E from the threshold has the same outcome
-// as the exact test, and a pair within E is evaluated again with the exact kernels (measure_all).  Ids are
-// therefore decided by exact fp32 distances or by a margin no rounding can cross; the graph hashes of the
-// parity tests (oracle: scalar CPU code) hold this at every size.
+// f32 accumulate: a chain of K fused multiply-adds per output element) gives a 32 x 32 tile of dots per pass
+// over the rows; it CANNOT reproduce the lane-ordered sums bit for bit, so it never stands in for a distance:
+// it only PREFILTERS the comparison.  Both sums round at most once per step, each step by at most
+// u |partial sum| <= u S with S = sum |a_k b_k| <= |a| |b| (u = 2^-24): the MFMA chain has K steps, the lane
+// order K/8 adds per lane plus a product rounding per term (u S in total) plus a three-level tree, so
+// |mfma - lane-ordered| <= (K + K/8 + 5) u S.  With E = (1.125 K + 32) u -- for rows of length <= 1 (ucosine;
+// checked per block on the Gram diagonal, a longer row sends its block to the exact path) or after the
+// division by the norms (cosine) -- a pair whose approximate distance is further than E from the threshold
+// has the same outcome as the exact test, and a pair within E is evaluated again with the exact kernels
+// (measure_all).  Measured (tools/mfma_probe.hip, K = 768): the two sums differ by 9.5e-7 at most; E = 5.3e-5.
+// Ids are therefore decided by exact fp32 distances or by a margin no rounding can cross; the graph hashes of
+// the parity tests (oracle: scalar CPU code) hold this at every size.
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 // D[i][j] = dot(row idA of lane (i = lane % 32 as A operand), row idB (j = lane % 32 as B operand)); result layout,
 // measured (tools/mfma_probe.hip): lane l, register v hold j = l % 32, i = 8 (v / 4) + 4 (l / 32) + v % 4.
@@ -1364,7 +1368,7 @@ __device__ __forceinline__ int nbcap_of(int max_edges) { return (max_edges + 1 +
 // selected ids to L.acc, returns their count.  The candidate under test is staged in L.qs2
 // and measured against ALL accepted rows at once (the reference's early break only skips
 // evaluations).
-template <int METRIC>
+template <int METRIC, bool MFMA = false>
 __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                                                          ND *cands, int n, int max_edges, const SearchLds &L, int lane,
                                                          unsigned long long &evals, bool presorted = false,
@@ -1405,17 +1409,46 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
     const bool prefetch = dim <= 64 * kPre;
     const int dimp = (dim + 3) & ~3;
     constexpr int kPreG = 4; // the grouped form prefetches four rows at once: rows up to 256 floats
-    if constexpr (METRIC == M_UCOS || METRIC == M_COS) {
-        // MFMA-prefiltered form (cosine family, rows of a multiple of 8 floats): candidates in blocks of 32.
+    if constexpr (MFMA && (METRIC == M_UCOS || METRIC == M_COS || METRIC == M_SQ)) {
+        // MFMA-prefiltered form (rows of a multiple of 8 floats, at least 256 of them: measured at C2's 128-float rows
+        // the tiles cost more than the grouped form below -- insert kernel 0.94 s against 0.83 s -- at C3's 768 they
+        // save 13 % of it; instantiated for the 8-register-set kernels only, i.e. beams above 256 candidates, which
+        // have the registers -- in the 168-VGPR variants the extra code spilled): candidates in blocks of 32.
         // Per block: one tile per 32 accepted ids (accepted x block) and one block x block tile give the
         // approximate distance of every pair the greedy pass can ask for; the pass then walks the 32 in order
         // on those numbers, and only a pair within E of its threshold is measured exactly.
-        const size_t need_sn = METRIC == M_COS ? 8u * (size_t)nbcap_of(max_edges) : 0u;
-        if ((dim & 7) == 0 && dim >= 64 && mfma_ok && (METRIC != M_COS || (gscratch && gscratch_bytes >= need_sn))) {
-            const float E = fmaxf(1e-4f, 16.0f * (float)dim * 5.9604645e-8f);
+        // sq_euclid: |a - b|^2 = na + nb - 2 dot with the three terms off the same tiles (na, nb: the Gram diagonal);
+        // each is a K-step chain, so |approx - lane-ordered| <= u (K (na + nb + 2 S) + (K/8 + 5) D) with S <= (na + nb) / 2
+        // and D = |a - b|^2 <= 2 (na + nb): E_pair = (2.25 K + 32) u (na + nb), norms taken 1 % up for their own error.
+        const size_t need_sn = METRIC == M_COS ? 8u * (size_t)nbcap_of(max_edges) : METRIC == M_SQ ? 4u * (size_t)nbcap_of(max_edges) : 0u;
+        if ((dim & 7) == 0 && dim >= 256 && mfma_ok && (METRIC == M_UCOS || (gscratch && gscratch_bytes >= need_sn))) {
+            const float E = (1.125f * (float)dim + 32.0f) * 5.9604645e-8f;
+            const float Esq = (2.25f * (float)dim + 32.0f) * 5.9604645e-8f * 1.01f;
             double *snacc = reinterpret_cast<double *>(gscratch); // cosine: sqrt-norms of the accepted rows, by position
+            float *nacc = reinterpret_cast<float *>(gscratch);    // sq_euclid: their squared norms (Gram diagonal)
             const int r = lane & 31, h = lane >> 5;
             float *qbuf = L.qs2;
+            // the exact test of one candidate against everything accepted so far (Heuristic.cs:31-35)
+            auto exact_rejects = [&](const ND c) -> bool {
+                const float *crow = rows + (size_t)c.id * dim;
+                __syncthreads();
+                for (int e = lane; e < dim; e += 64) qbuf[e] = crow[e];
+                double sbc = 0.0;
+                if (METRIC == M_COS) sbc = row_sn[c.id];
+                __syncthreads();
+                bool ok = true;
+                const int chunk = dim >= 512 ? 16 : 32;
+                for (int a0 = 0; a0 < rc && ok; a0 += chunk) {
+                    const int an = min(chunk, rc - a0);
+                    measure_all<METRIC>(rows, row_sn, dim, qbuf, sbc, acc + a0, L.dbuf, an, lane);
+                    __syncthreads();
+                    evals += (unsigned long long)an;
+                    const float dj = lane < an ? L.dbuf[lane] : 0.0f;
+                    ok = __ballot(lane < an && dj < c.dist) == 0ull;
+                    __syncthreads();
+                }
+                return !ok;
+            };
             for (int b0 = 0; b0 < n && rc < max_edges; b0 += 32) { // :23, thirty-two at a time
                 const int bsz = min(32, n - b0);
                 const ND mine = cands[b0 + (r < bsz ? r : 0)]; // column j = r of this block
@@ -1423,6 +1456,40 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                 double sn_j = 0.0;
                 if (METRIC == M_COS) sn_j = row_sn[mine.id];
                 const int rc0 = rc;
+                const floatx16 S = gram_tile(rows, dim, mine.id, mine.id, lane); // block x block
+                float sd[16], se[16]; // block x block: approximate distance and (sq_euclid) its error bound
+                bool long_row = false; // ucosine: the bound assumes |row| <= 1
+                float n_j = 0.0f;      // sq_euclid: |row j|^2 off the diagonal (one of the lanes r, r + 32 holds it)
+                if (METRIC == M_SQ) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) n_j += (8 * (v >> 2) + 4 * h + (v & 3)) == r ? S[v] : 0.0f;
+                    n_j += __shfl_xor(n_j, 32, 64);
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+                    se[v] = E;
+                    if (METRIC == M_UCOS) {
+                        sd[v] = 1.0f - S[v];
+                        long_row = long_row || (i == r && !(S[v] <= 1.0001f));
+                    } else if (METRIC == M_SQ) {
+                        const float n_i = __shfl(n_j, i, 64);
+                        sd[v] = (n_i + n_j) - 2.0f * S[v];
+                        se[v] = Esq * (n_i + n_j);
+                    } else {
+                        const double sn_i = __shfl(sn_j, i, 64); // row i of the block = column i's own norm
+                        const float denom = (float)(sn_i * sn_j);
+                        sd[v] = denom < 1e-30f ? 1.0f : 1.0f - S[v] / denom;
+                    }
+                }
+                if (__ballot(long_row) != 0ull) { // not unit rows: this block on the exact kernels alone
+                    for (int j = 0; j < bsz && rc < max_edges; ++j) {
+                        const ND c = cands[b0 + j];
+                        if (rc == 0 || !exact_rejects(c)) { if (lane == 0) acc[rc] = c.id; rc++; }
+                        __syncthreads();
+                    }
+                    continue;
+                }
                 bool def_r = false, unc_r = false; // column j against the ids accepted before the block
                 for (int a0 = 0; a0 < rc0; a0 += 32) {
                     const int na = min(32, rc0 - a0);
@@ -1430,27 +1497,19 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
                         const int i = 8 * (v >> 2) + 4 * h + (v & 3);
-                        float d;
+                        float d, e = E;
                         if (METRIC == M_UCOS) d = 1.0f - D[v];
-                        else {
+                        else if (METRIC == M_SQ) {
+                            const float n_i = nacc[a0 + (i < na ? i : 0)];
+                            d = (n_i + n_j) - 2.0f * D[v];
+                            e = Esq * (n_i + n_j);
+                        } else {
                             const float denom = (float)(snacc[a0 + (i < na ? i : 0)] * sn_j);
                             d = denom < 1e-30f ? 1.0f : 1.0f - D[v] / denom;
                         }
                         const bool valid = i < na && r < bsz;
-                        def_r = def_r || (valid && d < thr - E);
-                        unc_r = unc_r || (valid && !(d < thr - E) && !(d > thr + E)); // also catches NaN
-                    }
-                }
-                const floatx16 S = gram_tile(rows, dim, mine.id, mine.id, lane); // block x block
-                float sd[16];
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    if (METRIC == M_UCOS) sd[v] = 1.0f - S[v];
-                    else {
-                        const int i = 8 * (v >> 2) + 4 * h + (v & 3);
-                        const double sn_i = __shfl(sn_j, i, 64); // row i of the block = column i's own norm
-                        const float denom = (float)(sn_i * sn_j);
-                        sd[v] = denom < 1e-30f ? 1.0f : 1.0f - S[v] / denom;
+                        def_r = def_r || (valid && d < thr - e);
+                        unc_r = unc_r || (valid && !(d < thr - e) && !(d > thr + e)); // also catches NaN
                     }
                 }
                 unsigned in_block = 0u; // bit u: member u of the block accepted (uniform)
@@ -1461,34 +1520,17 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                         for (int v = 0; v < 16; ++v) {
                             const int i = 8 * (v >> 2) + 4 * h + (v & 3);
                             const bool live = ((in_block >> i) & 1u) != 0u; // accepted members all precede j
-                            def = def || (live && sd[v] < thr - E);
-                            unc = unc || (live && !(sd[v] < thr - E) && !(sd[v] > thr + E));
+                            def = def || (live && sd[v] < thr - se[v]);
+                            unc = unc || (live && !(sd[v] < thr - se[v]) && !(sd[v] > thr + se[v]));
                         }
                     }
                     const bool any_def = __ballot(def) != 0ull, any_unc = __ballot(unc) != 0ull;
                     const ND c = cands[b0 + j];
                     bool rejected = any_def;
-                    if (!any_def && any_unc) { // too close to call: the exact test (Heuristic.cs:31-35) on the exact kernels
-                        const float *crow = rows + (size_t)c.id * dim;
-                        __syncthreads();
-                        for (int e = lane; e < dim; e += 64) qbuf[e] = crow[e];
-                        double sbc = 0.0;
-                        if (METRIC == M_COS) sbc = row_sn[c.id];
-                        __syncthreads();
-                        bool ok = true;
-                        for (int a0 = 0; a0 < rc && ok; a0 += 32) {
-                            const int an = min(32, rc - a0);
-                            measure_all<METRIC>(rows, row_sn, dim, qbuf, sbc, acc + a0, L.dbuf, an, lane);
-                            __syncthreads();
-                            evals += (unsigned long long)an;
-                            const float dj = lane < an ? L.dbuf[lane] : 0.0f;
-                            ok = __ballot(lane < an && dj < c.dist) == 0ull;
-                            __syncthreads();
-                        }
-                        rejected = !ok;
-                    }
+                    if (!any_def && any_unc) rejected = exact_rejects(c); // too close to call
                     if (!rejected) {
                         if (lane == 0) { acc[rc] = c.id; if (METRIC == M_COS) snacc[rc] = row_sn[c.id]; }
+                        if (METRIC == M_SQ) { const float nj = __shfl(n_j, j, 64); if (lane == 0) nacc[rc] = nj; }
                         rc++;
                         in_block |= 1u << j;
                     }
@@ -1829,7 +1871,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         const long long ph_h0 = __builtin_readcyclecounter();
 #endif
         // the candidate heap's LDS area is idle now: the grouped heuristic borrows it
-        const int rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact,
+        const int rc = relative_neighbor_pruning<METRIC, NS == 8>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact,
 #ifdef HNSW_NO_GROUPED
                                                          nullptr, 0);
 #else

@@ -258,6 +258,35 @@ def test_config_c3_shape_ucosine_m32_efc400(Index):
     assert (a_ids == b_ids).all() and a_d.tobytes() == b_d.tobytes()
 
 
+@pytest.mark.parametrize("mfma", ["1", "0"])
+@pytest.mark.parametrize("metric,dim,kind", [("ucosine", 768, "unit"), ("ucosine", 256, "long"), ("cosine", 264, "raw"), ("sq_euclid", 256, "raw"),
+                                             ("sq_euclid", 512, "centred")])
+def test_mfma_prefiltered_heuristic_decides_like_the_exact_one(Index, monkeypatch, metric, dim, kind, mfma):
+    # RelativeNeighborPruning with the MFMA Gram-block prefilter (beams above 256 candidates, rows of >= 256
+    # floats): the approximate dot products only ever settle a comparison whose margin exceeds the rounding
+    # bound; everything else is measured exactly -- so the graph is the oracle's, with the prefilter on or off.
+    # "long": rows of length 3 under ucosine (the bound assumes unit rows: those blocks must take the exact path).
+    monkeypatch.setenv("HNSW_MI355X_MFMA", mfma)
+    n, M, efc = 2500, 24, 300
+    x = uniform(n, dim, 71)
+    if kind == "unit":
+        x = normalize_f32(x)
+    elif kind == "long":
+        x = normalize_f32(x) * np.float32(3.0)
+    elif kind == "centred":
+        x = x - np.float32(0.5)
+    q = x[:100] + np.float32(0.01)
+    ix = Index(dim, metric)
+    ix.set_collection_size(n); ix.set_max_edges(M); ix.set_max_candidates(efc); ix.set_min_nn(64); ix.set_insert_batch(700)
+    ix.add(x)
+    ref = oracle.OracleIndex(dim, metric, max_edges=M, max_candidates=efc, min_nn=64, collection_size=n)
+    ref.add_batched(x, 700)
+    assert ix.graph_hash() == ref.graph_hash()
+    a_ids, a_d = ix.knn_query(q, 10)
+    b_ids, b_d = ref.knn_query(q, 10)
+    assert (a_ids == b_ids).all() and a_d.tobytes() == b_d.tobytes()
+
+
 @pytest.mark.parametrize("metric,radius", [("sq_euclid", 16.0), ("cosine", 0.2), ("ucosine", 0.2)])
 def test_range_query_matches_oracle(Index, metric, radius):
     # bindings/__tests__/recall_test.py:49-58, GraphTests.cs:227-244: every result within the radius;
