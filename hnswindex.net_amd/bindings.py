@@ -281,7 +281,7 @@ class Index:
                                     dists.ctypes.data_as(_F))
         if status < 0:
             raise RuntimeError(last_error())
-        return ids.copy(), dists.copy()
+        return ids, dists  # freshly allocated above (the reference returns copies of equally fresh arrays, bindings.py:521)
 
     def range_query(self, queries: npt.ArrayLike, radius: float) -> Tuple[List[npt.NDArray[np.int32]], List[npt.NDArray[np.float32]]]:
         """bindings.py:523-597."""

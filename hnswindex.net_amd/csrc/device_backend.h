@@ -238,6 +238,10 @@ private:
     size_t s_lk_cap_[5] = {0, 0, 0, 0, 0};
     bool ensure_search_scratch(long long chunk, long long slots, int k, size_t vis_bytes_per_job);
     void *pinned_stage(size_t bytes);
+    bool staged_upload(float *dst, const float *src, size_t bytes);
+    void *up_pin_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // staged_upload: two pinned chunks per helper thread
+    void *up_ev_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool up_busy_[8] = {false, false, false, false, false, false, false, false};
     struct HostGraphStage;
     HostGraphStage *hg_ = nullptr;
     void *h_stage_ = nullptr;

@@ -162,6 +162,7 @@ Device::~Device()
 {
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) { (void)hipStreamSynchronize(S(stream_)); (void)hipStreamDestroy(S(stream_)); }
+    for (int i = 0; i < 8; ++i) { if (up_pin_[i]) (void)hipHostFree(up_pin_[i]); if (up_ev_[i]) (void)hipEventDestroy((hipEvent_t)up_ev_[i]); }
     if (bg_.th.joinable()) bg_.th.join();
     if (bg_.stream) (void)hipStreamDestroy(S(bg_.stream));
     for (int i = 0; i < 2; ++i) { if (bg_.pin[i]) (void)hipHostFree(bg_.pin[i]); if (bg_.ev[i]) (void)hipEventDestroy((hipEvent_t)bg_.ev[i]); }
@@ -365,6 +366,43 @@ bool Device::download_rows(int first_id, int n, float *rows)
     return true;
 }
 
+// Pageable host memory -> HBM for the large per-call inputs (a 65 536 x 128 query set is 33 MB): four host
+// threads copy their quarter of the source through two pinned 2-MB buffers each while the DMA engine drains the
+// buffers filled before -- the copy into pinned memory (3 ms on one thread) was most of what the boundary call
+// hnsw_knn_query cost beyond the resident-query step.  Everything is enqueued on the context's stream; returns
+// when the SOURCE has been read (the caller's buffer is borrowed only for the call), not when the DMA is done.
+bool Device::staged_upload(float *dst, const float *src, size_t bytes)
+{
+    constexpr int T = 4;
+    constexpr size_t kChunk = 2u << 20;
+    for (int i = 0; i < 2 * T; ++i) {
+        if (!up_pin_[i]) HIP_OK(hipHostMalloc(&up_pin_[i], kChunk, hipHostMallocDefault));
+        if (!up_ev_[i]) { hipEvent_t e; HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); up_ev_[i] = e; }
+    }
+    std::atomic<int> failed{0};
+    const size_t slice = (((bytes + T - 1) / T) + 255) & ~(size_t)255;
+    auto work = [&](int t) {
+        if (hipSetDevice(device_) != hipSuccess) { failed.store(1); return; }
+        const size_t lo = std::min(bytes, slice * (size_t)t), hi = std::min(bytes, slice * (size_t)(t + 1));
+        int b = 0;
+        for (size_t off = lo; off < hi; off += kChunk, b ^= 1) {
+            const int slot = 2 * t + b;
+            const size_t nb = std::min(kChunk, hi - off);
+            if (up_busy_[slot] && hipEventSynchronize((hipEvent_t)up_ev_[slot]) != hipSuccess) { failed.store(1); return; }
+            memcpy(up_pin_[slot], reinterpret_cast<const char *>(src) + off, nb);
+            if (hipMemcpyAsync(reinterpret_cast<char *>(dst) + off, up_pin_[slot], nb, hipMemcpyHostToDevice, S(stream_)) != hipSuccess ||
+                hipEventRecord((hipEvent_t)up_ev_[slot], S(stream_)) != hipSuccess) { failed.store(1); return; }
+            up_busy_[slot] = true;
+        }
+    };
+    std::thread th[T - 1];
+    for (int t = 1; t < T; ++t) th[t - 1] = std::thread(work, t);
+    work(0);
+    for (int t = 1; t < T; ++t) th[t - 1].join();
+    if (failed.load()) { set_dev_error("staged_upload: a HIP call failed"); return false; }
+    return true;
+}
+
 bool Device::set_queries(const float *queries, int nq)
 {
     if (nq < 0 || (nq > 0 && !queries)) { set_dev_error("set_queries: bad argument"); return false; }
@@ -382,13 +420,14 @@ bool Device::set_queries(const float *queries, int nq)
     if (nq == 0) return true;
     {
         const size_t bytes = (size_t)nq * dim_ * sizeof(float);
-        void *hs = bytes <= (256u << 20) ? pinned_stage(bytes) : nullptr;
+        void *hs = bytes < (4u << 20) ? pinned_stage(bytes) : nullptr;
         float *dst = d_queries_;
         if (metric_ == M_I8) { // floats to the staging area, quantised into the resident records
             if (!grow_dev(&q_stage_, &q_stage_cap_, (size_t)nq * (size_t)dim_)) return false;
             dst = q_stage_;
         }
-        if (hs) { memcpy(hs, queries, bytes); HIP_OK(hipMemcpyAsync(dst, hs, bytes, hipMemcpyHostToDevice, S(stream_))); }
+        if (bytes >= (4u << 20)) { if (!staged_upload(dst, queries, bytes)) return false; }
+        else if (hs) { memcpy(hs, queries, bytes); HIP_OK(hipMemcpyAsync(dst, hs, bytes, hipMemcpyHostToDevice, S(stream_))); }
         else HIP_OK(hipMemcpyAsync(dst, queries, bytes, hipMemcpyHostToDevice, S(stream_)));
         if (metric_ == M_I8) {
             hipLaunchKernelGGL(quantize_rows_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, S(stream_), q_stage_, dim_, nq, d_queries_, 0LL, pitch_);
