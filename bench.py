@@ -68,7 +68,11 @@ def parse():
                    help="uniform: i.i.d. U[0,1) (the reference's test data, BASELINE.md); clustered: 1000-centre Gaussian "
                         "mixture, only to show recall on data that has neighbourhood structure")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-clustered-check", action="store_true", help="skip the recall check on data with neighbourhood structure")
     p.add_argument("--no-add-modes", action="store_true")
+    p.add_argument("--build", choices=["replicate", "broadcast"], default="replicate",
+                   help="N > 1: replicate = every rank builds the same deterministic graph itself, in parallel (wall time of one build, "
+                        "no communication; default); broadcast = rank 0 builds, the graph is broadcast (RCCL) and imported by the others")
     p.add_argument("--traversal", choices=["device", "host"], default="device",
                    help="device: graph-resident search kernel (default); host: the literal north-star split -- traversal on "
                         "host threads, distances batched step by step through the inner C ABI (hnswdev_step_submit / _wait)")
@@ -187,9 +191,19 @@ def main():
     ix.set_profiling(True)                 # HIP events around the build kernels too (roofline_add)
     barrier()
     t0 = time.perf_counter()
-    ids = ix.add(x)
-    barrier()
-    build_s = time.perf_counter() - t0
+    if world > 1 and a.build == "broadcast":
+        if rank == 0:
+            ids = ix.add(x)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t0      # rank 0's build; the others wait for the graph
+        dmod.replicate_index(ix, x, a.max_edges, src=0)
+        barrier()
+        if rank != 0:
+            ids = np.arange(a.n, dtype=np.int32)
+    else:
+        ids = ix.add(x)
+        barrier()
+        build_s = time.perf_counter() - t0
     assert ids.size == a.n
     build_stats = ix.stats()
     ix.set_profiling(False)
@@ -400,6 +414,20 @@ def main():
                 del sub
             add_modes["bounded"]["recall_study"] = {"n": ns, **rec}
 
+    # The headline data (i.i.d. uniform, the reference's own test distribution) has no neighbourhood structure at
+    # this dimension, so recall@10 is low on CPU and GPU alike.  The same build and query on data that has some:
+    clustered = None
+    if world == 1 and a.data == "uniform" and not a.no_clustered_check and a.n <= 2_000_000 and a.traversal == "device":
+        xc = make_data(a.n, a.dim, 65537, a.metric, "clustered")
+        qc = make_data(4096, a.dim, 65538, a.metric, "clustered")
+        ic = new_index(a, dev_index, a.n, a.insert_batch)
+        t0 = time.perf_counter(); ic.add(xc); tb = time.perf_counter() - t0
+        ic.knn_query(qc, a.k)
+        t0 = time.perf_counter(); got, _ = ic.knn_query(qc, a.k); tq = time.perf_counter() - t0
+        clustered = {"data": "1000-centre Gaussian mixture, sigma 0.05", "recall_at_10": round(recall_of(xc, qc[:1000], a.k, a.metric, got[:1000]), 4),
+                     "adds_per_sec": round(a.n / tb, 1), "queries_per_sec_4096_per_call_boundary": round(4096 / tq, 1)}
+        del ic, xc
+
     qps = nq_total * a.steps / dt
     shape = (a.dim, a.metric, a.max_edges, a.ef_construction)
     cfg_name = {(128, "sq_euclid", 16, 200): "C2" if a.n <= 1_000_000 else "C4-size", (768, "ucosine", 32, 400): "C3",
@@ -415,14 +443,16 @@ def main():
                         f"(query set sharded over ranks, one all-gather of top-k)",
             "n": a.n, "dim": a.dim, "queries_per_gpu_per_step": per_gpu, "queries_per_step": nq_total, "k": a.k, "max_edges": a.max_edges,
             "ef_construction": a.ef_construction, "ef_search": a.ef_search,
-            "add_mode": f"snapshot-batched, cap {a.insert_batch}", "parallelism": f"query-shard x{world}, index replicated",
+            "add_mode": f"snapshot-batched, cap {a.insert_batch}", "parallelism": f"query-shard x{world}, index replicated ({a.build if world > 1 else 'one build'})",
         },
         "boundary_call_queries_per_sec": round(nq_total / dt_boundary, 1),
         "boundary_call_note": "the same step through the reference's export hnsw_knn_query (host buffers in and out every call: PCIe-inclusive); "
                               "`value` is the contract's figure with the query set already resident in HBM",
         "recall_at_10": round(recall, 4),
         "recall_note": "exact brute-force ground truth; i.i.d. uniform data (the reference's test distribution) has no "
-                       "neighbourhood structure at this size -- the CPU path returns the same ids (see cpu_baseline)",
+                       "neighbourhood structure at this size -- the CPU path returns the same ids (see cpu_baseline); "
+                       "recall_on_clustered_data is the same build and query on data that has structure",
+        "recall_on_clustered_data": clustered,
         "add_per_sec": round(a.n / build_s, 1), "build_seconds": round(build_s, 3),
         "add_note": "hnsw_add of the whole set in one call: the deterministic snapshot-batched schedule (DESIGN.md 4) -- one legal outcome "
                     "of the reference's Parallel.For Add(List), checked bit for bit against the CPU restatement of the same schedule; "

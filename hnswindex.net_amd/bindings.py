@@ -117,6 +117,8 @@ lib.hnsw_mi355x_set_profiling.restype = ct.c_int
 lib.hnsw_mi355x_set_profiling.argtypes = [ct.c_void_p, ct.c_int]
 
 # ---- (B) hnswdev_* -------------------------------------------------------------------------
+lib.hnsw_mi355x_import_nodes.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, _I, ct.c_int]
+lib.hnsw_mi355x_import_edges.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int]
 lib.hnswdev_device_count.restype = ct.c_int
 lib.hnswdev_create.restype = ct.c_int
 lib.hnswdev_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_longlong, ct.POINTER(ct.c_void_p)]
@@ -386,6 +388,21 @@ class Index:
         ix._initialized = True
         ix.dim = int(lib.hnsw_mi355x_dim(h))
         return ix
+
+    def import_graph(self, rows, levels, entry_point: int, layers):
+        """Load a graph built elsewhere into this (still empty) index: rows [n, dim], levels [n], the entry point and per
+        layer a (counts[n], edges[n, stride]) pair as `export_edges` returns them.  Afterwards the index answers and
+        grows exactly like the one the graph came from."""
+        if not self._initialized:
+            self._initialize()
+        a = _as_2d_f32(rows, self.dim)
+        lv = np.ascontiguousarray(levels, dtype=np.int32)
+        self._check(lib.hnsw_mi355x_import_nodes(self._h, a.ctypes.data_as(_F), int(a.shape[0]), int(a.shape[1]),
+                                                 lv.ctypes.data_as(_I), int(entry_point)))
+        for layer, (counts, edges) in enumerate(layers):
+            c = np.ascontiguousarray(counts, dtype=np.int32)
+            e = np.ascontiguousarray(edges, dtype=np.int32)
+            self._check(lib.hnsw_mi355x_import_edges(self._h, layer, c.ctypes.data_as(_I), e.ctypes.data_as(_I), int(e.shape[1])))
 
     def graph_hash(self) -> int:
         return int(lib.hnsw_mi355x_graph_hash(self._h))

@@ -315,6 +315,22 @@ API void *hnsw_mi355x_deserialize(const char *distance_metric, const char *path_
     }
     return ix;
 }
+API int hnsw_mi355x_import_nodes(void *h, const float *rows, int n, int dim, const int *levels, int entry_point)
+{
+    if (!h) return 0;
+    LOCK_INDEX(h);
+    std::string err;
+    if (static_cast<HnswIndex *>(h)->import_nodes(rows, n, dim, levels, entry_point, err) < 0) { set_error(err); return -1; }
+    return 0;
+}
+API int hnsw_mi355x_import_edges(void *h, int layer, const int *counts, const int *edges, int stride)
+{
+    if (!h) return 0;
+    LOCK_INDEX(h);
+    std::string err;
+    if (static_cast<HnswIndex *>(h)->import_edges(layer, counts, edges, stride, err) < 0) { set_error(err); return -1; }
+    return 0;
+}
 API uint64_t hnsw_mi355x_graph_hash(void *h)
 {
     if (!h) return 0;

@@ -1292,6 +1292,57 @@ HnswIndex *HnswIndex::deserialize(int metric, const Params &backend, const char 
     return ix;
 }
 
+// ---- import of a graph built elsewhere --------------------------------------------------------
+int HnswIndex::import_nodes(const float *rows, int n, int dim, const int *levels, int entry_point, std::string &err)
+{
+    if (failed(err)) return -1;
+    if (!rows || !levels || n <= 0 || dim <= 0) { err = "System.ArgumentException: hnsw_mi355x_import_nodes: bad argument"; return -1; }
+    if (graph_.length != 0) { err = "System.InvalidOperationException: hnsw_mi355x_import_nodes: the index already holds items"; return -1; }
+    if (entry_point < 0 || entry_point >= n) { err = "System.ArgumentException: hnsw_mi355x_import_nodes: entry point outside the nodes"; return -1; }
+    for (int i = 0; i < n; ++i)
+        if (levels[i] < 0 || levels[i] > 200) { err = "System.ArgumentException: hnsw_mi355x_import_nodes: level out of range"; return -1; }
+    if (!ensure_dim(dim, err)) return -1;
+    if (!ensure_capacity(n, err)) return -1;
+    graph_.grow_for(n);
+    for (int i = 0; i < n; ++i) (void)graph_.add_node(levels[i], false);
+    for (int i = 0; i < n; ++i) (void)rng_.next_single(); // one level draw per item, as on the index the graph came from
+    graph_.entry = entry_point;
+    if (!dev_->upload_rows(0, n, rows)) return fail(get_dev_error(), err);
+    graph_dirty_ = true;       // the HBM mirror is (re)built from the host lists on the next call
+    host_lists_stale_ = false;
+    return 0;
+}
+
+int HnswIndex::import_edges(int layer, const int *counts, const int *edges, int stride, std::string &err)
+{
+    if (failed(err)) return -1;
+    if (!counts || !edges || layer < 0 || stride < 1) { err = "System.ArgumentException: hnsw_mi355x_import_edges: bad argument"; return -1; }
+    if (graph_.length <= 0) { err = "System.InvalidOperationException: hnsw_mi355x_import_edges: call hnsw_mi355x_import_nodes first"; return -1; }
+    if (!refresh_host_lists(err)) return -1;
+    const int n = graph_.length, cap = graph_.max_edges_at(layer);
+    // validate everything before anything is written: a bad list must not leave a half-imported layer behind
+    std::vector<int> stamp((size_t)n, -1);
+    for (int i = 0; i < n; ++i) {
+        if (graph_.level[(size_t)i] < layer) continue;
+        const int c = counts[i];
+        if (c < 0 || c > cap || c > stride) { err = "System.ArgumentException: hnsw_mi355x_import_edges: list longer than MaxEdges(layer) (or than the stride)"; return -1; }
+        for (int j = 0; j < c; ++j) {
+            const int t = edges[(size_t)i * stride + j];
+            if (t < 0 || t >= n || graph_.level[(size_t)t] < layer) { err = "System.ArgumentException: hnsw_mi355x_import_edges: edge to a node outside the layer"; return -1; }
+            if (stamp[(size_t)t] == i) { err = "System.ArgumentException: hnsw_mi355x_import_edges: duplicate id in a list"; return -1; }
+            stamp[(size_t)t] = i;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        if (graph_.level[(size_t)i] < layer) continue;
+        int *l = graph_.list(i, layer);
+        l[0] = counts[i];
+        std::memcpy(l + 1, edges + (size_t)i * stride, sizeof(int) * (size_t)counts[i]);
+    }
+    graph_dirty_ = true;
+    return 0;
+}
+
 uint64_t HnswIndex::graph_hash()
 {
     std::string e;

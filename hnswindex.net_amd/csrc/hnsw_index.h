@@ -59,6 +59,10 @@ public:
     int serialize(const char *path, std::string &err);
     static HnswIndex *deserialize(int metric, const Params &backend, const char *path, std::string &err);
 
+    // hnsw_mi355x_import_nodes / _edges: a graph built elsewhere into an empty index (see include/hnsw_mi355x.h)
+    int import_nodes(const float *rows, int n, int dim, const int *levels, int entry_point, std::string &err);
+    int import_edges(int layer, const int *counts, const int *edges, int stride, std::string &err);
+
     int count() const { return graph_.count; }
     int dim() const { return dim_; }
     // The host copy of the graph.  After a device-linked Add the neighbour lists live in the HBM

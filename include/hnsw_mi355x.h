@@ -132,6 +132,16 @@ uint64_t hnsw_mi355x_graph_hash(void *handle);
  * hnsw_mi355x_set_* backend knobs are consumed as by hnsw_create. */
 int hnsw_mi355x_serialize(void *handle, const char *path_utf8);
 void *hnsw_mi355x_deserialize(const char *distance_metric_utf8, const char *path_utf8);
+/* Loading a graph that was built elsewhere -- by another replica of this index (multi-GPU: build once, broadcast,
+ * import; hnswindex.net_amd/distributed.py::replicate_index) or by a host that owns one -- into a handle that holds
+ * nothing yet.  hnsw_mi355x_import_nodes: rows (n x dim float32, id == row index), levels[i] = MaxLayer of node i
+ * (Node.cs:27), the entry point (GraphData.EntryPointId); then one hnsw_mi355x_import_edges per layer 0..max(levels)
+ * in the layout of hnsw_mi355x_export_edges (counts ignored where the node lacks the layer; ids in EdgeList order,
+ * Node.cs:31-107).  Lists are validated (ids in range and on that layer, no duplicates, length <= MaxEdges(layer)).
+ * Afterwards the index behaves as if it had inserted the n items itself: the level generator is advanced by n draws
+ * (GraphData.cs:211-219), so later Adds continue exactly as on the index the graph came from.  0 / -1. */
+int hnsw_mi355x_import_nodes(void *handle, const float *rows, int n, int dim, const int *levels, int entry_point);
+int hnsw_mi355x_import_edges(void *handle, int layer, const int *counts, const int *edges, int stride);
 /* Bulk forms: levels of nodes [0, min(count, cap)); returns count. */
 int hnsw_mi355x_export_levels(void *handle, int *out, int cap);
 /* counts[id] = out-degree of (id, layer), -1 where the node has no such layer;

@@ -44,6 +44,18 @@ def main():
             res[f"dst{dst}"] = bool((ids == full_ids).all() and np.ascontiguousarray(d).tobytes() == full_d.tobytes())
     lo, hi = hnswindex.net_amd.distributed.shard_bounds(q.shape[0], world, rank)
     res["shard_calls"] = calls == [hi - lo, hi - lo]
+    # build once on rank 0, broadcast the graph, import on rank 1: the replica equals the one rank 1 built itself
+    rep = hnswindex.Index(32)
+    rep.set_collection_size(20000); rep.set_max_candidates(64); rep.set_min_nn(32)
+    hnswindex.net_amd.distributed.replicate_index(ix if rank == 0 else rep, x, 16, src=0)
+    if rank != 0:
+        r_ids, r_d = rep.knn_query(q[:200], 10)
+        o_ids, o_d = ix.knn_query(q[:200], 10)
+        extra = uniform(300, 32, 13)
+        res["replicated"] = bool(rep.graph_hash() == ix.graph_hash() and (r_ids == o_ids).all() and r_d.tobytes() == o_d.tobytes()
+                                 and (rep.add(extra) == ix.add(extra)).all() and rep.graph_hash() == ix.graph_hash())
+    else:
+        res["replicated"] = True
     res["native_lib"] = str(hnswindex.net_amd.LIB_PATH)
     (out_dir / f"rank{rank}.json").write_text(json.dumps(res))
     dist.barrier()

@@ -78,6 +78,6 @@ def test_two_ranks_share_the_gpu_with_the_product_searcher(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for rank in (0, 1):
         res = json.loads((tmp_path / f"rank{rank}.json").read_text())
-        assert res["replicas_identical"] and res["dstNone"] and res["dst0"] and res["shard_calls"], res
+        assert res["replicas_identical"] and res["dstNone"] and res["dst0"] and res["shard_calls"] and res["replicated"], res
         assert res["native_lib"].endswith("HNSWIndex.Native.so")
 

@@ -388,3 +388,43 @@ def test_resident_query_set_gives_the_same_answers(Index):
     for _ in range(2):
         b_ids, b_d = ix.knn_query_resident(10)
         assert (a_ids == b_ids).all() and a_d.tobytes() == b_d.tobytes()
+
+
+@pytest.mark.parametrize("metric", ["sq_euclid", "cosine"])
+def test_import_graph_makes_an_identical_replica(Index, metric):
+    # hnsw_mi355x_import_nodes / _edges (build once, broadcast, import): the replica has the source's graph hash and
+    # answers, and grows identically afterwards (the level generator is advanced past the imported items)
+    n, dim, M = 6000, 48, 12
+    x, more, q = uniform(n, dim, 301), uniform(500, dim, 302), uniform(300, dim, 303)
+    def make():
+        ix = Index(dim, metric)
+        ix.set_collection_size(4096); ix.set_max_edges(M); ix.set_max_candidates(80); ix.set_min_nn(40)
+        return ix
+    src = make()
+    src.add(x)
+    lv = src.levels()
+    layers = [src.export_edges(L, 2 * M + 2 if L == 0 else M + 2) for L in range(int(lv.max()) + 1)]
+    rep = make()
+    rep.import_graph(x, lv, src.entry_point, layers)
+    assert rep.graph_hash() == src.graph_hash() and rep.count == n and (rep.levels() == lv).all()
+    a, b = src.knn_query(q, 10), rep.knn_query(q, 10)
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
+    assert (src.add(more) == rep.add(more)).all() and rep.graph_hash() == src.graph_hash()
+    rep.remove([5, 17]); src.remove([5, 17])
+    assert rep.graph_hash() == src.graph_hash()
+    # refused: a second import, and lists that would send a traversal out of bounds
+    with pytest.raises(RuntimeError, match="already holds items"):
+        rep.import_graph(x, lv, src.entry_point, layers)
+    flat = int(np.nonzero(lv == 0)[0][0])
+    tall = int(np.nonzero(lv >= 1)[0][0])
+    bad = [(c.copy(), e.copy()) for c, e in layers]
+    bad[1][1][tall, 0] = flat                                  # layer-1 edge to a node without layer 1
+    fresh = make()
+    with pytest.raises(RuntimeError, match="outside the layer"):
+        fresh.import_graph(x, lv, src.entry_point, bad)
+    bad = [(c.copy(), e.copy()) for c, e in layers]
+    bad[0][1][flat, 1] = bad[0][1][flat, 0]                    # duplicate id
+    fresh2 = make()
+    with pytest.raises(RuntimeError, match="duplicate id"):
+        fresh2.import_graph(x, lv, src.entry_point, bad)
+
