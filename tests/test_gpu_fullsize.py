@@ -69,6 +69,18 @@ def test_full_size_query_properties(built):
     assert ix.stats()["search_overflows"] == 0
 
 
+def test_c2_whole_graph_equals_the_cpu_restatement_of_the_schedule(built):
+    # The full C2 build both ways: the product's graph (default schedule: snapshot batches, device insert + link
+    # kernels, grouped heuristic) against the oracle running the same schedule on 16 host threads -- one hash for
+    # the million adjacency lists.  (The schedule is this build's own, DESIGN.md 4: this pins HIP == CPU restatement.)
+    ix, x = built
+    ref = oracle.OracleIndex(DIM, max_edges=16, max_candidates=200, min_nn=128, collection_size=N, allow_removals=False)
+    ref.add_batched(x, 65536, threads=16)
+    assert ref.graph_hash() == ix.graph_hash()
+    del ref
+    gc.collect()
+
+
 # ------------------------------------------------------------------ C3 and C4 at full size
 def _uniform_chunked(n, dim, seed, chunk=1_000_000):
     """uniform(n, dim, seed) filled chunk by chunk (the generator's stream is the same; no 2x peak)."""

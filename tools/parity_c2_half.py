@@ -16,10 +16,10 @@ cap = 65536
 x = np.random.default_rng(65537).random((n, 128), dtype=np.float32)
 q = np.random.default_rng(65538).random((20_000, 128), dtype=np.float32)
 ix = hnswindex.Index(128)
-ix.set_collection_size(n); ix.set_max_edges(16); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_insert_batch(cap)
+ix.set_collection_size(n); ix.set_max_edges(16); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_insert_batch(cap); ix.set_allow_removals(False)
 t = time.time(); ix.add(x); tg = time.time() - t
 print(f"gpu build {tg:.2f} s ({n / tg:.0f} adds/s)", flush=True)
-ref = oracle.OracleIndex(128, max_edges=16, max_candidates=200, min_nn=128, collection_size=n)
+ref = oracle.OracleIndex(128, max_edges=16, max_candidates=200, min_nn=128, collection_size=n, allow_removals=False)
 done = threading.Event()
 
 
@@ -30,7 +30,7 @@ def heartbeat():  # the oracle call is silent for minutes; the GPU runner takes 
 
 t = time.time()
 threading.Thread(target=heartbeat, daemon=True).start()
-ref.add_batched(x, cap)
+ref.add_batched(x, cap, threads=16)  # the same schedule, searches and per-list link work on 16 host threads
 done.set()
 tr = time.time() - t
 print(f"oracle build {tr:.1f} s ({n / tr:.0f} adds/s)", flush=True)
