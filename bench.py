@@ -209,10 +209,11 @@ def main():
     ix.set_profiling(False)
     my_hash = ix.graph_hash()
     replicas_identical = True
-    if world > 1:  # every rank builds the same deterministic graph (replicas only): prove it
-        hs = [None] * world
-        dist.all_gather_object(hs, int(my_hash))
-        replicas_identical = len(set(hs)) == 1
+    if world > 1:  # every rank holds the same deterministic graph (replicas only): prove it
+        h63 = torch.tensor([int(my_hash) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        hs = torch.empty(world, dtype=torch.int64, device=h63.device)
+        dist.all_gather_into_tensor(hs, h63)
+        replicas_identical = bool((hs == hs[0]).all().item())
 
     nq_total = a.nq * world if a.scaling == "weak" else a.nq
     q_all = make_data(nq_total, a.dim, 65538, a.metric, a.data)  # queries distinct from the base vectors
