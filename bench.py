@@ -69,6 +69,8 @@ def parse():
                         "mixture, only to show recall on data that has neighbourhood structure")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-clustered-check", action="store_true", help="skip the recall check on data with neighbourhood structure")
+    p.add_argument("--no-process-warmup", action="store_true", help="skip the throw-away index that warms the process up (profiler runs: "
+                   "its launches would be averaged into the per-kernel statistics)")
     p.add_argument("--no-add-modes", action="store_true")
     p.add_argument("--build", choices=["replicate", "broadcast"], default="replicate",
                    help="N > 1: replicate = every rank builds the same deterministic graph itself, in parallel (wall time of one build, "
@@ -183,10 +185,11 @@ def main():
     extra_total = a.seq_adds + a.bounded_adds + a.batched_adds
     # process warm-up (untimed): a throw-away index loads the library's code objects and creates the HIP
     # context once -- 0.15 s on the first launch of every kernel family, which is not Add throughput
-    warm = new_index(a, dev_index, 4096, a.insert_batch)
-    warm.add(x[:4096])
-    warm.knn_query(x[:64], a.k)
-    del warm
+    if not a.no_process_warmup:
+        warm = new_index(a, dev_index, 4096, a.insert_batch)
+        warm.add(x[:4096])
+        warm.knn_query(x[:64], a.k)
+        del warm
     ix = new_index(a, dev_index, a.n + extra_total, a.insert_batch)
     ix.set_profiling(True)                 # HIP events around the build kernels too (roofline_add)
     barrier()

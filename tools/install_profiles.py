@@ -23,7 +23,8 @@ shutil.copy(src / "pmc_calibration.json", dst / f"{r}_pmc_calibration_kbench.jso
 (dst / f"{r}_pmc_calibration_kbench.log").write_text("".join(l for l in open(src / "kbench_calibration.log") if l.startswith(("N=", "v1"))))
 for f, name in (("bench_under_rocprof", "bench_under_rocprof"), ("bench_pmc_fetch", "bench_pmc_fetch"), ("bench_pmc_write", "bench_pmc_write"),
                 ("bench_plain", "bench_1m_plain"), ("bench_host_cabi", "bench_host_cabi_200k"), ("bench_c3", "bench_c3_1m_768_ucosine"),
-                ("bench_c4_size", "bench_c4_10m_1gpu"), ("bench_c5_size", "bench_c5_10m_96_int8_1gpu"), ("bench_clustered", "bench_1m_clustered")):
+                ("bench_c4_size", "bench_c4_10m_1gpu"), ("bench_c5_size", "bench_c5_10m_96_int8_1gpu"), ("bench_clustered", "bench_1m_clustered"),
+                ("bench_2rank_gloo", "bench_2rank_gloo_rehearsal_200k")):
     if (src / f"{f}.log").exists() and json_line(src / f"{f}.log"):
         (dst / f"{r}_{name}.json").write_text(json_line(src / f"{f}.log"))
 if (src / "kernel_stats_host_cabi.json").exists():

@@ -9,7 +9,7 @@ WHAT=${1:-all}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profiles; mkdir -p $O
 [ -x $R/tools/kbench ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off $R/tools/kbench.hip -o $R/tools/kbench
 cd /tmp && export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-add-modes --small-batch 0"
+Q="--no-cpu-baseline --no-add-modes --small-batch 0 --no-clustered-check --no-process-warmup"
 if [ $WHAT = core ] || [ $WHAT = all ]; then
 # 0) the plain default line (no profiler attached)
 python3 $R/bench.py > $O/bench_plain.log 2>&1
