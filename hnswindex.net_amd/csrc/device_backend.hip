@@ -675,6 +675,7 @@ static int resident_blocks(K kernel, size_t lds, int num_cu)
 {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (const char *e = std::getenv("HNSW_MI355X_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e))); // experiments: fewer persistent waves
     return per_cu * std::max(1, num_cu);
 }
 
