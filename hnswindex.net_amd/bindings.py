@@ -50,7 +50,9 @@ class Stats(ct.Structure):
                 ("insert_launches", ct.c_uint64), ("insert_evals", ct.c_uint64), ("insert_timed_launches", ct.c_uint64),
                 ("insert_timed_evals", ct.c_uint64), ("insert_kernel_ms", ct.c_double),
                 ("link_launches", ct.c_uint64), ("link_evals", ct.c_uint64), ("link_timed_launches", ct.c_uint64),
-                ("link_timed_evals", ct.c_uint64), ("link_kernel_ms", ct.c_double), ("visited_hash_launches", ct.c_uint64)]
+                ("link_timed_evals", ct.c_uint64), ("link_kernel_ms", ct.c_double), ("visited_hash_launches", ct.c_uint64),
+                ("range_launches", ct.c_uint64), ("range_evals", ct.c_uint64), ("range_timed_launches", ct.c_uint64),
+                ("range_timed_evals", ct.c_uint64), ("range_kernel_ms", ct.c_double), ("range_handbacks", ct.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -132,6 +134,10 @@ lib.hnswdev_graph_begin.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, _I]
 lib.hnswdev_graph_set_layer.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int]
 lib.hnswdev_graph_commit.argtypes = [ct.c_void_p]
 lib.hnswdev_knn_search.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _I, _F, _I]
+lib.hnswdev_range_search.restype = ct.c_int
+lib.hnswdev_range_search.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, ct.c_float, _I, _I]
+lib.hnswdev_range_results.restype = ct.c_int
+lib.hnswdev_range_results.argtypes = [ct.c_void_p, _I, _F]
 lib.hnswdev_sync.argtypes = [ct.c_void_p]
 lib.hnswdev_set_profiling.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnswdev_get_stats.argtypes = [ct.c_void_p, ct.POINTER(Stats)]
@@ -523,6 +529,21 @@ class DeviceBackend:
         self._check(lib.hnswdev_knn_search(self._ctx, q.ctypes.data_as(_F), n, int(entry_point), int(k_beam), int(k_out),
                                            ids.ctypes.data_as(_I), d.ctypes.data_as(_F), flags.ctypes.data_as(_I)))
         return ids, d, flags
+
+    def range_search(self, queries, entry_point: int, radius: float):
+        """Per query the ids / distances within `radius`, ascending by distance; flags[i] = 1: handed back (empty)."""
+        q = _as_2d_f32(queries, self.dim)
+        n = q.shape[0]
+        counts = np.zeros(n, dtype=np.int32)
+        flags = np.zeros(n, dtype=np.int32)
+        self._check(lib.hnswdev_range_search(self._ctx, q.ctypes.data_as(_F), n, int(entry_point), float(radius),
+                                             counts.ctypes.data_as(_I), flags.ctypes.data_as(_I)))
+        total = int(counts.sum())
+        ids = np.empty(max(total, 1), dtype=np.int32)
+        d = np.empty(max(total, 1), dtype=np.float32)
+        self._check(lib.hnswdev_range_results(self._ctx, ids.ctypes.data_as(_I), d.ctypes.data_as(_F)))
+        cuts = np.cumsum(counts)[:-1]
+        return np.split(ids[:total], cuts), np.split(d[:total], cuts), flags
 
     def set_profiling(self, on: bool):
         self._check(lib.hnswdev_set_profiling(self._ctx, int(on)))

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <vector>
 #include <thread>
 
 #include "../../include/hnsw_mi355x.h"
@@ -167,6 +168,17 @@ public:
     bool graph_set_layer(int layer, const int *counts, const int *edges, int stride);
     bool graph_commit();
     bool knn_search(const float *queries, int nq, int entry_point, int k_beam, int k_out, int *out_ids, float *out_d, int *out_flag);
+    // RangeQuery on the device (graph_range_kernel): per job the results within `range`, UNSORTED, at
+    // found[off[i] .. off[i] + cnt[i]); flag[i] = 1: handed back (cnt 0).  jobs[].qref must name a resident query.
+    struct RangeResults {
+        std::vector<unsigned long long> off;
+        std::vector<int> cnt, flag, entry; // entry[i]: the layer-0 entry node FindEntryPointQuery reached
+        std::vector<SearchHit> found;
+    };
+    bool range_batch(const SearchJob *jobs, int njobs, float range, RangeResults *res);
+    // the C ABI's form: sorted per query, equal distances handed back; results kept until the next call
+    bool range_search(const float *queries, int nq, int entry_point, float range, int *out_counts, int *out_flags);
+    bool range_results(int *out_ids, float *out_d);
 
     void set_profiling(bool on) { profiling_ = on; }
     void get_stats(hnswdev_stats *out);
@@ -216,7 +228,7 @@ private:
     int *s_vistab_ = nullptr; // per-wave visited-id hash tables
     size_t s_vistab_cap_ = 0;
     int s_vistab_each_ = 0;
-    bool visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_cap);
+    bool visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_cap, int min_cap = 512);
     int num_cu_ = 256;
     // Persistent launches never use more than 16 one-wave blocks per CU (the traversal kernels need
     // >= 128 VGPRs): the per-wave scratch (visited bitsets, spill areas, logs) is sized for that.
@@ -234,6 +246,15 @@ private:
     size_t s_order_cap_ = 0;
     SearchHit *s_spill_ = nullptr;
     size_t s_spill_cap_ = 0;
+    SearchHit *s_arena_ = nullptr; // range search: the launch's results, packed
+    size_t s_arena_cap_ = 0;
+    unsigned long long *s_roff_ = nullptr, *s_arena_used_ = nullptr;
+    int *s_rentry_ = nullptr;
+    SearchHit *s_rlists_ = nullptr; // range search: long per-wave result lists for the few jobs that outgrow s_spill_'s
+    size_t s_rlists_cap_ = 0;
+    double range_hint_ = 48.0;      // results per query of the last range search (sizes the next arena)
+    size_t s_roff_cap_ = 0;
+    std::vector<SearchHit> abi_range_; // hnswdev_range_search's results until hnswdev_range_results
     int *s_lk_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t s_lk_cap_[5] = {0, 0, 0, 0, 0};
     bool ensure_search_scratch(long long chunk, long long slots, int k, size_t vis_bytes_per_job);

@@ -194,7 +194,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -712,7 +712,7 @@ static bool mfma_heuristic()
 // The per-wave visited-id hash tables (VisitedSet): capacity a power of two, >= 16384 and >= 64 per
 // beam entry (a traversal visits roughly 35 ids per beam entry), all entries -1 between jobs.
 // HNSW_MI355X_VIS_HASH=1/0 forces / forbids them; HNSW_MI355X_VIS_HASH_CAP overrides the capacity (tests).
-bool Device::visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_cap)
+bool Device::visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_cap, int min_cap)
 {
     *out = nullptr;
     *out_cap = 0;
@@ -724,6 +724,8 @@ bool Device::visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_
     int cap = 16384;
     while (cap < 64 * k && cap < (1 << 22)) cap <<= 1;
     if (const char *c = std::getenv("HNSW_MI355X_VIS_HASH_CAP")) { cap = 64; while (cap < std::atoi(c) && cap < (1 << 22)) cap <<= 1; }
+    // a traversal step inserts up to min_cap / 4 ids between two looks at crowded() (limit: 3/4 of the table)
+    while (cap < min_cap) cap <<= 1;
     const size_t need = (size_t)max_slots() * (size_t)cap;
     if (need > s_vistab_cap_ || cap != s_vistab_each_) {
         HIP_OK(hipStreamSynchronize(S(stream_)));
@@ -1327,6 +1329,218 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     return true;
 }
 
+// RangeQuery on the device (graph_range_kernel).  A launch packs its results into an arena sized from the last
+// call's results per query (at least 1M entries); the jobs that did not fit run once more in an arena of exactly
+// the size they asked for.  Jobs whose result set outgrew a wave's list (kSpillCap entries) run again, few at a
+// time, with lists as long as the graph.
+bool Device::range_batch(const SearchJob *jobs, int njobs, float range, RangeResults *res)
+{
+    res->off.assign((size_t)std::max(njobs, 0), 0ull);
+    res->cnt.assign((size_t)std::max(njobs, 0), 0);
+    res->flag.assign((size_t)std::max(njobs, 0), 0);
+    res->entry.assign((size_t)std::max(njobs, 0), -1);
+    res->found.clear();
+    if (njobs <= 0) return true;
+    if (!jobs) { set_dev_error("range_batch: bad argument"); return false; }
+    if (g_n_ <= 0) { set_dev_error("range_batch: no graph uploaded"); return false; }
+    if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("range_batch: job outside the uploaded graph / rows / queries"); return false; }
+    for (int i = 0; i < njobs; ++i)
+        if (jobs[i].qref < 0 || jobs[i].search_layer != 0) { set_dev_error("range_batch: jobs must name a resident query and layer 0"); return false; }
+    const int nbcap_r = kRangeFan * nbcap(); // the kernel expands kRangeFan lists per step
+    const size_t lds = search_lds_bytes(0, 0, pitch_, false, nbcap_r);
+    if (lds > 64 * 1024) { set_dev_error("range_batch: dimension exceeds the LDS budget"); return false; }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    long long vis_words = ((g_n_ + 31) / 32 + 3) & ~3LL;
+    size_t vis_bytes_per_job = sizeof(unsigned) * (size_t)vis_words;
+    int *vis_tab = nullptr;
+    int vis_tab_cap = 0;
+    // 32 768 slots: 24 576 visited ids before a hand-back; a step inserts up to kRangeFan lists of 128 ids
+    if (!visited_table(vis_bytes_per_job, 512, &vis_tab, &vis_tab_cap, 4 * kRangeFan * 128)) return false;
+    if (vis_tab) { vis_words = 0; vis_bytes_per_job = 16; }
+    const long long chunk = std::min<long long>(njobs, 1 << 20);
+    if (!ensure_search_scratch(chunk, max_slots(), 0, vis_bytes_per_job)) return false; // also the per-wave result lists (s_spill_)
+    if ((size_t)chunk > s_roff_cap_) {
+        if (s_roff_) HIP_OK(hipFree(s_roff_));
+        if (s_rentry_) HIP_OK(hipFree(s_rentry_));
+        s_roff_ = nullptr; s_rentry_ = nullptr; s_roff_cap_ = 0;
+        HIP_OK(hipMalloc(&s_roff_, sizeof(unsigned long long) * (size_t)chunk));
+        HIP_OK(hipMalloc(&s_rentry_, sizeof(int) * (size_t)chunk));
+        s_roff_cap_ = (size_t)chunk;
+    }
+    if (!s_arena_used_) HIP_OK(hipMalloc(&s_arena_used_, sizeof(unsigned long long)));
+    constexpr size_t kArenaMax = (size_t)1 << 27; // 1 GB of results per launch; what does not fit then is handed back
+
+    // One launch over the jobs listed in `todo` (at most `chunk`): results appended to res->found; jobs that found
+    // the arena full are listed in `again` and *need = the entries they asked for; handed-back jobs in `handed`.
+    auto launch = [&](const int *todo, int nj, ND *lists, int list_cap, int grid_cap, size_t arena_cap, std::vector<int> &again,
+                      unsigned long long *need, std::vector<int> &handed) -> bool {
+        if (!grow_dev(&s_arena_, &s_arena_cap_, arena_cap)) return false;
+        // pinned layout: [evals, used (16 B) | jobs | offsets | counts | flags | entries]; then reused for the results
+        const size_t b_jobs = sizeof(SearchJob) * (size_t)nj, b_off = 8u * (size_t)nj, b_i = 4u * (size_t)nj;
+        char *hs = static_cast<char *>(pinned_stage(16 + b_jobs + b_off + 3 * b_i));
+        if (!hs) return false;
+        SearchJob *h_jobs = reinterpret_cast<SearchJob *>(hs + 16);
+        for (int i = 0; i < nj; ++i) h_jobs[i] = jobs[todo[i]];
+        HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, b_jobs, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int), st));
+        HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
+        HIP_OK(hipMemsetAsync(s_arena_used_, 0, sizeof(unsigned long long), st));
+        const bool timed = profiling_;
+        if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
+#define LAUNCH_RANGE2(M, H_)                                                                                                          \
+    do {                                                                                                                               \
+        const int slots_ = std::min(std::min(max_slots(), grid_cap), resident_blocks(graph_range_kernel<M, H_>, lds, num_cu_));        \
+        hipLaunchKernelGGL((graph_range_kernel<M, H_>), dim3(std::min<int>(nj, slots_)), dim3(64), lds, st, d_rows_, d_row_sn_,        \
+                           d_queries_, d_q_sn_, pitch_, g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, range,            \
+                           lists, list_cap, s_visited_, vis_words, vis_tab, vis_tab_cap,                                               \
+                           reinterpret_cast<ND *>(s_arena_), (unsigned long long)arena_cap, s_arena_used_, s_roff_, s_cnt_, s_flag_,   \
+                           s_rentry_, s_evals_, nbcap_r, nj, s_jobctr_);                                                               \
+    } while (0)
+#define LAUNCH_RANGE(M) do { if (vis_tab) LAUNCH_RANGE2(M, true); else LAUNCH_RANGE2(M, false); } while (0)
+        if (metric_ == M_SQ) LAUNCH_RANGE(M_SQ);
+        else if (metric_ == M_COS) LAUNCH_RANGE(M_COS);
+        else if (metric_ == M_I8) LAUNCH_RANGE(M_I8);
+        else LAUNCH_RANGE(M_UCOS);
+#undef LAUNCH_RANGE
+#undef LAUNCH_RANGE2
+        HIP_OK(hipGetLastError());
+        if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
+        unsigned long long *h_hdr = reinterpret_cast<unsigned long long *>(hs);
+        unsigned long long *h_off = reinterpret_cast<unsigned long long *>(hs + 16 + b_jobs);
+        int *h_cnt = reinterpret_cast<int *>(hs + 16 + b_jobs + b_off);
+        int *h_flag = h_cnt + nj, *h_entry = h_flag + nj;
+        HIP_OK(hipMemcpyAsync(h_hdr, s_evals_, 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(h_hdr + 1, s_arena_used_, 8, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(h_off, s_roff_, b_off, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(h_cnt, s_cnt_, b_i, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(h_flag, s_flag_, b_i, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(h_entry, s_rentry_, b_i, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        const unsigned long long ev = h_hdr[0], used = h_hdr[1];
+        // entries claimed beyond arena_cap belong to the jobs flagged 3 and were never written; the claims of the
+        // finished jobs all lie below it, though not contiguously: the span they cover is copied back
+        unsigned long long span = 0, finished = 0;
+        const size_t base = res->found.size();
+        for (int i = 0; i < nj; ++i) {
+            const int j = todo[i];
+            res->entry[(size_t)j] = h_entry[i];
+            res->flag[(size_t)j] = 0;
+            if (h_flag[i] == 0) {
+                res->off[(size_t)j] = base + h_off[i];
+                res->cnt[(size_t)j] = h_cnt[i];
+                finished += (unsigned long long)h_cnt[i];
+                if (h_cnt[i] > 0) span = std::max(span, h_off[i] + (unsigned long long)h_cnt[i]);
+            } else if (h_flag[i] == 3) again.push_back(j);
+            else { res->flag[(size_t)j] = 1; handed.push_back(j); }
+        }
+        *need = used - finished;
+        if (span > 0) { // (the stage is reused from here on: everything above has been consumed)
+            res->found.resize(base + (size_t)span);
+            const size_t piece = (size_t)8 << 20; // entries per copy (64 MB)
+            for (size_t o = 0; o < (size_t)span; o += piece) {
+                const size_t nn = std::min(piece, (size_t)span - o);
+                char *hr = static_cast<char *>(pinned_stage(sizeof(SearchHit) * nn));
+                if (!hr) return false;
+                HIP_OK(hipMemcpyAsync(hr, s_arena_ + o, sizeof(SearchHit) * nn, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipStreamSynchronize(st));
+                memcpy(res->found.data() + base + o, hr, sizeof(SearchHit) * nn);
+            }
+        }
+        if (vis_tab) stats_.visited_hash_launches++;
+        stats_.search_launches++;
+        stats_.search_evals += ev;
+        stats_.range_launches++;
+        stats_.range_evals += ev;
+        if (timed) {
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)ev0_, (hipEvent_t)ev1_));
+            stats_.search_kernel_ms += ms;
+            stats_.search_timed_launches++;
+            stats_.search_timed_evals += ev;
+            stats_.range_kernel_ms += ms;
+            stats_.range_timed_launches++;
+            stats_.range_timed_evals += ev;
+        }
+        return true;
+    };
+    // `todo` through `launch`, with one more pass for the jobs that found the arena full
+    auto run = [&](std::vector<int> todo, ND *lists, int list_cap, int grid_cap, size_t arena_cap, std::vector<int> &handed) -> bool {
+        for (int pass = 0; pass < 2 && !todo.empty(); ++pass) {
+            std::vector<int> again;
+            unsigned long long need_total = 0;
+            for (size_t off = 0; off < todo.size(); off += (size_t)chunk) {
+                const int nj = (int)std::min<size_t>((size_t)chunk, todo.size() - off);
+                unsigned long long need = 0;
+                if (!launch(todo.data() + off, nj, lists, list_cap, grid_cap, arena_cap, again, &need, handed)) return false;
+                need_total = std::max(need_total, need);
+            }
+            todo.swap(again);
+            arena_cap = (size_t)std::min<unsigned long long>(std::max<unsigned long long>(need_total, 1ull << 20), kArenaMax);
+        }
+        for (int j : todo) { res->flag[(size_t)j] = 1; handed.push_back(j); } // more than kArenaMax results in one launch
+        return true;
+    };
+
+    std::vector<int> all((size_t)njobs), handed, still;
+    for (int i = 0; i < njobs; ++i) all[(size_t)i] = i;
+    const size_t guess = (size_t)((range_hint_ * 1.25 + 16.0) * (double)std::min<long long>(chunk, njobs));
+    if (!run(std::move(all), reinterpret_cast<ND *>(s_spill_), kSpillCap, max_slots(), std::min(std::max<size_t>((size_t)1 << 20, guess), kArenaMax), handed)) return false;
+    // result sets beyond a wave's list: again, with lists as long as the graph (at most 1 GB of them at a time);
+    // a visited table filling up (graphs above 4M nodes) is not helped by that and stays handed back
+    if (!handed.empty() && !vis_tab && g_n_ > kSpillCap) {
+        const size_t list_cap = (size_t)std::min<long long>(g_n_, 1 << 24);
+        const int waves = (int)std::max<size_t>(1, std::min<size_t>(handed.size(), ((size_t)1 << 27) / list_cap));
+        if (!grow_dev(&s_rlists_, &s_rlists_cap_, list_cap * (size_t)waves)) return false;
+        if (!run(handed, reinterpret_cast<ND *>(s_rlists_), (int)list_cap, waves, std::min(std::max<size_t>((size_t)1 << 20, list_cap), kArenaMax), still)) return false;
+        handed.swap(still);
+    }
+    stats_.range_handbacks += handed.size();
+    unsigned long long total = 0;
+    for (int i = 0; i < njobs; ++i) total += (unsigned long long)res->cnt[(size_t)i];
+    range_hint_ = (double)total / (double)njobs;
+    return true;
+}
+
+// float.CompareTo order on distances that are never NaN here (d <= range held)
+static inline bool range_hit_less(const SearchHit &a, const SearchHit &b) { return a.dist < b.dist; }
+
+bool Device::range_search(const float *queries, int nq, int entry_point, float range, int *out_counts, int *out_flags)
+{
+    abi_range_.clear();
+    if (nq <= 0) return true;
+    if (!out_counts || !out_flags) { set_dev_error("range_search: null argument"); return false; }
+    if (!hg_ || g_n_ <= 0) { set_dev_error("range_search: no graph committed"); return false; }
+    if (entry_point < 0 || entry_point >= hg_->n) { set_dev_error("range_search: bad argument"); return false; }
+    if (!set_queries(queries, nq)) return false;
+    std::vector<SearchJob> jobs((size_t)nq);
+    const int top = hg_->level[(size_t)entry_point];
+    for (int i = 0; i < nq; ++i) jobs[(size_t)i] = SearchJob{i, entry_point, top, 0, -1};
+    RangeResults r;
+    if (!range_batch(jobs.data(), nq, range, &r)) return false;
+    for (int i = 0; i < nq; ++i) {
+        out_counts[i] = 0;
+        out_flags[i] = r.flag[(size_t)i];
+        if (out_flags[i]) continue;
+        SearchHit *b = r.found.data() + r.off[(size_t)i], *e = b + r.cnt[(size_t)i];
+        std::sort(b, e, range_hit_less);
+        bool tie = false;
+        for (SearchHit *p = b; p + 1 < e; ++p) tie |= p[0].dist == p[1].dist; // also -0 next to +0
+        if (tie) { out_flags[i] = 1; continue; } // OrderBy keeps the heap array's order there (HNSWIndex.cs:155)
+        out_counts[i] = r.cnt[(size_t)i];
+        abi_range_.insert(abi_range_.end(), b, e);
+    }
+    return true;
+}
+
+bool Device::range_results(int *out_ids, float *out_d)
+{
+    if (abi_range_.empty()) return true;
+    if (!out_ids || !out_d) { set_dev_error("range_results: null argument"); return false; }
+    for (size_t i = 0; i < abi_range_.size(); ++i) { out_ids[i] = abi_range_[i].id; out_d[i] = abi_range_[i].dist; }
+    return true;
+}
+
 // ---- C-ABI graph staging (layer by layer) -------------------------------------------------
 bool Device::graph_begin(int n, int max_edges, const int *levels)
 {
@@ -1569,6 +1783,12 @@ DEV_API int hnswdev_knn_search(void *ctx, const float *queries, int nq, int entr
     CTX_OR_FAIL();
     return d->knn_search(queries, nq, entry_point, k_beam, k_out, out_ids, out_dists, out_flags) ? 0 : -1;
 }
+DEV_API int hnswdev_range_search(void *ctx, const float *queries, int nq, int entry_point, float range, int *out_counts, int *out_flags)
+{
+    CTX_OR_FAIL();
+    return d->range_search(queries, nq, entry_point, range, out_counts, out_flags) ? 0 : -1;
+}
+DEV_API int hnswdev_range_results(void *ctx, int *out_ids, float *out_dists) { CTX_OR_FAIL(); return d->range_results(out_ids, out_dists) ? 0 : -1; }
 DEV_API int hnswdev_sync(void *ctx) { CTX_OR_FAIL(); return d->sync() ? 0 : -1; }
 DEV_API int hnswdev_set_profiling(void *ctx, int enabled) { CTX_OR_FAIL(); d->set_profiling(enabled != 0); return 0; }
 DEV_API int hnswdev_get_stats(void *ctx, hnswdev_stats *out)

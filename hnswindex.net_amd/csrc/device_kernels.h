@@ -712,12 +712,13 @@ struct VisitedSet {
             return (atomicOr(&bits[id >> 5], bit) & bit) == 0u;
         }
         unsigned h = ((unsigned)id * 2654435761u) & tab_mask;
-        for (;;) {
+        for (unsigned probes = 0; probes <= tab_mask; ++probes) {
             const int old = atomicCAS(&tab[h], -1, id);
             if (old == -1) return true;
             if (old == id) return false;
             h = (h + 1) & tab_mask;
         }
+        return true; // table full (the host sizes it so that crowded() fires long before): the job is handed back, never stuck
     }
     __device__ __forceinline__ bool crowded() const { return HASHED && seen > limit; }
     __device__ __forceinline__ void clear(int lane)
@@ -1810,6 +1811,156 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
         V.clear(lane);
     }
 }
+
+#ifdef HNSW_HOST_TU // few variants and launched from one place: defined only in the unit that launches it
+// RangeQuery on the device: FindEntryPointQuery + GraphNavigator.SearchLayerRange (GraphNavigator.cs:262-325)
+// for one query per wave.  What the reference's two heaps compute there is a closure: a neighbour enters
+// `candidates` and `topCandidates` iff its distance is <= range (:302-308), nothing ever leaves topCandidates
+// (its root never exceeds range, :310-311), and the stop test (:286-289) can only fire for the entry point, whose
+// farthestResultDist is still MaxValue -- so every listed node and the entry point are expanded exactly once,
+// whatever the pop order, and the result SET and the evaluation count do not depend on it.  The order shows only
+// in RangeQuery's stable OrderBy over the heap array (HNSWIndex.cs:155) between results of EQUAL distance; the
+// host sorts what comes back, and for a query that holds such a pair replays the two heaps from the entry point
+// with the distances found here (no evaluation: a neighbour that is not among the results is out of range).
+// `found` (per wave, found_cap entries) is both the result list and the work queue: entry `head` is the next
+// node to expand.  Results are then copied to a launch-wide arena at an offset taken with one atomic.
+// out_flag: 0 done; 1 hand back (more than found_cap results, or the visited table filling up); 3 arena full.
+constexpr int kRangeFan = 8; // nodes expanded per step; the id / distance scratch holds kRangeFan adjacency lists
+template <int METRIC, bool HASHED>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) // at most 168 VGPRs: three waves per SIMD
+graph_range_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
+                   const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
+                   const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
+                   const SearchJob *__restrict__ jobs, float range, ND *__restrict__ found_all, int found_cap,
+                   unsigned *__restrict__ visited, long long vis_words, int *__restrict__ vis_tab, int vis_tab_cap,
+                   ND *__restrict__ arena, unsigned long long arena_cap, unsigned long long *__restrict__ arena_used,
+                   unsigned long long *__restrict__ out_off, int *__restrict__ out_cnt, int *__restrict__ out_flag,
+                   int *__restrict__ out_entry, unsigned long long *__restrict__ eval_counter, int nbcap, int njobs,
+                   int *__restrict__ job_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
+                         vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, (unsigned)(vis_tab_cap - 1), 0, vis_tab_cap / 4 * 3};
+    const SearchLds L = carve_lds(smem, 0, 0, dim, nbcap);
+    const GraphView G{adj0, stride0, upper, pool, strideU};
+    // the queue is read back through L2 (agent-scope loads): a line of it cached earlier may lack later entries
+    unsigned long long *found = reinterpret_cast<unsigned long long *>(found_all + (size_t)blockIdx.x * (size_t)found_cap);
+    int *nbuf = L.nbuf;
+    float *dbuf = L.dbuf;
+    for (;;) {
+        int job = 0;
+        if (lane == 0) job = atomicAdd(job_counter, 1);
+        job = __builtin_amdgcn_readfirstlane(job);
+        if (job >= njobs) break;
+        const SearchJob jb = jobs[job];
+        const float *q = queries + (size_t)jb.qref * dim;
+        double sb = 0.0;
+        if (METRIC == M_COS) sb = q_sn[jb.qref];
+        __syncthreads();
+        for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+        unsigned long long evals = 0;
+        int best;
+        float cur;
+        descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals); // FindEntryPointQuery; :268 reuses its distance
+        if (lane == 0) (void)V.first_visit(best);                                  // :279
+        V.seen += 1;
+        int count = 0, head = 0;
+        if (cur <= range) { // :271-275
+            if (lane == 0) found[0] = ((unsigned long long)__float_as_uint(cur) << 32) | (unsigned)best;
+            count = 1;
+        }
+        // :277 the entry point is a candidate either way; out of range it is still expanded, unless its distance
+        // exceeds farthestResultDist's initial MaxValue (+inf): then :286-289 ends the search at once
+        bool entry_pending = !(cur <= range) && !(cur > 3.402823466e+38f);
+        bool ok = true;
+        for (;;) {
+            // up to kRangeFan listed nodes are expanded per step (any order gives the same set): a large result set
+            // is a long dependent chain on one wave otherwise
+            int W, c0 = best;
+            if (entry_pending) { W = 1; entry_pending = false; }
+            else {
+                W = min(kRangeFan, count - head); // :283 no candidates left
+                if (W == 0) break;
+                unsigned long long e = 0ull;
+                if (lane < W) e = __hip_atomic_load(&found[head + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // :285, :290
+                c0 = (int)(unsigned)e;
+                head += W;
+            }
+            int n[kRangeFan], nb[kRangeFan];
+            const int *lw[kRangeFan];
+#pragma unroll
+            for (int w = 0; w < kRangeFan; ++w) {
+                lw[w] = G.list(__builtin_amdgcn_readlane(c0, w < W ? w : 0), 0);
+                n[w] = w < W ? __builtin_amdgcn_readfirstlane(lw[w][0]) : 0;
+                nb[w] = lane < n[w] ? lw[w][1 + lane] : 0;
+            }
+            bool fr[kRangeFan];
+#pragma unroll
+            for (int w = 0; w < kRangeFan; ++w) fr[w] = lane < n[w] && V.first_visit(nb[w]); // :297 / :318 (a node two lists share is fresh once)
+            int m = 0;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < kRangeFan; ++w) {
+                const unsigned long long mask = __ballot(fr[w]);
+                const int posn = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (fr[w]) nbuf[m + posn] = nb[w];
+                m += __popcll(mask);
+                for (int base = 64; base < n[w]; base += 64) { // lists beyond 64 ids (MaxEdges > 32)
+                    const int i = base + lane;
+                    bool fresh = false;
+                    int x = 0;
+                    if (i < n[w]) { x = lw[w][1 + i]; fresh = V.first_visit(x); }
+                    const unsigned long long mk = __ballot(fresh);
+                    const int pp = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+                    if (fresh) nbuf[m + pp] = x;
+                    m += __popcll(mk);
+                }
+            }
+            __syncthreads();
+            if (m == 0) continue;
+            V.seen += m;
+            if (V.crowded()) { ok = false; break; }
+            measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, nbuf, dbuf, m, lane); // :299
+            __syncthreads();
+            evals += (unsigned long long)m;
+            for (int base = 0; base < m && ok; base += 64) {
+                const int i = base + lane;
+                const float d = i < m ? dbuf[i] : 0.0f;
+                const bool in = i < m && d <= range; // :302
+                const unsigned long long mask = __ballot(in);
+                const int add = __popcll(mask);
+                if (count + add > found_cap) { ok = false; break; }
+                const int posn = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (in) found[count + posn] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)nbuf[i]; // :305, :308
+                count += add;
+            }
+            if (!ok) break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the queue entries just written are read above (through L2)
+        }
+        unsigned long long off = 0;
+        int flag = ok ? 0 : 1;
+        if (ok && count > 0) {
+            if (lane == 0) off = atomicAdd(arena_used, (unsigned long long)count);
+            off = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+            if (off + (unsigned long long)count > arena_cap) flag = 3;
+            else
+                for (int i = lane; i < count; i += 64) {
+                    const unsigned long long e = __hip_atomic_load(&found[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    arena[off + i] = ND{(int)(unsigned)e, __uint_as_float((unsigned)(e >> 32))};
+                }
+        }
+        if (lane == 0) {
+            out_off[job] = off;
+            out_cnt[job] = flag == 0 ? count : 0;
+            out_flag[job] = flag;
+            out_entry[job] = best; // FindEntryPointQuery's answer: where a host replay of the heaps starts
+            if (flag != 3) atomicAdd(eval_counter, evals); // (a job that found the arena full runs again)
+        }
+        V.clear(lane);
+    }
+}
+#endif
 
 // Insert, search half, fused: for one new item, GraphConnector.AddNewConnections' whole loop
 // (GraphConnector.cs:172-181): FindEntryPoint, then for every layer of the item ConnectAtLayer's

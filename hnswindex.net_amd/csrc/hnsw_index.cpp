@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <limits>
 #include <thread>
 #include <unordered_map>
@@ -1114,26 +1115,143 @@ int HnswIndex::knn_query_resident(int k, int *out_ids, float *out_dists, std::st
     return knn_query_lockstep(nullptr, count, k, out_ids, out_dists, err);
 }
 
+// Host lock-step range search for the queries listed in `which` (nullptr: all `count` queries).
+int HnswIndex::range_query_lockstep(const int *which, int count, float range, std::vector<std::vector<NodeDist>> &out, std::string &err)
+{
+    if (!refresh_host_lists(err)) return -1;
+    RangeSource src;
+    src.jobs.resize((size_t)count);
+    for (int i = 0; i < count; ++i) {
+        const int qi = which ? which[i] : i;
+        RangeJob &j = src.jobs[(size_t)i];
+        j.g = &graph_;
+        j.capacity = (int)capacity_;
+        j.qi = qi;
+        j.range = range;
+        j.out = &out[(size_t)qi];
+    }
+    if (!engine()->run(src, count)) { err = get_dev_error(); return -1; }
+    return 0;
+}
+
+// SearchLayerRange's two heaps (GraphNavigator.cs:262-325) replayed from `entry` with every distance already
+// known: `found` is the query's whole result set as the device kernel measured it, so a neighbour that is not in it
+// is out of range -- it would be marked visited and dropped (:302, :318) -- and needs no evaluation; the entry
+// point's own distance is never compared when it is out of range (it is alone in `candidates` when popped, and
+// farthestResultDist is still MaxValue at :286).  Result: topCandidates' array, stably sorted (HNSWIndex.cs:155).
+static void replay_range_heaps(const Graph &g, int entry, float range, const SearchHit *found, int m, std::vector<NodeDist> &out)
+{
+    size_t cap = 16;
+    while (cap < 2 * (size_t)m) cap <<= 1;
+    struct Slot { int id; float dist; bool visited; };
+    std::vector<Slot> tab(cap, Slot{-1, 0.0f, false});
+    auto slot_of = [&](int id) -> Slot * { // the slot holding id, or nullptr
+        size_t h = ((size_t)(uint32_t)id * 2654435761u) & (cap - 1);
+        while (tab[h].id != -1) {
+            if (tab[h].id == id) return &tab[h];
+            h = (h + 1) & (cap - 1);
+        }
+        return nullptr;
+    };
+    for (int i = 0; i < m; ++i) {
+        size_t h = ((size_t)(uint32_t)found[i].id * 2654435761u) & (cap - 1);
+        while (tab[h].id != -1) h = (h + 1) & (cap - 1);
+        tab[h] = Slot{found[i].id, found[i].dist, false};
+    }
+    BinaryHeap<FartherFirst> top;
+    BinaryHeap<CloserFirst> cand;
+    top.reset(g.max_edges_at(0));      // :265
+    cand.reset(g.max_edges_at(0) * 2); // :266
+    float farthest = std::numeric_limits<float>::max(); // :269
+    Slot *es = slot_of(entry);
+    NodeDist e{entry, es ? es->dist : std::numeric_limits<float>::infinity()};
+    if (es) { top.push(e); farthest = e.dist; es->visited = true; } // :271-275, :279
+    cand.push(e);                                                  // :277
+    while (cand.count > 0) {
+        const NodeDist closest = cand.peek();                                        // :285
+        if (es == nullptr && closest.id == entry) { /* :286-289 cannot fire: farthest is MaxValue */ }
+        else if (closest.dist > farthest && closest.dist > range) break;
+        cand.pop();                                                                  // :290
+        const int *l = g.list(closest.id, 0);
+        for (int i = 1; i <= l[0]; ++i) {
+            Slot *sl = slot_of(l[i]);
+            if (!sl || sl->visited) continue; // :297, or out of range (:302 fails, :318)
+            sl->visited = true;
+            NodeDist sel{sl->id, sl->dist};
+            cand.push(sel);                                   // :305
+            top.push(sel);                                    // :308
+            if (top.peek().dist > range) top.pop();           // :310-311
+            if (top.count > 0) farthest = top.peek().dist;    // :313-314
+        }
+    }
+    out.assign(top.buf.begin(), top.buf.begin() + top.count);
+    std::stable_sort(out.begin(), out.end(), [](const NodeDist &a, const NodeDist &b) { return float_compare_to(a.dist, b.dist) < 0; });
+}
+
+// Graph-resident range search (graph_range_kernel): the result SET of SearchLayerRange does not depend on the
+// order its heaps pop in; the reference's stable OrderBy (HNSWIndex.cs:155) does only between results of equal
+// distance, and for a query holding such a pair the heaps are replayed on the host from the known distances.
+int HnswIndex::range_query_device(int count, float range, std::vector<std::vector<NodeDist>> &out, std::string &err)
+{
+    if (!sync_graph(err)) return -1;
+    std::vector<SearchJob> jobs((size_t)count);
+    const int ep = graph_.entry, top = graph_.top_layer();
+    for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0, -1};
+    Device::RangeResults r;
+    if (!dev_->range_batch(jobs.data(), count, range, &r)) { err = get_dev_error(); return -1; }
+    // host threads over the queries: sort each result list; a list holding two equal distances is replayed instead
+    auto parallel_for = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)> &body) {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t lo; (lo = next.fetch_add(grain, std::memory_order_relaxed)) < n;) body(lo, std::min(n, lo + grain));
+        };
+        const int nth = (int)std::min<size_t>((size_t)std::max(1, threads_), (n + grain - 1) / grain);
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nth; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+    };
+    std::vector<unsigned char> state((size_t)count, 0); // 1: hand-back (lock-step), 2: equal distances (replay)
+    parallel_for((size_t)count, 256, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            if (r.flag[i]) { state[i] = 1; continue; }
+            SearchHit *b = r.found.data() + r.off[i], *e = b + r.cnt[i];
+            std::sort(b, e, [](const SearchHit &x, const SearchHit &y) { return x.dist < y.dist; }); // no NaN: d <= range held
+            bool tie = false;
+            for (SearchHit *p = b; p + 1 < e; ++p) tie |= p[0].dist == p[1].dist; // also -0 next to +0
+            if (tie) { state[i] = 2; continue; }
+            std::vector<NodeDist> &o = out[i];
+            o.resize((size_t)(e - b));
+            for (size_t a = 0; a < o.size(); ++a) o[a] = NodeDist{b[a].id, b[a].dist};
+        }
+    });
+    std::vector<int> redo, replay;
+    for (int i = 0; i < count; ++i) {
+        if (state[(size_t)i] == 1) redo.push_back(i);
+        else if (state[(size_t)i] == 2) replay.push_back(i);
+    }
+    if (!replay.empty()) {
+        if (!refresh_host_lists(err)) return -1; // the replay walks the host's copy of the lists
+        parallel_for(replay.size(), 1, [&](size_t lo, size_t hi) {
+            for (size_t t = lo; t < hi; ++t) {
+                const int i = replay[t];
+                replay_range_heaps(graph_, r.entry[(size_t)i], range, r.found.data() + r.off[(size_t)i], r.cnt[(size_t)i], out[(size_t)i]);
+            }
+        });
+    }
+    if (!redo.empty()) return range_query_lockstep(redo.data(), (int)redo.size(), range, out, err);
+    return 0;
+}
+
 int HnswIndex::range_query(const float *queries, int count, int dim, float range, std::vector<std::vector<NodeDist>> &out, std::string &err)
 {
     out.assign((size_t)std::max(count, 0), {});
     if (failed(err)) return -1;
     if (count <= 0 || graph_.entry < 0) return 0; // HNSWIndex.cs:146
     if (!ensure_dim(dim, err)) return -1;
-    if (!refresh_host_lists(err)) return -1;
     if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; }
-    RangeSource src;
-    src.jobs.resize((size_t)count);
-    for (int i = 0; i < count; ++i) {
-        RangeJob &j = src.jobs[(size_t)i];
-        j.g = &graph_;
-        j.capacity = (int)capacity_;
-        j.qi = i;
-        j.range = range;
-        j.out = &out[(size_t)i];
-    }
-    if (!engine()->run(src, count)) { err = get_dev_error(); return -1; }
-    return 0;
+    if (p_.device_traversal && dev_->traversal_fits(1, false, p_.max_edges)) return range_query_device(count, range, out, err);
+    return range_query_lockstep(nullptr, count, range, out, err);
 }
 
 // ---- HNSWIndex.Remove (src/HNSWIndex/HNSWIndex.cs:83-102) ------------------------------------

@@ -120,6 +120,8 @@ private:
     bool refresh_host_lists(std::string &err);
     int knn_query_device(const float *queries, int count, int k, int *out_ids, float *out_dists, std::string &err);
     int knn_query_lockstep(const int *which, int count, int k, int *out_ids, float *out_dists, std::string &err);
+    int range_query_lockstep(const int *which, int count, float range, std::vector<std::vector<NodeDist>> &out, std::string &err);
+    int range_query_device(int count, float range, std::vector<std::vector<NodeDist>> &out, std::string &err);
 
     int metric_ = 0;
     int dim_ = 0; // fixed by the first add (the reference takes it from the arrays)

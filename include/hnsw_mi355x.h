@@ -190,6 +190,10 @@ typedef struct hnswdev_stats {
     uint64_t link_launches, link_evals, link_timed_launches, link_timed_evals;
     double link_kernel_ms;
     uint64_t visited_hash_launches; /* traversal launches whose visited sets were per-wave hash tables (graphs above 4M nodes) */
+    /* graph_range_kernel (RangeQuery on the device; also part of the search_* totals) */
+    uint64_t range_launches, range_evals, range_timed_launches, range_timed_evals;
+    double range_kernel_ms;
+    uint64_t range_handbacks;       /* range traversals handed back (more results than a wave's list holds, visited table full) */
 } hnswdev_stats;
 
 /* All return 0 on success, < 0 on error (message via hnswdev_ctx_last_error / hnswdev_last_error).
@@ -266,6 +270,16 @@ int hnswdev_graph_commit(void *ctx);
  * capacity, NaN or -0 distance) -- evaluate it with hnswdev_dist_query_batch instead. */
 int hnswdev_knn_search(void *ctx, const float *queries, int nq, int entry_point, int k_beam, int k_out, int *out_ids,
                        float *out_dists, int *out_flags);
+
+/* RangeQuery for nq queries from `entry_point`: FindEntryPointQuery + SearchLayerRange at layer 0
+ * (HNSWIndex.cs:144-156, GraphNavigator.cs:262-325), no filter.  out_counts[i] = results of query i, kept in the
+ * context until the next range search and copied out by hnswdev_range_results: concatenated in query order, each
+ * query's results ascending by distance (out_ids / out_dists hold sum(out_counts) entries).  out_flags[i] = 1:
+ * handed back (count 0) -- the query holds two results of EQUAL distance, whose order in the reference depends on
+ * its heap layout, or more results than the device path keeps per query (8192): evaluate it with
+ * hnswdev_dist_query_batch instead. */
+int hnswdev_range_search(void *ctx, const float *queries, int nq, int entry_point, float range, int *out_counts, int *out_flags);
+int hnswdev_range_results(void *ctx, int *out_ids, float *out_dists);
 
 int hnswdev_sync(void *ctx);
 int hnswdev_set_profiling(void *ctx, int enabled);

@@ -307,6 +307,54 @@ def test_range_query_matches_oracle(Index, metric, radius):
         assert a.tolist() == c.tolist() and b.tobytes() == d.tobytes()
 
 
+@pytest.mark.parametrize("metric", ["sq_euclid", "sq_euclid_i8"])
+def test_range_query_runs_on_the_device_and_hands_back_what_it_must(Index, metric, monkeypatch):
+    # graph_range_kernel answers RangeQuery.  Results of equal distance (their order is the reference's heap layout)
+    # are put in order by replaying the heaps on the host; a visited table that fills up goes to the lock-step path
+    n, dim = 12000, 16
+    x = uniform(n, dim, 171)
+    x[500:560] = x[100:160]                      # exact duplicates: equal distances in the same result
+    q = np.concatenate([x[100:130], uniform(170, dim, 172)])
+    ix = Index(dim, metric); ix.set_collection_size(n); ix.set_insert_batch(1024)
+    ix.add(x)
+    ref = oracle.OracleIndex(dim, metric, collection_size=n); ref.add_batched(x, 1024)
+    assert ix.graph_hash() == ref.graph_hash()
+
+    def same(radius, qq):
+        a_ids, a_d = ix.range_query(qq, radius)
+        for lo in range(0, len(qq), 1000):       # the oracle's result buffers are dense: keep them small
+            b_ids, b_d = ref.range_query(qq[lo:lo + 1000], radius, cap=n if len(qq) < 100 else 6000)
+            for a, b, c, d in zip(a_ids[lo:lo + 1000], a_d[lo:lo + 1000], b_ids, b_d):
+                assert a.tolist() == c.tolist() and b.tobytes() == d.tobytes()
+        same.tied = sum(int(len(b) > 1 and (np.diff(b) == 0).any()) for b in a_d)
+        return sum(len(a) for a in a_ids)
+
+    ix.reset_stats()
+    assert same(0.9, q) > 200
+    st = ix.stats()
+    assert st["range_launches"] >= 1 and st["range_handbacks"] == 0
+    assert same.tied >= 10                       # a duplicated row and its twin, both within reach of the first 30 queries
+    same(0.0, q[:40])                            # at most the query's own row and its twin
+    assert same(-1.0, q[:40]) == 0               # nothing within reach, the entry point included
+    # a launch-wide arena too small for everything: the unfinished queries run once more in one of the right size
+    qs = uniform(8000, dim, 173)
+    ix.reset_stats()
+    total = same(1.2 if metric == "sq_euclid" else 1.25, qs)
+    assert total > (1 << 20) and ix.stats()["range_launches"] == 2 and ix.stats()["range_handbacks"] == 0
+    ix.reset_stats()
+    assert same(1e30, q[:3]) == 3 * n            # the whole graph: beyond a wave's list, run again with lists as long as the graph
+    assert ix.stats()["range_launches"] >= 2 and ix.stats()["range_handbacks"] == 0
+    # per-wave visited hash tables (graphs above 4M nodes), forced here
+    monkeypatch.setenv("HNSW_MI355X_VIS_HASH", "1")
+    ix.reset_stats()
+    assert same(0.9, q) > 200
+    assert ix.stats()["visited_hash_launches"] >= 1 and ix.stats()["range_handbacks"] == 0
+    monkeypatch.setenv("HNSW_MI355X_VIS_HASH_CAP", "64")   # (raised to 4096:) 3072 visited ids, then the traversal is handed back
+    ix.reset_stats()
+    assert same(1.3, q) > 10000
+    assert 0 < ix.stats()["range_handbacks"] < len(q)
+
+
 def test_shapes_beyond_the_device_kernels_fall_back_to_host_traversal(Index):
     # MaxEdges > 63 and beam widths beyond the LDS budget are served by the lock-step path --
     # same results, no error
