@@ -232,7 +232,8 @@ private:
     int num_cu_ = 256;
     // Persistent launches never use more than 16 one-wave blocks per CU (the traversal kernels need
     // >= 128 VGPRs): the per-wave scratch (visited bitsets, spill areas, logs) is sized for that.
-    int max_slots() const { return num_cu_ * 16; }
+    int max_slots() const { return num_cu_ * max_waves_per_cu(); }
+    static int max_waves_per_cu(); // persistent waves per CU the per-wave scratch is sized for
     SearchJob *s_jobs_ = nullptr;
     SearchHit *s_hits_ = nullptr;
     int *s_cnt_ = nullptr, *s_flag_ = nullptr;

@@ -669,6 +669,14 @@ static int sorted_top_sets(int k)
 }
 constexpr long long kSortedTopMaxNodes = 1LL << 30; // the sorted list keeps two mark bits in the id word
 
+int Device::max_waves_per_cu()
+{
+    // 20 = five per SIMD: what the int8 kernels' 92 VGPRs allow (10M x 96 int8, 12 500-query calls: 2.19 M queries/s at
+    // 16, 2.31 M at 20); the float kernels (168 VGPRs) keep 12 resident whatever this says
+    static const int v = [] { const char *e = std::getenv("HNSW_MI355X_MAX_WAVES_PER_CU"); return e ? std::max(1, std::min(32, std::atoi(e))) : 20; }();
+    return v;
+}
+
 // Blocks (= waves) of a persistent traversal launch: what stays resident on the chip.
 template <class K>
 static int resident_blocks(K kernel, size_t lds, int num_cu)
