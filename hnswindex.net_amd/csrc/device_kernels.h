@@ -980,7 +980,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         bool have = false;     // this lane holds an unvisited neighbour
         float lane_d = 0.0f;
         int lane_id = 0;
-        const bool overlapped = overlap && n <= 64 && !HASHED;
+        const bool overlapped = overlap && n <= 64;
         if (overlapped) {
             // Latency-bound launch (fewer jobs than resident waves): the rows of ALL listed neighbours
             // are fetched together with the visited atomics instead of after them -- one dependent
@@ -991,7 +991,11 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             __syncthreads();
             unsigned old = 0u;
             const unsigned bit = 1u << (nb_a & 31);
-            if (in) old = atomicOr(&V.bits[nb_a >> 5], bit); // :181, in flight with the row loads below
+            unsigned hpos = 0u;
+            if constexpr (HASHED) { // first probe of the id table; a collision is followed up after the rows
+                hpos = ((unsigned)nb_a * 2654435761u) & V.tab_mask;
+                if (in) old = (unsigned)atomicCAS(&V.tab[hpos], -1, nb_a);
+            } else if (in) old = atomicOr(&V.bits[nb_a >> 5], bit); // :181, in flight with the row loads below
             pre_id = -1;
             {
                 const int nxt = T.first_open(top_n, lane);
@@ -1006,9 +1010,21 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             }
             if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
             __syncthreads();
-            have = in && (old & bit) == 0u;
+            if constexpr (HASHED) {
+                have = in && (int)old == -1;
+                if (in && (int)old != -1 && (int)old != nb_a) { // slot taken by another id: probe on (VisitedSet::first_visit)
+                    for (unsigned probes = 0; probes <= V.tab_mask; ++probes) {
+                        hpos = (hpos + 1) & V.tab_mask;
+                        const int o2 = atomicCAS(&V.tab[hpos], -1, nb_a);
+                        if (o2 == -1) { have = true; break; }
+                        if (o2 == nb_a) break;
+                    }
+                }
+            } else have = in && (old & bit) == 0u;
             const unsigned long long mask = __ballot(have);
             m = __popcll(mask);
+            V.seen += m;
+            if (V.crowded()) { hash_full = true; break; }
             lane_d = in ? dbuf[lane] : 0.0f;
             lane_id = nb_a;
             PH(4);
@@ -1787,7 +1803,8 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
 // whole launch and leaves the bitset clean after every job, so the scratch is sized by the
 // resident waves (not by the batch) and nothing is memset between launches.
 template <int METRIC, int NS, bool HASHED>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS <= 4 ? 3 : 2))) // 168 VGPRs: three waves per SIMD
+// float rows: 168 VGPRs, three waves per SIMD; int8 records keep 16 registers of rows in flight, not 64: five waves
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(METRIC == M_I8 ? (NS <= 2 ? 5 : 4) : (NS <= 4 ? 3 : 2))))
 graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
