@@ -903,6 +903,60 @@ struct SortedTop {
         }
         if (count < k) ++count;
     }
+    // Several insertions at once: the candidates of the lanes in `pass` (my_key, my_id; at least one).  What `insert`
+    // called once per candidate in lane order leaves behind is the k smallest of the union -- a candidate that a
+    // tighter farthest distance would have turned away ends beyond position k here and drops just the same -- with
+    // a new entry before old entries of equal key and a later lane's before an earlier lane's.  So the final
+    // position of every entry follows from counting: an old entry moves up by the new keys <= its own, a new one
+    // lands at (old keys < its own) + (new ones that go before it).  The entries are scattered to `lds`
+    // (k + 1 slots: ids with their mark bits, keys) at those positions and read back: one compare per register set
+    // and candidate instead of insert's shift of the whole list.
+    // boundary_tie: entries were dropped and the first one dropped has the key of the last one kept (the
+    // reference's list may hold that twin instead: the caller marks the survivors DOUBTFUL, rule (i)).
+    __device__ __forceinline__ void merge(unsigned long long pass, unsigned my_key, int my_id, int &count, int k, int lane,
+                                          uint2 *lds, unsigned &last_key, bool &boundary_tie)
+    {
+        int shift[NS];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) shift[t] = 0;
+        int rank_old = 0, rank_new = 0;
+        for (unsigned long long mm = pass; mm; mm &= mm - 1) {
+            const int src = __builtin_ctzll(mm);
+            const unsigned xk = (unsigned)__builtin_amdgcn_readlane((int)my_key, src);
+            int r = 0;
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                if (64 * t >= count) break;
+                const bool have = lane + 64 * t < count;
+                const bool lt = have && key[t] < xk;
+                r += (int)__popcll(__ballot(lt));
+                shift[t] += (have && !lt) ? 1 : 0;
+            }
+            if (lane == src) rank_old = r;
+            rank_new += (xk < my_key || (xk == my_key && src > lane)) ? 1 : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int p = lane + 64 * t;
+            if (p < count && p + shift[t] <= k) lds[p + shift[t]] = make_uint2((unsigned)id[t], key[t]);
+        }
+        if ((pass >> lane) & 1ull) {
+            const int np = rank_old + rank_new;
+            if (np <= k) lds[np] = make_uint2((unsigned)my_id, my_key);
+        }
+        __syncthreads();
+        const int total = count + (int)__popcll(pass);
+        count = min(k, total);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int p = lane + 64 * t;
+            if (p < count) { const uint2 e = lds[p]; id[t] = (int)e.x; key[t] = e.y; }
+        }
+        last_key = lds[count - 1].y;
+        boundary_tie = total > k && lds[k].y == last_key;
+        __syncthreads();
+    }
     // any p in [1, upto) with key[p] == key[p - 1]?  (uniform result)
     __device__ __forceinline__ bool adjacent_equal(int upto, int lane) const
     {
@@ -1074,6 +1128,18 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             const unsigned my_key = f2key(my_d);
             if (__ballot(valid && key_unsafe(my_d))) { unsafe = true; break; }
             unsigned long long maybe = __ballot(valid && (top_n < k || my_key < far_key));
+#ifndef HNSW_NO_BATCH_MERGE
+            if (maybe & (maybe - 1)) { // two or more: one counting merge instead of as many list shifts
+                unsigned last = 0u;
+                bool boundary_tie = false;
+                T.merge(maybe, my_key, my_id, top_n, k, lane, reinterpret_cast<uint2 *>(L.top), last, boundary_tie);
+                if (top_n == k) {
+                    if (boundary_tie) T.mark_key(last, top_n, lane, kDoubt); // (i)
+                    far_key = last;                                          // :176-177
+                }
+                maybe = 0ull;
+            }
+#endif
             while (maybe) {
                 const int src = __builtin_ctzll(maybe);
                 maybe &= maybe - 1;
