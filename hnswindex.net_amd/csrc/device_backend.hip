@@ -45,6 +45,7 @@
 #include "device_backend.h"
 #define HNSW_HOST_TU
 #include "device_kernels.h"
+#include "range_replay.h"
 
 namespace hnsw {
 
@@ -1537,8 +1538,14 @@ bool Device::range_search(const float *queries, int nq, int entry_point, float r
         std::sort(b, e, range_hit_less);
         bool tie = false;
         for (SearchHit *p = b; p + 1 < e; ++p) tie |= p[0].dist == p[1].dist; // also -0 next to +0
-        if (tie) { out_flags[i] = 1; continue; } // OrderBy keeps the heap array's order there (HNSWIndex.cs:155)
         out_counts[i] = r.cnt[(size_t)i];
+        if (tie) { // OrderBy keeps the heap array's order there (HNSWIndex.cs:155): replay the heaps on the committed graph
+            std::vector<NodeDist> ordered;
+            replay_range_heaps([&](int id) { return hg_->adj0.data() + (size_t)id * (size_t)hg_->stride0; }, 2 * hg_->M, r.entry[(size_t)i], range, b,
+                               r.cnt[(size_t)i], ordered);
+            for (const NodeDist &nd : ordered) abi_range_.push_back(SearchHit{nd.id, nd.dist});
+            continue;
+        }
         abi_range_.insert(abi_range_.end(), b, e);
     }
     return true;

@@ -274,10 +274,10 @@ int hnswdev_knn_search(void *ctx, const float *queries, int nq, int entry_point,
 /* RangeQuery for nq queries from `entry_point`: FindEntryPointQuery + SearchLayerRange at layer 0
  * (HNSWIndex.cs:144-156, GraphNavigator.cs:262-325), no filter.  out_counts[i] = results of query i, kept in the
  * context until the next range search and copied out by hnswdev_range_results: concatenated in query order, each
- * query's results ascending by distance (out_ids / out_dists hold sum(out_counts) entries).  out_flags[i] = 1:
- * handed back (count 0) -- the query holds two results of EQUAL distance, whose order in the reference depends on
- * its heap layout, or more results than the device path keeps per query (8192): evaluate it with
- * hnswdev_dist_query_batch instead. */
+ * query's results in RangeQuery's order -- ascending by distance, results of EQUAL distance in the order of the
+ * reference's heap array (replayed on the committed graph) -- out_ids / out_dists hold sum(out_counts) entries.
+ * out_flags[i] = 1: handed back (count 0; on graphs above 4M nodes, a traversal that outgrows its visited table):
+ * evaluate it with hnswdev_dist_query_batch instead. */
 int hnswdev_range_search(void *ctx, const float *queries, int nq, int entry_point, float range, int *out_counts, int *out_flags);
 int hnswdev_range_results(void *ctx, int *out_ids, float *out_dists);
 

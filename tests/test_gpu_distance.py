@@ -231,13 +231,10 @@ def test_knn_search_on_a_host_supplied_graph(net, metric):
     radius = {"sq_euclid": 6.5, "cosine": 0.16, "ucosine": 0.16}[metric]
     rids, rd, rflags = dev.range_search(q, ref.entry_point, radius)
     want_rids, want_rd = ref.range_query(q, radius)
-    # (a query whose results hold two equal distances is handed back: 1 - dot rounds many pairs together)
-    assert rflags.sum() <= len(q) // 10 and sum(len(a) for a in rids) > 100
-    for a, b, c, e, f in zip(rids, rd, want_rids, want_rd, rflags):
-        if f:
-            assert len(a) == 0 and (np.diff(e) == 0).any()
-        else:
-            assert a.tolist() == c.tolist() and b.tobytes() == e.tobytes()
+    # (results of equal distance -- 1 - dot rounds many pairs together -- come in the order of the reference's heap array)
+    assert (rflags == 0).all() and sum(len(a) for a in rids) > 100
+    for a, b, c, e in zip(rids, rd, want_rids, want_rd):
+        assert a.tolist() == c.tolist() and b.tobytes() == e.tobytes()
     st = dev.stats()
     assert st["range_launches"] == 1 and st["range_handbacks"] == 0
     with pytest.raises(RuntimeError, match="bad argument"):
