@@ -11,6 +11,7 @@
 
 #include "../../include/hnsw_mi355x.h"
 #include "hnsw_index.h"
+#include "range_replay.h"
 #include "snapshot_io.h"
 
 using hnsw::HnswIndex;
@@ -418,6 +419,19 @@ API void hnswhost_test_sort(int *ids, float *dists, int n)
     for (int i = 0; i < n; ++i) k[(size_t)i] = hnsw::NodeDist{ids[i], dists[i]};
     hnsw::dotnet_sort(k.data(), n);
     for (int i = 0; i < n; ++i) { ids[i] = k[(size_t)i].id; dists[i] = k[(size_t)i].dist; }
+}
+// RangeQuery's order among equal distances (range_replay.h) on a graph handed in as layer-0 lists [count, ids...]
+// of `stride` ints per node: `found` = the query's result set in ANY order; out_ids = the reference's order.
+API int hnswhost_test_range_replay(const int *adj0, int stride, int max_edges0, int entry, float range, const int *found_ids, const float *found_d,
+                                   int m, int *out_ids, float *out_d)
+{
+    struct Hit { int id; float dist; };
+    std::vector<Hit> found((size_t)m);
+    for (int i = 0; i < m; ++i) found[(size_t)i] = Hit{found_ids[i], found_d[i]};
+    std::vector<hnsw::NodeDist> out;
+    hnsw::replay_range_heaps([&](int id) { return adj0 + (size_t)id * (size_t)stride; }, max_edges0, entry, range, found.data(), m, out);
+    for (size_t i = 0; i < out.size(); ++i) { out_ids[i] = out[i].id; out_d[i] = out[i].dist; }
+    return (int)out.size();
 }
 API int hnswhost_test_heap_script(int closer_first, const int *ops, const float *d, int n, int *out_ids, float *out_d, int *popped_ids, int *n_popped)
 {

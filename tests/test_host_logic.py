@@ -102,3 +102,40 @@ def test_next_single_redraws_a_sample_that_rounds_to_one(lib):
     for seed in (31337, 65537, 12345):
         assert oracle.dotnet_random_next(seed, 200000).max() < edge + 1
 
+
+
+def test_range_replay_orders_equal_distances_like_the_reference(lib):
+    # RangeQuery on the device returns each query's result SET; where two results have the same distance the order
+    # of the reference's stable OrderBy over its heap array (HNSWIndex.cs:155) is recovered by replaying the two
+    # heaps of SearchLayerRange on the distances already known (csrc/range_replay.h).  Here: the oracle's result,
+    # shuffled, must come back in the oracle's order -- on integer-grid data, where most distances tie.
+    lib.hnswhost_test_range_replay.argtypes = [I, ct.c_int, ct.c_int, ct.c_int, ct.c_float, I, F, ct.c_int, I, F]
+    rng = np.random.default_rng(77)
+    n, dim, M = 1500, 6, 8
+    x = rng.integers(0, 3, (n, dim)).astype(np.float32)          # 729 distinct points: duplicates and ties everywhere
+    ref = oracle.OracleIndex(dim, "sq_euclid", max_edges=M, max_candidates=40, collection_size=n)
+    ref.add(x)
+    stride = 2 * M + 2
+    adj = np.zeros((n, stride), dtype=np.int32)
+    for i in range(n):
+        e = ref.edges(i, 0)
+        adj[i, 0] = e.size
+        adj[i, 1:1 + e.size] = e
+    q = rng.integers(0, 3, (120, dim)).astype(np.float32) + np.float32(0.25)
+    tied = 0
+    for radius in (0.9, 2.0, 3.5):
+        want_ids, want_d = ref.range_query(q, radius)
+        for qi in range(q.shape[0]):
+            ids, d = want_ids[qi], want_d[qi]
+            if ids.size == 0:
+                continue
+            tied += int((np.diff(d) == 0).any())
+            perm = rng.permutation(ids.size)
+            f_ids, f_d = np.ascontiguousarray(ids[perm]), np.ascontiguousarray(d[perm])
+            out_ids, out_d = np.empty(ids.size, np.int32), np.empty(ids.size, np.float32)
+            entry = ref.find_entry_point(0, q[qi])
+            m = lib.hnswhost_test_range_replay(adj.ctypes.data_as(I), stride, 2 * M, entry, radius, f_ids.ctypes.data_as(I),
+                                               f_d.ctypes.data_as(F), ids.size, out_ids.ctypes.data_as(I), out_d.ctypes.data_as(F))
+            assert m == ids.size
+            assert out_ids.tolist() == ids.tolist() and out_d.tobytes() == d.tobytes()
+    assert tied > 100
