@@ -107,7 +107,16 @@ public:
     // Runs njobs KnnQuery traversals with beam width k and returns the first k_out results of
     // the stable distance order (padded with -1 / NaN); out_flag: 1 where the candidate heap
     // outgrew LDS + spill capacity (caller re-runs that job on the lock-step path).  Synchronous.
-    bool search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag);
+    bool search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag = false);
+    // Remove, second half, for the `n` affected nodes of one (removed node, layer) step (graph_relink_kernel): per node
+    // the new neighbour selection out_sel[i * sel_stride ..][0 .. out_cnt[i]); out_flag[i] = 1: this node's answer
+    // depends on the heap-array order of the candidates (the caller repeats the step on the lock-step path).
+    // Reads the HBM graph mirror; writes nothing to it.  Synchronous.
+    bool relink_batch(const int *affected, int n, int layer, int removed, const int *cands, int ncand, int max_edges, int *out_sel,
+                      int *out_cnt, int *out_flag, int sel_stride);
+    // Overwrites adjacency lists of the mirror: records [node, layer, count, ids...] of `row_stride` ints; the lists are
+    // marked as NOT being a heuristic's ordered output (the link kernel's tested-prefix shortcut starts from 0).
+    bool patch_lists(const int *recs, int nrows, int row_stride);
     // Insert, search half, fused on the device: for every job (new item) the descent from
     // (entry, entry_layer) to search_layer = the item's first layer, then on every layer from there
     // down to 0 the traversal with beam k (= MaxCandidates) + RelativeNeighborPruning, the next
@@ -243,6 +252,8 @@ private:
     size_t s_sel_cap_ = 0, s_lcnt_cap_ = 0, s_selU_cap_ = 0, s_cntU_cap_ = 0, s_iflag_cap_ = 0;
     void *h_res_ = nullptr; // pinned: results of insert_search_batch
     size_t h_res_cap_ = 0;
+    int *s_rl_ = nullptr; // relink / patch staging on the device
+    size_t s_rl_cap_ = 0;
     int *s_order_ = nullptr; // insert search: processing order of a batch's jobs
     size_t s_order_cap_ = 0;
     SearchHit *s_spill_ = nullptr;

@@ -195,7 +195,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -1243,7 +1243,7 @@ void *Device::pinned_stage(size_t bytes)
 // KnnQuery on the device: descent + layer-0 beam search (width k) + the stable top-k_out tail.
 // out_ids / out_d: njobs x k_out, final (padded with -1 / NaN); out_flag: 1 = not run to
 // completion (candidate heap beyond LDS + spill), caller re-runs that job on the lock-step path.
-bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag)
+bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag)
 {
     if (njobs <= 0) return true;
     if (!jobs || !out_ids || !out_d || !out_flag || k < 1 || k_out < 1) { set_dev_error("search_batch: bad argument"); return false; }
@@ -1322,7 +1322,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         memcpy(out_ids + (size_t)off * k_out, h_ids, 4u * (size_t)nj * k_out);
         memcpy(out_d + (size_t)off * k_out, h_d, 4u * (size_t)nj * k_out);
         for (int i = 0; i < nj; ++i) {
-            if (h_flag[i] == 2) { stats_.search_repeats++; h_flag[i] = 0; }
+            if (h_flag[i] == 2) { stats_.search_repeats++; if (!keep_repeat_flag) h_flag[i] = 0; }
         }
         memcpy(out_flag + off, h_flag, sizeof(int) * (size_t)nj);
         const unsigned long long ev = *h_ev;
@@ -1337,7 +1337,88 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
             stats_.search_timed_evals += ev;
         }
     }
-    for (int i = 0; i < njobs; ++i) stats_.search_overflows += (uint64_t)(out_flag[i] != 0);
+    for (int i = 0; i < njobs; ++i) stats_.search_overflows += (uint64_t)(out_flag[i] == 1);
+    return true;
+}
+
+bool Device::relink_batch(const int *affected, int n, int layer, int removed, const int *cands, int ncand, int max_edges, int *out_sel,
+                          int *out_cnt, int *out_flag, int sel_stride)
+{
+    if (n <= 0) return true;
+    if (!affected || !out_sel || !out_cnt || !out_flag || ncand < 0 || (ncand > 0 && !cands) || layer < 0 || max_edges < 1 || sel_stride < max_edges) {
+        set_dev_error("relink_batch: bad argument");
+        return false;
+    }
+    if (g_n_ <= 0) { set_dev_error("relink_batch: no graph uploaded"); return false; }
+    if (removed < 0 || removed >= g_n_) { set_dev_error("relink_batch: node outside the graph"); return false; }
+    for (int i = 0; i < n; ++i)
+        if (affected[i] < 0 || affected[i] >= g_n_ || affected[i] >= n_rows_hw_) { set_dev_error("relink_batch: node outside the graph / rows"); return false; }
+    for (int i = 0; i < ncand; ++i)
+        if (cands[i] < 0 || cands[i] >= g_n_ || cands[i] >= n_rows_hw_) { set_dev_error("relink_batch: candidate outside the graph / rows"); return false; }
+    const int list_max = (layer == 0 ? g_stride0_ : g_strideU_) - 2;
+    const int kcap = list_max + ncand + 1, nb = (kcap + 7) & ~7;
+    const size_t lds = search_lds_bytes(kcap, 0, pitch_, true, nb);
+    if (lds > 64 * 1024) { set_dev_error("relink_batch: candidate count / dimension exceed the LDS budget"); return false; }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    if (!ensure_search_scratch(1, 1, 0, 16)) return false;
+    // device staging: [affected | cands | sel | cnt | flag]
+    const size_t o_c = (size_t)n, o_s = o_c + (size_t)std::max(ncand, 1), o_n = o_s + (size_t)n * sel_stride, o_f = o_n + (size_t)n, total = o_f + (size_t)n;
+    if (!grow_dev(&s_rl_, &s_rl_cap_, total)) return false;
+    int *hs = static_cast<int *>(pinned_stage(sizeof(int) * total + 16));
+    if (!hs) return false;
+    memcpy(hs, affected, sizeof(int) * (size_t)n);
+    if (ncand > 0) memcpy(hs + o_c, cands, sizeof(int) * (size_t)ncand);
+    HIP_OK(hipMemcpyAsync(s_rl_, hs, sizeof(int) * o_s, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
+#define LAUNCH_RL(M)                                                                                                                  \
+    hipLaunchKernelGGL(graph_relink_kernel<M>, dim3(n), dim3(64), lds, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, g_upper_,   \
+                       g_pool_, g_strideU_, s_rl_, layer, removed, s_rl_ + o_c, ncand, max_edges, kcap, nb, s_rl_ + o_s, s_rl_ + o_n,  \
+                       s_rl_ + o_f, sel_stride, s_evals_)
+    if (metric_ == M_SQ) LAUNCH_RL(M_SQ);
+    else if (metric_ == M_COS) LAUNCH_RL(M_COS);
+    else if (metric_ == M_I8) LAUNCH_RL(M_I8);
+    else LAUNCH_RL(M_UCOS);
+#undef LAUNCH_RL
+    HIP_OK(hipGetLastError());
+    unsigned long long *h_ev = reinterpret_cast<unsigned long long *>(hs + ((total + 1) & ~(size_t)1));
+    HIP_OK(hipMemcpyAsync(hs + o_s, s_rl_ + o_s, sizeof(int) * (total - o_s), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    memcpy(out_sel, hs + o_s, sizeof(int) * (size_t)n * sel_stride);
+    memcpy(out_cnt, hs + o_n, sizeof(int) * (size_t)n);
+    memcpy(out_flag, hs + o_f, sizeof(int) * (size_t)n);
+    stats_.search_evals += *h_ev;
+    return true;
+}
+
+bool Device::patch_lists(const int *recs, int nrows, int row_stride)
+{
+    if (nrows <= 0) return true;
+    if (!recs || row_stride < 4) { set_dev_error("patch_lists: bad argument"); return false; }
+    if (g_n_ <= 0) { set_dev_error("patch_lists: no graph uploaded"); return false; }
+    std::vector<int> tagged(recs, recs + (size_t)nrows * row_stride);
+    for (int r = 0; r < nrows; ++r) { // a bad record must be an error return, never a GPU fault
+        int *x = tagged.data() + (size_t)r * row_stride;
+        const int cap = (x[1] == 0 ? g_stride0_ : g_strideU_) - 2;
+        bool ok = x[0] >= 0 && x[0] < g_n_ && x[1] >= 0 && x[1] < 0x4000 && x[2] >= 0 && x[2] <= row_stride - 3 && x[2] <= cap &&
+                  (x[1] == 0 || (hg_ ? hg_->level[(size_t)x[0]] >= x[1] : true));
+        for (int i = 0; ok && i < x[2]; ++i) ok = x[3 + i] >= 0 && x[3 + i] < g_n_;
+        if (!ok) { set_dev_error("patch_lists: record outside the graph"); return false; }
+        x[1] |= 1 << 30; // not a heuristic's ordered output
+    }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    const size_t total = (size_t)nrows * row_stride;
+    if (!grow_dev(&s_rl_, &s_rl_cap_, total)) return false;
+    int *hs = static_cast<int *>(pinned_stage(sizeof(int) * total));
+    if (!hs) return false;
+    memcpy(hs, tagged.data(), sizeof(int) * total);
+    HIP_OK(hipMemcpyAsync(s_rl_, hs, sizeof(int) * total, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(graph_write_rows_kernel, dim3(nrows), dim3(64), 0, st, g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_rl_, row_stride,
+                       g_tested0_, g_testedU_, g_stride0_ - 2);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(st)); // the staging buffers are reused
     return true;
 }
 

@@ -2164,6 +2164,85 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
 }
 
 // Insert, link half, on the HBM mirror.  (a) new nodes' own lists.
+#ifdef HNSW_HOST_TU // launched from one place: defined only in the unit that launches it
+// Remove, second half (GraphConnector.RemoveConnectionsAtLayer :100-133): one wave per AFFECTED node (an in-edge
+// neighbour of the removed node): drop the edge to the removed node (EdgeList.Remove: the last entry takes its
+// place), candidates = the remaining neighbours followed by the search candidates that are neither the node itself
+// nor among them (:115-129), Distance(candidate, node) for all of them, RelativeNeighborPruning (:131).  Nothing
+// is written to the graph: the selection goes back to the host, which applies the difference (:135-164).
+// `cands` arrive ascending by distance to the removed node, not in the reference's heap-array order; that order
+// shows only if the heuristic returns its input unsorted (fewer candidates than MaxEdges) or sorts equal distances:
+// both raise out_flag and the host repeats the step on the exact lock-step path.
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+graph_relink_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, const int *__restrict__ adj0, int stride0,
+                    const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU, const int *__restrict__ affected,
+                    int layer, int removed, const int *__restrict__ cands, int ncand, int max_edges, int kcap, int nbcap,
+                    int *__restrict__ out_sel, int *__restrict__ out_cnt, int *__restrict__ out_flag, int sel_stride,
+                    unsigned long long *__restrict__ eval_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x, job = blockIdx.x;
+    const SearchLds L = carve_lds(smem, kcap, 0, dim, nbcap);
+    const GraphView G{adj0, stride0, upper, pool, strideU};
+    const int aid = affected[job];
+    const float *q = rows + (size_t)aid * dim;
+    double sb = 0.0;
+    if (METRIC == M_COS) sb = row_sn[aid];
+    for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+    const int *l = G.list(aid, layer);
+    int cnt = l[0];
+    // RemoveOutEdge :104 (EdgeList.Remove, Node.cs:79-93: swap with the last)
+    int pos = -1;
+    for (int base = 0; base < cnt && pos < 0; base += 64) {
+        const unsigned long long hit = __ballot(base + lane < cnt && l[1 + base + lane] == removed);
+        if (hit) pos = base + (int)__builtin_ctzll(hit);
+    }
+    const int last = cnt - 1;
+    if (pos >= 0) --cnt;
+    for (int i = lane; i < cnt; i += 64) L.nbuf[i] = (i == pos) ? l[1 + last] : l[1 + i]; // :110-120 the existing neighbours
+    __syncthreads();
+    int n = cnt;
+    bool bad = false;
+    for (int base = 0; base < ncand; base += 64) { // :123-129
+        const int i = base + lane;
+        const int c = i < ncand ? cands[i] : -1;
+        bool keep = i < ncand && c != aid;
+        for (int t = 0; keep && t < cnt; ++t) keep = L.nbuf[t] != c;
+        const unsigned long long mask = __ballot(keep);
+        const int posn = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+        if (n + (int)__popcll(mask) > min(kcap, nbcap)) { bad = true; break; }
+        if (keep) L.nbuf[n + posn] = c;
+        n += (int)__popcll(mask);
+    }
+    __syncthreads();
+    unsigned long long evals = 0;
+    int rc = 0;
+    if (!bad && n < max_edges) bad = true; // Heuristic.cs:13-18 returns the INPUT order: the heap array's
+    if (!bad && n > 0) {
+        measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, L.nbuf, L.dbuf, n, lane); // Distance(id, affectedNodeId) :118, :128
+        __syncthreads();
+        evals += (unsigned long long)n;
+        for (int i = lane; i < n; i += 64) L.top[i] = ND{L.nbuf[i], L.dbuf[i]};
+        __syncthreads();
+        rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, n, max_edges, L, lane, evals); // sorts L.top
+        __syncthreads();
+        bool odd = false; // equal, NaN or -0 distances: Span.Sort's answer depends on the input order
+        for (int i = lane; i < n; i += 64) {
+            const float d = L.top[i].dist;
+            odd |= key_unsafe(d) || (i + 1 < n && f2key(L.top[i + 1].dist) == f2key(d));
+        }
+        if (__ballot(odd) != 0ull) bad = true;
+    }
+    if (!bad) for (int i = lane; i < rc; i += 64) out_sel[(size_t)job * sel_stride + i] = L.acc[i];
+    if (lane == 0) {
+        out_cnt[job] = bad ? 0 : rc;
+        out_flag[job] = bad ? 1 : 0;
+        atomicAdd(eval_counter, evals);
+    }
+}
+#endif
+
 #ifdef HNSW_HOST_TU // non-template kernels: only the unit that launches them defines them
 __global__ void __launch_bounds__(64)
 graph_write_rows_kernel(int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool,
@@ -2171,7 +2250,8 @@ graph_write_rows_kernel(int *__restrict__ adj0, int stride0, const int64_t *__re
                         int *__restrict__ testedU, int max_edges0)
 {
     const int *r = recs + (size_t)blockIdx.x * row_stride;
-    const int node = r[0], layer = r[1], cnt = r[2];
+    const int node = r[0], layer = r[1] & 0xffff, cnt = r[2];
+    const bool untested = (r[1] >> 30) & 1; // the list is not a heuristic's ordered output (a removal's re-link)
     int *l = layer == 0 ? adj0 + (size_t)node * stride0 : pool + upper[node] + (size_t)(layer - 1) * strideU;
     if (threadIdx.x == 0) {
         l[0] = cnt;
@@ -2179,7 +2259,7 @@ graph_write_rows_kernel(int *__restrict__ adj0, int stride0, const int64_t *__re
         // than MaxEdges come back unsorted, Heuristic.cs:13-18): its entries are mutually tested
         const int me = layer == 0 ? max_edges0 : (max_edges0 >> 1);
         int *t = layer == 0 ? tested0 + node : testedU + (upper[node] / strideU + (layer - 1));
-        *t = cnt == me ? cnt : 0;
+        *t = (cnt == me && !untested) ? cnt : 0;
     }
     for (int i = threadIdx.x; i < cnt; i += 64) l[1 + i] = r[3 + i];
 }

@@ -491,12 +491,16 @@ struct AffectedJob : Job {
         for (int i = 1; i <= l[0]; ++i)
             if (l[i] == x) { int last = l[0]--; if (i != last) l[i] = l[last]; return; }
     }
+    void gather() // RemoveOutEdge + the existing neighbours
+    {
+        int *l = g->list(aid, layer);
+        swap_remove(l, removed); // RemoveOutEdge :104
+        old_ids.assign(l + 1, l + 1 + l[0]); // :110-111
+    }
     bool prepare(SlotIO &io, SlotScratch &) override
     {
         if (stage == 0) {
-            int *l = g->list(aid, layer);
-            swap_remove(l, removed); // RemoveOutEdge :104
-            old_ids.assign(l + 1, l + 1 + l[0]); // :110-111
+            gather();
             cands.clear();
             for (int id : old_ids) cands.push_back(NodeDist{id, 0.f}); // :115-120
             for (const NodeDist &c : *sc_cands) { // :123-129
@@ -530,9 +534,9 @@ struct AffectedJob : Job {
             prune.consume(io);
         }
     }
-    void finish()
+    void finish() { apply(prune.acc); }
+    void apply(const std::vector<int> &nw) // the new selection against the old list (:135-164)
     {
-        const std::vector<int> &nw = prune.acc;
         int *l = g->list(aid, layer);
         for (int o : old_ids) { // :135-143
             if (has(nw, o)) continue;
@@ -1236,7 +1240,11 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
         auto it = std::find(v.begin(), v.end(), x);
         if (it != v.end()) { *it = v.back(); v.pop_back(); }
     };
-    graph_dirty_ = true;
+    // With device traversal the HBM mirror is brought up to date once and then kept in step list by list
+    // (Device::patch_lists); otherwise it is rebuilt from the host lists on the next call that needs it.
+    const bool on_device = p_.device_traversal && dim_ <= 2048 && dev_->traversal_fits(p_.remove_max_candidates + 1, false, p_.max_edges);
+    if (on_device) { if (!sync_graph(err)) return -1; }
+    else graph_dirty_ = true;
     for (int t = 0; t < count; ++t) {
         const int id = ids[t];
         g.removed[(size_t)id] = 1; // item.IsRemoved = true, GraphConnector.cs:55-57
@@ -1267,23 +1275,71 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
             const int *rl = g.list(id, layer);
             for (int e = 1; e <= rl[0]; ++e) erase_from(in_of(rl[e], layer), id); // DetachOutgoingReferences :277-288
             const std::vector<int> affected = in_of(id, layer);                   // :95
-            VecSource<RemoveSearchJob> ssrc;
-            ssrc.jobs.resize(1);
-            RemoveSearchJob &sj = ssrc.jobs[0];
-            sj.g = &g; sj.capacity = (int)capacity_; sj.removed = id; sj.layer = layer; sj.k = p_.remove_max_candidates;
-            if (!engine()->run(ssrc, 1)) { err = get_dev_error(); return -1; }
-            if (!affected.empty()) {
-                VecSource<AffectedJob> asrc;
-                asrc.jobs.resize(affected.size());
+            VecSource<AffectedJob> asrc;
+            asrc.jobs.resize(affected.size());
+            for (size_t a = 0; a < affected.size(); ++a) {
+                AffectedJob &aj = asrc.jobs[a];
+                aj.g = &g; aj.aid = affected[a]; aj.layer = layer; aj.removed = id;
+            }
+            // Graph-resident form: the search is one traversal on the device and the affected nodes are re-linked by
+            // one launch (graph_relink_kernel); whatever depends on the heap-array order of the candidates (equal
+            // distances, fewer candidates than MaxEdges) is repeated below on the exact lock-step path.
+            bool done = false;
+            if (on_device && !affected.empty()) {
+                const int k = p_.remove_max_candidates;
+                // SearchLayer(removed, layer, k, its own vector, id != removed) (:96): the entry point is a candidate
+                // but not a result, so the sorted list holds it as one extra entry: k + 1 slots, the closest is itself
+                SearchJob sjob{~id, id, layer, layer, -1};
+                std::vector<int> sid((size_t)k + 1), sflag(1);
+                std::vector<float> sd((size_t)k + 1);
+                if (!dev_->search_batch(&sjob, 1, k + 1, k + 1, sid.data(), sd.data(), sflag.data(), true)) { err = get_dev_error(); return -1; }
+                std::vector<int> cids;
+                bool self_seen = false;
+                for (int i = 0; i <= k && sid[(size_t)i] >= 0; ++i) {
+                    if (sid[(size_t)i] == id) self_seen = true;
+                    else cids.push_back(sid[(size_t)i]);
+                }
+                if (sflag[0] == 0 && self_seen) {
+                    const int me = g.max_edges_at(layer), n = (int)affected.size();
+                    std::vector<int> sel((size_t)n * (size_t)me), scnt((size_t)n), sfl((size_t)n);
+                    if (!dev_->relink_batch(affected.data(), n, layer, id, cids.data(), (int)cids.size(), me, sel.data(), scnt.data(), sfl.data(), me)) {
+                        err = get_dev_error();
+                        return -1;
+                    }
+                    done = std::all_of(sfl.begin(), sfl.end(), [](int f) { return f == 0; });
+                    if (done)
+                        for (int a = 0; a < n; ++a) {
+                            AffectedJob &aj = asrc.jobs[(size_t)a];
+                            aj.gather();
+                            aj.apply(std::vector<int>(sel.begin() + (size_t)a * me, sel.begin() + (size_t)a * me + scnt[(size_t)a]));
+                        }
+                }
+            }
+            if (!done) {
+                VecSource<RemoveSearchJob> ssrc;
+                ssrc.jobs.resize(1);
+                RemoveSearchJob &sj = ssrc.jobs[0];
+                sj.g = &g; sj.capacity = (int)capacity_; sj.removed = id; sj.layer = layer; sj.k = p_.remove_max_candidates;
+                if (!engine()->run(ssrc, 1)) { err = get_dev_error(); return -1; }
+                if (!affected.empty()) {
+                    for (AffectedJob &aj : asrc.jobs) aj.sc_cands = &sj.result;
+                    if (!engine()->run(asrc, (long long)affected.size())) { err = get_dev_error(); return -1; }
+                }
+            }
+            for (AffectedJob &aj : asrc.jobs) {
+                for (int o : aj.in_remove) erase_from(in_of(o, layer), aj.aid);
+                for (int w : aj.in_add) in_of(w, layer).push_back(aj.aid);
+            }
+            if (on_device && !affected.empty()) { // the re-linked lists, into the HBM mirror
+                const int stride = (layer == 0 ? g.stride0 : g.strideU) + 1;
+                std::vector<int> recs(affected.size() * (size_t)stride, 0);
                 for (size_t a = 0; a < affected.size(); ++a) {
-                    AffectedJob &aj = asrc.jobs[a];
-                    aj.g = &g; aj.aid = affected[a]; aj.layer = layer; aj.removed = id; aj.sc_cands = &sj.result;
+                    const int *l = g.list(affected[a], layer);
+                    int *r = recs.data() + a * (size_t)stride;
+                    r[0] = affected[a]; r[1] = layer; r[2] = l[0];
+                    for (int e = 0; e < l[0]; ++e) r[3 + e] = l[1 + e];
                 }
-                if (!engine()->run(asrc, (long long)affected.size())) { err = get_dev_error(); return -1; }
-                for (AffectedJob &aj : asrc.jobs) {
-                    for (int o : aj.in_remove) erase_from(in_of(o, layer), aj.aid);
-                    for (int w : aj.in_add) in_of(w, layer).push_back(aj.aid);
-                }
+                if (!dev_->patch_lists(recs.data(), (int)affected.size(), stride)) { err = get_dev_error(); return -1; }
             }
             in_of(id, layer).clear();
             if (layer == 0) g.retire(id); // GraphData.RemoveItem :124-128

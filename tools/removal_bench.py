@@ -1,0 +1,37 @@
+"""Removal throughput (hnsw_remove, ids in order) against the CPU restatement, same index and ids.
+usage: python tools/removal_bench.py [n] [nremove]"""
+import sys, time, json
+import numpy as np
+sys.path.insert(0, ".")
+from hnswindex import Index
+import oracle
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+m = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+dim = 128
+x = np.random.default_rng(65537).random((n, dim), dtype=np.float32)
+ids = np.random.default_rng(1).permutation(n)[:m].astype(np.int32)
+out = {"n": n, "removed": m}
+hashes = {}
+for mode in ("device", "host"):
+    ix = Index(dim); ix.set_collection_size(n); ix.set_max_candidates(200); ix.set_min_nn(128)
+    ix.set_device_traversal(mode == "device")
+    if mode == "host":
+        ix.set_insert_batch(65536)
+    ix.add(x)
+    ix.remove(ids[:50])                      # warm (graph fetch, kernels)
+    t0 = time.perf_counter(); ix.remove(ids[50:]); dt = time.perf_counter() - t0
+    out[mode] = {"removals_per_sec": round((m - 50) / dt, 1)}
+    hashes[mode] = ix.graph_hash()
+    if mode == "device":
+        q = np.random.default_rng(7).random((2000, dim), dtype=np.float32)
+        got = ix.knn_query(q, 10)
+ref = oracle.OracleIndex(dim, "sq_euclid", max_candidates=200, min_nn=128, collection_size=n)
+ref.add_batched(x, 65536, threads=16)
+ref.remove(ids[:50])
+t0 = time.perf_counter(); ref.remove(ids[50:]); dt = time.perf_counter() - t0
+out["cpu_one_thread"] = {"removals_per_sec": round((m - 50) / dt, 1)}
+want = ref.knn_query(q, 10)
+out["graph_hash_equal"] = bool(hashes["device"] == ref.graph_hash() and hashes["host"] == ref.graph_hash())
+out["queries_after_removal_equal"] = bool((got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes())
+print(json.dumps(out))
