@@ -107,13 +107,17 @@ public:
     // Runs njobs KnnQuery traversals with beam width k and returns the first k_out results of
     // the stable distance order (padded with -1 / NaN); out_flag: 1 where the candidate heap
     // outgrew LDS + spill capacity (caller re-runs that job on the lock-step path).  Synchronous.
-    bool search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag = false);
+    // two_heap: the exact two-heap traversal for every job (jobs with aux == -2: the entry point is filtered out of the
+    // results and the output is the result heap's ARRAY, the removal search's return value)
+    bool search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag = false,
+                      bool two_heap = false);
     // Remove, second half, for the `n` affected nodes of one (removed node, layer) step (graph_relink_kernel): per node
     // the new neighbour selection out_sel[i * sel_stride ..][0 .. out_cnt[i]); out_flag[i] = 1: this node's answer
     // depends on the heap-array order of the candidates (the caller repeats the step on the lock-step path).
     // Reads the HBM graph mirror; writes nothing to it.  Synchronous.
+    // heap_order: `cands` are in the reference's heap-array order (search_batch with two_heap): nothing is flagged.
     bool relink_batch(const int *affected, int n, int layer, int removed, const int *cands, int ncand, int max_edges, int *out_sel,
-                      int *out_cnt, int *out_flag, int sel_stride);
+                      int *out_cnt, int *out_flag, int sel_stride, bool heap_order = false);
     // Overwrites adjacency lists of the mirror: records [node, layer, count, ids...] of `row_stride` ints; the lists are
     // marked as NOT being a heuristic's ordered output (the link kernel's tested-prefix shortcut starts from 0).
     bool patch_lists(const int *recs, int nrows, int row_stride);

@@ -1243,7 +1243,8 @@ void *Device::pinned_stage(size_t bytes)
 // KnnQuery on the device: descent + layer-0 beam search (width k) + the stable top-k_out tail.
 // out_ids / out_d: njobs x k_out, final (padded with -1 / NaN); out_flag: 1 = not run to
 // completion (candidate heap beyond LDS + spill), caller re-runs that job on the lock-step path.
-bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag)
+bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag,
+                          bool two_heap)
 {
     if (njobs <= 0) return true;
     if (!jobs || !out_ids || !out_d || !out_flag || k < 1 || k_out < 1) { set_dev_error("search_batch: bad argument"); return false; }
@@ -1252,7 +1253,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     const int cand_cap = cand_lds_cap(k, pitch_, false, nbcap());
     const size_t lds = search_lds_bytes(k, cand_cap, pitch_, false, nbcap());
     if (lds > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
-    const int ns = g_n_ < kSortedTopMaxNodes ? sorted_top_sets(k) : 0;
+    const int ns = (g_n_ < kSortedTopMaxNodes && !two_heap) ? sorted_top_sets(k) : 0;
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     long long vis_words = ((g_n_ + 31) / 32 + 3) & ~3LL;
@@ -1342,7 +1343,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
 }
 
 bool Device::relink_batch(const int *affected, int n, int layer, int removed, const int *cands, int ncand, int max_edges, int *out_sel,
-                          int *out_cnt, int *out_flag, int sel_stride)
+                          int *out_cnt, int *out_flag, int sel_stride, bool heap_order)
 {
     if (n <= 0) return true;
     if (!affected || !out_sel || !out_cnt || !out_flag || ncand < 0 || (ncand > 0 && !cands) || layer < 0 || max_edges < 1 || sel_stride < max_edges) {
@@ -1374,7 +1375,7 @@ bool Device::relink_batch(const int *affected, int n, int layer, int removed, co
 #define LAUNCH_RL(M)                                                                                                                  \
     hipLaunchKernelGGL(graph_relink_kernel<M>, dim3(n), dim3(64), lds, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, g_upper_,   \
                        g_pool_, g_strideU_, s_rl_, layer, removed, s_rl_ + o_c, ncand, max_edges, kcap, nb, s_rl_ + o_s, s_rl_ + o_n,  \
-                       s_rl_ + o_f, sel_stride, s_evals_)
+                       s_rl_ + o_f, sel_stride, s_evals_, heap_order ? 1 : 0)
     if (metric_ == M_SQ) LAUNCH_RL(M_SQ);
     else if (metric_ == M_COS) LAUNCH_RL(M_COS);
     else if (metric_ == M_I8) LAUNCH_RL(M_I8);

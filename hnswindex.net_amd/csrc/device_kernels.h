@@ -1222,14 +1222,17 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
     best = __builtin_amdgcn_readfirstlane(best);
     cur = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cur)));
     if (key_unsafe(cur)) overflow = true;
+    // jb.aux == -2 (removal's search, GraphConnector.cs:96): the filter id != entry keeps the entry point out of the
+    // results (:132-136) -- it is a candidate only, and farthestResultDist starts at MaxValue
+    const bool entry_filtered = jb.aux == -2;
     {
         HEnt e{best, f2key(cur)};
-        heap_push<false>(top, top_n, e); // :134
+        if (!entry_filtered) heap_push<false>(top, top_n, e); // :134
         heap_push<true>(cand, cand_n, e); // :138
         if (lane == 0) (void)V.first_visit(best);                       // :140
             V.seen += 1;
     }
-    unsigned far_key = f2key(cur); // farthestResultDist :135
+    unsigned far_key = entry_filtered ? 0xffffffffu : f2key(cur); // farthestResultDist :135
     // Speculative prefetch of the NEXT expansion's out-edge list: while the current candidate
     // rows are in flight, lanes 0..stride fetch the list of the heap's current root.  If that
     // node is indeed popped next (it is, unless this expansion pushes something closer) its list
@@ -1797,6 +1800,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
     int top_n = 0;
     bool repeated = false;
     if constexpr (NS > 0) {
+        if (jb.aux != -2) {
         bool tie = false;
         // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
         const bool ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap);
@@ -1820,8 +1824,23 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         evals = 0;
         top_n = 0;
         repeated = true;
+        }
     }
     const bool ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
+    if (jb.aux == -2) { // SearchLayer's own return value: topCandidates.ToArray(), the heap's array (BinaryHeap.cs:41-44)
+        __syncthreads();
+        for (int r = lane; r < k_out; r += 64) {
+            const bool have = ok && r < top_n;
+            out_ids[(size_t)job * k_out + r] = have ? L.top[r].id : -1;
+            out_d[(size_t)job * k_out + r] = have ? L.top[r].dist : __uint_as_float(0x7fc00000u);
+        }
+        if (lane == 0) {
+            out_cnt[job] = ok ? top_n : 0;
+            out_flag[job] = ok ? 0 : 1;
+            atomicAdd(eval_counter, evals);
+        }
+        return;
+    }
     // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(c => c.Dist) is a STABLE sort over the heap
     // array (ToArray(), BinaryHeap.cs:41-44) and only the first k_out survive -- so select the
     // k_out smallest (float.CompareTo order: NaN first, -0 == +0) with ties broken by array index:
@@ -2179,7 +2198,7 @@ graph_relink_kernel(const float *__restrict__ rows, const double *__restrict__ r
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU, const int *__restrict__ affected,
                     int layer, int removed, const int *__restrict__ cands, int ncand, int max_edges, int kcap, int nbcap,
                     int *__restrict__ out_sel, int *__restrict__ out_cnt, int *__restrict__ out_flag, int sel_stride,
-                    unsigned long long *__restrict__ eval_counter)
+                    unsigned long long *__restrict__ eval_counter, int heap_order)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, job = blockIdx.x;
@@ -2218,7 +2237,10 @@ graph_relink_kernel(const float *__restrict__ rows, const double *__restrict__ r
     __syncthreads();
     unsigned long long evals = 0;
     int rc = 0;
-    if (!bad && n < max_edges) bad = true; // Heuristic.cs:13-18 returns the INPUT order: the heap array's
+    // heap_order: `cands` are SearchLayer's heap array itself (the exact two-heap search), so the candidate array is
+    // the reference's, element for element, and nothing below depends on anything else
+    if (!bad && !heap_order && n < max_edges) bad = true; // Heuristic.cs:13-18 returns the INPUT order: the heap array's
+    if (!bad && n == 0) rc = 0;
     if (!bad && n > 0) {
         measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, L.nbuf, L.dbuf, n, lane); // Distance(id, affectedNodeId) :118, :128
         __syncthreads();
@@ -2232,7 +2254,7 @@ graph_relink_kernel(const float *__restrict__ rows, const double *__restrict__ r
             const float d = L.top[i].dist;
             odd |= key_unsafe(d) || (i + 1 < n && f2key(L.top[i + 1].dist) == f2key(d));
         }
-        if (__ballot(odd) != 0ull) bad = true;
+        if (!heap_order && __ballot(odd) != 0ull) bad = true;
     }
     if (!bad) for (int i = lane; i < rc; i += 64) out_sel[(size_t)job * sel_stride + i] = L.acc[i];
     if (lane == 0) {

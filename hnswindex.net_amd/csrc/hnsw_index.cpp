@@ -1286,34 +1286,51 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
             // distances, fewer candidates than MaxEdges) is repeated below on the exact lock-step path.
             bool done = false;
             if (on_device && !affected.empty()) {
-                const int k = p_.remove_max_candidates;
-                // SearchLayer(removed, layer, k, its own vector, id != removed) (:96): the entry point is a candidate
-                // but not a result, so the sorted list holds it as one extra entry: k + 1 slots, the closest is itself
-                SearchJob sjob{~id, id, layer, layer, -1};
-                std::vector<int> sid((size_t)k + 1), sflag(1);
+                const int k = p_.remove_max_candidates, me = g.max_edges_at(layer), n = (int)affected.size();
+                std::vector<int> sid((size_t)k + 1), sflag(1), cids, sel((size_t)n * (size_t)me), scnt((size_t)n), sfl((size_t)n);
                 std::vector<float> sd((size_t)k + 1);
+                auto relink = [&](bool heap_order) -> int { // 1 applied, 0 flagged, -1 error
+                    if (!dev_->relink_batch(affected.data(), n, layer, id, cids.data(), (int)cids.size(), me, sel.data(), scnt.data(), sfl.data(), me, heap_order)) {
+                        err = get_dev_error();
+                        return -1;
+                    }
+                    if (!std::all_of(sfl.begin(), sfl.end(), [](int f) { return f == 0; })) return 0;
+                    for (int a = 0; a < n; ++a) {
+                        AffectedJob &aj = asrc.jobs[(size_t)a];
+                        aj.gather();
+                        aj.apply(std::vector<int>(sel.begin() + (size_t)a * me, sel.begin() + (size_t)a * me + scnt[(size_t)a]));
+                    }
+                    return 1;
+                };
+                // (1) SearchLayer(removed, layer, k, its own vector, id != removed) (:96) on the sorted-list traversal: the
+                // entry point is a candidate but not a result, so the list holds it as one extra entry (k + 1 slots, its own
+                // distance keeps it in front).  Candidates come out ascending: fine unless something below is flagged.
+                SearchJob sjob{~id, id, layer, layer, -1};
                 if (!dev_->search_batch(&sjob, 1, k + 1, k + 1, sid.data(), sd.data(), sflag.data(), true)) { err = get_dev_error(); return -1; }
-                std::vector<int> cids;
                 bool self_seen = false;
                 for (int i = 0; i <= k && sid[(size_t)i] >= 0; ++i) {
                     if (sid[(size_t)i] == id) self_seen = true;
                     else cids.push_back(sid[(size_t)i]);
                 }
+                int r = 0;
                 if (sflag[0] == 0 && self_seen) {
-                    const int me = g.max_edges_at(layer), n = (int)affected.size();
-                    std::vector<int> sel((size_t)n * (size_t)me), scnt((size_t)n), sfl((size_t)n);
-                    if (!dev_->relink_batch(affected.data(), n, layer, id, cids.data(), (int)cids.size(), me, sel.data(), scnt.data(), sfl.data(), me)) {
-                        err = get_dev_error();
-                        return -1;
-                    }
-                    done = std::all_of(sfl.begin(), sfl.end(), [](int f) { return f == 0; });
-                    if (done)
-                        for (int a = 0; a < n; ++a) {
-                            AffectedJob &aj = asrc.jobs[(size_t)a];
-                            aj.gather();
-                            aj.apply(std::vector<int>(sel.begin() + (size_t)a * me, sel.begin() + (size_t)a * me + scnt[(size_t)a]));
-                        }
+                    r = relink(false);
+                    if (r < 0) return -1;
                 }
+                // (2) equal distances somewhere, or fewer candidates than MaxEdges: the same step with the exact two-heap
+                // search, whose result array IS topCandidates.ToArray() -- the candidate arrays are then the reference's
+                // element for element and Span.Sort's answer follows
+                if (r == 0) {
+                    sjob.aux = -2;
+                    if (!dev_->search_batch(&sjob, 1, k, k, sid.data(), sd.data(), sflag.data(), true, true)) { err = get_dev_error(); return -1; }
+                    if (sflag[0] == 0) {
+                        cids.clear();
+                        for (int i = 0; i < k && sid[(size_t)i] >= 0; ++i) cids.push_back(sid[(size_t)i]);
+                        r = relink(true);
+                        if (r < 0) return -1;
+                    }
+                }
+                done = r == 1;
             }
             if (!done) {
                 VecSource<RemoveSearchJob> ssrc;
