@@ -934,6 +934,7 @@ bool HnswIndex::insert_batch(const std::vector<int> &bid, std::string &err)
 int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::string &err)
 {
     if (failed(err)) return -1;
+    in_valid_ = false;
     if (!ensure_dim(dim, err)) return -1;
     Tick t_total(g_pt.add_total);
     double t_nodes0 = g_pt.on ? now_s() : 0;
@@ -1224,18 +1225,23 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
     }
     Graph &g = graph_;
     // in-edge sets: layer 0 by node, upper layers by (node, layer)
-    std::vector<std::vector<int>> in0((size_t)g.length);
-    std::unordered_map<uint64_t, std::vector<int>> inU;
+    std::vector<std::vector<int>> &in0 = in0_;
+    std::unordered_map<uint64_t, std::vector<int>> &inU = inU_;
     auto in_of = [&](int node, int layer) -> std::vector<int> & {
         return layer == 0 ? in0[(size_t)node] : inU[((uint64_t)(uint32_t)node << 8) | (uint64_t)(uint32_t)layer];
     };
-    for (int a = 0; a < g.count; ++a) {
-        const int i = g.dense[(size_t)a];
-        for (int layer = 0; layer <= g.level[(size_t)i]; ++layer) {
-            const int *l = g.list(i, layer);
-            for (int e = 1; e <= l[0]; ++e) in_of(l[e], layer).push_back(i);
+    if (!in_valid_ || in0.size() != (size_t)g.length) { // (an Add, an import or a load since the last removal)
+        in0.assign((size_t)g.length, {});
+        inU.clear();
+        for (int a = 0; a < g.count; ++a) {
+            const int i = g.dense[(size_t)a];
+            for (int layer = 0; layer <= g.level[(size_t)i]; ++layer) {
+                const int *l = g.list(i, layer);
+                for (int e = 1; e <= l[0]; ++e) in_of(l[e], layer).push_back(i);
+            }
         }
     }
+    in_valid_ = false; // until this call has gone through: an error return leaves the sets half updated
     auto erase_from = [](std::vector<int> &v, int x) {
         auto it = std::find(v.begin(), v.end(), x);
         if (it != v.end()) { *it = v.back(); v.pop_back(); }
@@ -1362,6 +1368,7 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
             if (layer == 0) g.retire(id); // GraphData.RemoveItem :124-128
         }
     }
+    in_valid_ = true;
     return 0;
 }
 
@@ -1435,6 +1442,7 @@ HnswIndex *HnswIndex::deserialize(int metric, const Params &backend, const char 
 int HnswIndex::import_nodes(const float *rows, int n, int dim, const int *levels, int entry_point, std::string &err)
 {
     if (failed(err)) return -1;
+    in_valid_ = false;
     if (!rows || !levels || n <= 0 || dim <= 0) { err = "System.ArgumentException: hnsw_mi355x_import_nodes: bad argument"; return -1; }
     if (graph_.length != 0) { err = "System.InvalidOperationException: hnsw_mi355x_import_nodes: the index already holds items"; return -1; }
     if (entry_point < 0 || entry_point >= n) { err = "System.ArgumentException: hnsw_mi355x_import_nodes: entry point outside the nodes"; return -1; }
@@ -1455,6 +1463,7 @@ int HnswIndex::import_nodes(const float *rows, int n, int dim, const int *levels
 int HnswIndex::import_edges(int layer, const int *counts, const int *edges, int stride, std::string &err)
 {
     if (failed(err)) return -1;
+    in_valid_ = false;
     if (!counts || !edges || layer < 0 || stride < 1) { err = "System.ArgumentException: hnsw_mi355x_import_edges: bad argument"; return -1; }
     if (graph_.length <= 0) { err = "System.InvalidOperationException: hnsw_mi355x_import_edges: call hnsw_mi355x_import_nodes first"; return -1; }
     if (!refresh_host_lists(err)) return -1;

@@ -5,6 +5,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "device_backend.h"
@@ -139,6 +140,11 @@ private:
     bool profiling_ = false;
     int resident_queries_ = 0;
     bool graph_dirty_ = true;       // HBM mirror needs a full re-upload
+    // in-edge sets for Remove (content only, see remove()): built by transposing the out-lists on the first removal
+    // after anything else changed the graph, kept current by the removals themselves
+    std::vector<std::vector<int>> in0_;
+    std::unordered_map<uint64_t, std::vector<int>> inU_;
+    bool in_valid_ = false;
     bool host_lists_stale_ = false; // the HBM mirror holds newer neighbour lists than graph_ (device-linked Add)
     long long dev_pool_len_ = 0;    // pool ints already mirrored
     std::vector<int> grp_of_node0_; // link half: group index per layer-0 neighbour (-1 = none)
