@@ -76,7 +76,7 @@ lib.hnsw_free_results.restype = None
 lib.hnsw_free_results.argtypes = [ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_p), ct.c_int]
 for _name in ("hnsw_set_collection_size", "hnsw_set_max_edges", "hnsw_set_max_candidates",
               "hnsw_set_remove_max_candidates", "hnsw_set_random_seed", "hnsw_set_min_nn",
-              "hnsw_mi355x_set_device", "hnsw_mi355x_set_insert_batch", "hnsw_mi355x_set_search_slots",
+              "hnsw_mi355x_set_device", "hnsw_mi355x_set_insert_batch", "hnsw_mi355x_set_remove_batch", "hnsw_mi355x_set_search_slots",
               "hnsw_mi355x_set_host_threads", "hnsw_mi355x_set_device_traversal"):
     getattr(lib, _name).restype = ct.c_int
     getattr(lib, _name).argtypes = [ct.c_int]
@@ -246,6 +246,10 @@ class Index:
     def set_insert_batch(self, max_batch: int):
         """1 = strictly sequential inserts (the reference's HNSWIndex.Add(item) semantics)."""
         self._check(lib.hnsw_mi355x_set_insert_batch(max_batch))
+
+    def set_remove_batch(self, max_batch: int):
+        """1 (default): remove() takes the ids one after the other; B > 1: removals with disjoint neighbourhoods together."""
+        self._check(lib.hnsw_mi355x_set_remove_batch(max_batch))
 
     def set_search_slots(self, slots: int):
         self._check(lib.hnsw_mi355x_set_search_slots(slots))

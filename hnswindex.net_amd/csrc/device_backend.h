@@ -116,8 +116,11 @@ public:
     // depends on the heap-array order of the candidates (the caller repeats the step on the lock-step path).
     // Reads the HBM graph mirror; writes nothing to it.  Synchronous.
     // heap_order: `cands` are in the reference's heap-array order (search_batch with two_heap): nothing is flagged.
-    bool relink_batch(const int *affected, int n, int layer, int removed, const int *cands, int ncand, int max_edges, int *out_sel,
-                      int *out_cnt, int *out_flag, int sel_stride, bool heap_order = false);
+    // Jobs i < n: affected[i] at layer[i], un-linking removed[i], with the search candidates of step[i]:
+    // cands[cand_off[s] ..][0 .. cand_cnt[s]) for the nsteps (removed node, layer) steps.  max_edges0 = MaxEdges(0).
+    bool relink_batch(const int *affected, const int *layer, const int *removed, const int *step, int n, const int *cands, const int *cand_off,
+                      const int *cand_cnt, int nsteps, int max_edges0, int *out_sel, int *out_cnt, int *out_flag, int sel_stride,
+                      bool heap_order = false);
     // Overwrites adjacency lists of the mirror: records [node, layer, count, ids...] of `row_stride` ints; the lists are
     // marked as NOT being a heuristic's ordered output (the link kernel's tested-prefix shortcut starts from 0).
     bool patch_lists(const int *recs, int nrows, int row_stride);

@@ -1342,40 +1342,53 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     return true;
 }
 
-bool Device::relink_batch(const int *affected, int n, int layer, int removed, const int *cands, int ncand, int max_edges, int *out_sel,
-                          int *out_cnt, int *out_flag, int sel_stride, bool heap_order)
+bool Device::relink_batch(const int *affected, const int *layer, const int *removed, const int *step, int n, const int *cands, const int *cand_off,
+                          const int *cand_cnt, int nsteps, int max_edges0, int *out_sel, int *out_cnt, int *out_flag, int sel_stride, bool heap_order)
 {
     if (n <= 0) return true;
-    if (!affected || !out_sel || !out_cnt || !out_flag || ncand < 0 || (ncand > 0 && !cands) || layer < 0 || max_edges < 1 || sel_stride < max_edges) {
+    if (!affected || !layer || !removed || !step || !cand_off || !cand_cnt || !out_sel || !out_cnt || !out_flag || nsteps < 1 || max_edges0 < 2 ||
+        sel_stride < max_edges0) {
         set_dev_error("relink_batch: bad argument");
         return false;
     }
     if (g_n_ <= 0) { set_dev_error("relink_batch: no graph uploaded"); return false; }
-    if (removed < 0 || removed >= g_n_) { set_dev_error("relink_batch: node outside the graph"); return false; }
-    for (int i = 0; i < n; ++i)
-        if (affected[i] < 0 || affected[i] >= g_n_ || affected[i] >= n_rows_hw_) { set_dev_error("relink_batch: node outside the graph / rows"); return false; }
-    for (int i = 0; i < ncand; ++i)
+    int total_c = 0, max_c = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        if (cand_cnt[s] < 0 || cand_off[s] != total_c) { set_dev_error("relink_batch: candidate ranges must be packed in step order"); return false; }
+        total_c += cand_cnt[s];
+        max_c = std::max(max_c, cand_cnt[s]);
+    }
+    if (total_c > 0 && !cands) { set_dev_error("relink_batch: bad argument"); return false; }
+    for (int i = 0; i < total_c; ++i)
         if (cands[i] < 0 || cands[i] >= g_n_ || cands[i] >= n_rows_hw_) { set_dev_error("relink_batch: candidate outside the graph / rows"); return false; }
-    const int list_max = (layer == 0 ? g_stride0_ : g_strideU_) - 2;
-    const int kcap = list_max + ncand + 1, nb = (kcap + 7) & ~7;
+    for (int i = 0; i < n; ++i)
+        if (affected[i] < 0 || affected[i] >= g_n_ || affected[i] >= n_rows_hw_ || removed[i] < 0 || removed[i] >= g_n_ || layer[i] < 0 || layer[i] > 200 ||
+            step[i] < 0 || step[i] >= nsteps) {
+            set_dev_error("relink_batch: job outside the graph / rows");
+            return false;
+        }
+    const int kcap = (g_stride0_ - 2) + max_c + 1, nb = (kcap + 7) & ~7;
     const size_t lds = search_lds_bytes(kcap, 0, pitch_, true, nb);
     if (lds > 64 * 1024) { set_dev_error("relink_batch: candidate count / dimension exceed the LDS budget"); return false; }
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     if (!ensure_search_scratch(1, 1, 0, 16)) return false;
-    // device staging: [affected | cands | sel | cnt | flag]
-    const size_t o_c = (size_t)n, o_s = o_c + (size_t)std::max(ncand, 1), o_n = o_s + (size_t)n * sel_stride, o_f = o_n + (size_t)n, total = o_f + (size_t)n;
-    if (!grow_dev(&s_rl_, &s_rl_cap_, total)) return false;
+    // device staging: [jobs (4 n) | cand_off | cand_cnt | cands | sel | cnt | flag]
+    const size_t o_off = 4u * (size_t)n, o_cnt = o_off + (size_t)nsteps, o_c = o_cnt + (size_t)nsteps, o_s = o_c + (size_t)std::max(total_c, 1),
+                 o_n = o_s + (size_t)n * sel_stride, o_f = o_n + (size_t)n, total = o_f + (size_t)n;
+    if (!grow_dev(&s_rl_, &s_rl_cap_, total + 4)) return false; // (+4: the int4 view of the jobs starts aligned, hipMalloc is)
     int *hs = static_cast<int *>(pinned_stage(sizeof(int) * total + 16));
     if (!hs) return false;
-    memcpy(hs, affected, sizeof(int) * (size_t)n);
-    if (ncand > 0) memcpy(hs + o_c, cands, sizeof(int) * (size_t)ncand);
+    for (int i = 0; i < n; ++i) { hs[4 * i] = affected[i]; hs[4 * i + 1] = layer[i]; hs[4 * i + 2] = removed[i]; hs[4 * i + 3] = step[i]; }
+    memcpy(hs + o_off, cand_off, sizeof(int) * (size_t)nsteps);
+    memcpy(hs + o_cnt, cand_cnt, sizeof(int) * (size_t)nsteps);
+    if (total_c > 0) memcpy(hs + o_c, cands, sizeof(int) * (size_t)total_c);
     HIP_OK(hipMemcpyAsync(s_rl_, hs, sizeof(int) * o_s, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
 #define LAUNCH_RL(M)                                                                                                                  \
     hipLaunchKernelGGL(graph_relink_kernel<M>, dim3(n), dim3(64), lds, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, g_upper_,   \
-                       g_pool_, g_strideU_, s_rl_, layer, removed, s_rl_ + o_c, ncand, max_edges, kcap, nb, s_rl_ + o_s, s_rl_ + o_n,  \
-                       s_rl_ + o_f, sel_stride, s_evals_, heap_order ? 1 : 0)
+                       g_pool_, g_strideU_, reinterpret_cast<const int4 *>(s_rl_), s_rl_ + o_c, s_rl_ + o_off, s_rl_ + o_cnt, max_edges0,  \
+                       kcap, nb, s_rl_ + o_s, s_rl_ + o_n, s_rl_ + o_f, sel_stride, s_evals_, heap_order ? 1 : 0)
     if (metric_ == M_SQ) LAUNCH_RL(M_SQ);
     else if (metric_ == M_COS) LAUNCH_RL(M_COS);
     else if (metric_ == M_I8) LAUNCH_RL(M_I8);

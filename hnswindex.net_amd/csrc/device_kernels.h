@@ -2195,16 +2195,21 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
 template <int METRIC>
 __global__ void __launch_bounds__(64)
 graph_relink_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, const int *__restrict__ adj0, int stride0,
-                    const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU, const int *__restrict__ affected,
-                    int layer, int removed, const int *__restrict__ cands, int ncand, int max_edges, int kcap, int nbcap,
-                    int *__restrict__ out_sel, int *__restrict__ out_cnt, int *__restrict__ out_flag, int sel_stride,
+                    const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU, const int4 *__restrict__ jobs,
+                    const int *__restrict__ cands_all, const int *__restrict__ cand_off, const int *__restrict__ cand_cnt, int max_edges0,
+                    int kcap, int nbcap, int *__restrict__ out_sel, int *__restrict__ out_cnt, int *__restrict__ out_flag, int sel_stride,
                     unsigned long long *__restrict__ eval_counter, int heap_order)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x, job = blockIdx.x;
     const SearchLds L = carve_lds(smem, kcap, 0, dim, nbcap);
     const GraphView G{adj0, stride0, upper, pool, strideU};
-    const int aid = affected[job];
+    // jobs[]: (affected node, layer, removed node, step); the step's search candidates: cands_all[cand_off[step] ..][0 .. cand_cnt[step])
+    const int4 jd = jobs[job];
+    const int aid = jd.x, layer = jd.y, removed = jd.z;
+    const int *cands = cands_all + cand_off[jd.w];
+    const int ncand = cand_cnt[jd.w];
+    const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
     const float *q = rows + (size_t)aid * dim;
     double sb = 0.0;
     if (METRIC == M_COS) sb = row_sn[aid];

@@ -179,6 +179,7 @@ SETTER(hnsw_set_min_nn, min_nn, int)                               // :261
 SETTER(hnsw_set_allow_removals, allow_removals, bool)              // :268
 SETTER(hnsw_mi355x_set_device, device, int)
 SETTER(hnsw_mi355x_set_insert_batch, insert_batch, int)
+SETTER(hnsw_mi355x_set_remove_batch, remove_batch, int)
 SETTER(hnsw_mi355x_set_search_slots, search_slots, int)
 SETTER(hnsw_mi355x_set_host_threads, host_threads, int)
 SETTER(hnsw_mi355x_set_device_traversal, device_traversal, int)

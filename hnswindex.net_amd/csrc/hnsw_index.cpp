@@ -1251,8 +1251,8 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
     const bool on_device = p_.device_traversal && dim_ <= 2048 && dev_->traversal_fits(p_.remove_max_candidates + 1, false, p_.max_edges);
     if (on_device) { if (!sync_graph(err)) return -1; }
     else graph_dirty_ = true;
-    for (int t = 0; t < count; ++t) {
-        const int id = ids[t];
+    // HNSWIndex.Remove(id) (:83-90) -> GraphConnector.RemoveNodeConnections (:53-66)
+    auto remove_one = [&](const int id) -> bool {
         g.removed[(size_t)id] = 1; // item.IsRemoved = true, GraphConnector.cs:55-57
         for (int layer = g.level[(size_t)id]; layer >= 0; --layer) { // :59-66
             // ReplaceEntryPointIfNeeded :72-85
@@ -1292,11 +1292,14 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
             // distances, fewer candidates than MaxEdges) is repeated below on the exact lock-step path.
             bool done = false;
             if (on_device && !affected.empty()) {
-                const int k = p_.remove_max_candidates, me = g.max_edges_at(layer), n = (int)affected.size();
+                const int k = p_.remove_max_candidates, me = g.max_edges_at(0), n = (int)affected.size(); // me: stride of the selections
                 std::vector<int> sid((size_t)k + 1), sflag(1), cids, sel((size_t)n * (size_t)me), scnt((size_t)n), sfl((size_t)n);
                 std::vector<float> sd((size_t)k + 1);
                 auto relink = [&](bool heap_order) -> int { // 1 applied, 0 flagged, -1 error
-                    if (!dev_->relink_batch(affected.data(), n, layer, id, cids.data(), (int)cids.size(), me, sel.data(), scnt.data(), sfl.data(), me, heap_order)) {
+                    const std::vector<int> jl((size_t)n, layer), jr((size_t)n, id), js((size_t)n, 0);
+                    const int c_off = 0, c_cnt = (int)cids.size();
+                    if (!dev_->relink_batch(affected.data(), jl.data(), jr.data(), js.data(), n, cids.data(), &c_off, &c_cnt, 1, g.max_edges_at(0), sel.data(),
+                                            scnt.data(), sfl.data(), me, heap_order)) {
                         err = get_dev_error();
                         return -1;
                     }
@@ -1312,7 +1315,7 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
                 // entry point is a candidate but not a result, so the list holds it as one extra entry (k + 1 slots, its own
                 // distance keeps it in front).  Candidates come out ascending: fine unless something below is flagged.
                 SearchJob sjob{~id, id, layer, layer, -1};
-                if (!dev_->search_batch(&sjob, 1, k + 1, k + 1, sid.data(), sd.data(), sflag.data(), true)) { err = get_dev_error(); return -1; }
+                if (!dev_->search_batch(&sjob, 1, k + 1, k + 1, sid.data(), sd.data(), sflag.data(), true)) { err = get_dev_error(); return false; }
                 bool self_seen = false;
                 for (int i = 0; i <= k && sid[(size_t)i] >= 0; ++i) {
                     if (sid[(size_t)i] == id) self_seen = true;
@@ -1321,19 +1324,19 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
                 int r = 0;
                 if (sflag[0] == 0 && self_seen) {
                     r = relink(false);
-                    if (r < 0) return -1;
+                    if (r < 0) return false;
                 }
                 // (2) equal distances somewhere, or fewer candidates than MaxEdges: the same step with the exact two-heap
                 // search, whose result array IS topCandidates.ToArray() -- the candidate arrays are then the reference's
                 // element for element and Span.Sort's answer follows
                 if (r == 0) {
                     sjob.aux = -2;
-                    if (!dev_->search_batch(&sjob, 1, k, k, sid.data(), sd.data(), sflag.data(), true, true)) { err = get_dev_error(); return -1; }
+                    if (!dev_->search_batch(&sjob, 1, k, k, sid.data(), sd.data(), sflag.data(), true, true)) { err = get_dev_error(); return false; }
                     if (sflag[0] == 0) {
                         cids.clear();
                         for (int i = 0; i < k && sid[(size_t)i] >= 0; ++i) cids.push_back(sid[(size_t)i]);
                         r = relink(true);
-                        if (r < 0) return -1;
+                        if (r < 0) return false;
                     }
                 }
                 done = r == 1;
@@ -1343,10 +1346,10 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
                 ssrc.jobs.resize(1);
                 RemoveSearchJob &sj = ssrc.jobs[0];
                 sj.g = &g; sj.capacity = (int)capacity_; sj.removed = id; sj.layer = layer; sj.k = p_.remove_max_candidates;
-                if (!engine()->run(ssrc, 1)) { err = get_dev_error(); return -1; }
+                if (!engine()->run(ssrc, 1)) { err = get_dev_error(); return false; }
                 if (!affected.empty()) {
                     for (AffectedJob &aj : asrc.jobs) aj.sc_cands = &sj.result;
-                    if (!engine()->run(asrc, (long long)affected.size())) { err = get_dev_error(); return -1; }
+                    if (!engine()->run(asrc, (long long)affected.size())) { err = get_dev_error(); return false; }
                 }
             }
             for (AffectedJob &aj : asrc.jobs) {
@@ -1362,12 +1365,144 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
                     r[0] = affected[a]; r[1] = layer; r[2] = l[0];
                     for (int e = 0; e < l[0]; ++e) r[3 + e] = l[1 + e];
                 }
-                if (!dev_->patch_lists(recs.data(), (int)affected.size(), stride)) { err = get_dev_error(); return -1; }
+                if (!dev_->patch_lists(recs.data(), (int)affected.size(), stride)) { err = get_dev_error(); return false; }
             }
             in_of(id, layer).clear();
             if (layer == 0) g.retire(id); // GraphData.RemoveItem :124-128
         }
-    }
+        return true;
+    };
+
+    // Snapshot batches of removals with disjoint neighbourhoods (hnsw_mi355x_set_remove_batch(B), B > 1): the
+    // deterministic counterpart of the reference's Remove(List) = Parallel.For under region locks (HNSWIndex.cs:95-101,
+    // GraphLocker.cs:28-72).  Disjoint regions make the members' un-linking steps independent of each other, so
+    // every (member, layer) search and every re-link of the batch is computed from the graph as it stands before
+    // the batch -- two launches for the whole batch -- and the differences are applied member by member, in order.
+    auto remove_in_batches = [&]() -> bool {
+        const int B = p_.remove_batch, k = p_.remove_max_candidates, me = g.max_edges_at(0);
+        std::vector<int> rem(ids, ids + count), next, batch;
+        std::vector<unsigned char> marked((size_t)g.length + 1, 0);
+        auto region = [&](int id, auto &&fn) { // itself, its out- and in-neighbours on every layer
+            fn(id);
+            for (int layer = 0; layer <= g.level[(size_t)id]; ++layer) {
+                const int *l = g.list(id, layer);
+                for (int e = 1; e <= l[0]; ++e) fn(l[e]);
+                for (int v : in_of(id, layer)) fn(v);
+            }
+        };
+        while (!rem.empty()) {
+            if (rem[0] == g.entry) { // the entry point moves: alone, sequentially
+                if (!remove_one(rem[0])) return false;
+                rem.erase(rem.begin());
+                continue;
+            }
+            const size_t window = std::min(rem.size(), (size_t)8 * (size_t)B);
+            batch.clear(); next.clear();
+            for (size_t t = 0; t < window; ++t) {
+                const int id = rem[t];
+                bool ok = id != g.entry && (int)batch.size() < B;
+                if (ok) region(id, [&](int v) { ok = ok && !marked[(size_t)v]; });
+                if (!ok) { next.push_back(id); continue; }
+                batch.push_back(id);
+                region(id, [&](int v) { marked[(size_t)v] = 1; });
+            }
+            next.insert(next.end(), rem.begin() + (long)window, rem.end());
+            for (int id : batch) region(id, [&](int v) { marked[(size_t)v] = 0; });
+            // (1) every (member, layer) search on the snapshot: the exact two-heap traversal, entry point filtered,
+            // result = topCandidates.ToArray() (the candidate arrays below are then the reference's element for element)
+            std::vector<SearchJob> sjobs;
+            std::vector<int> step_id, step_layer;
+            for (int id : batch)
+                for (int layer = g.level[(size_t)id]; layer >= 0; --layer) {
+                    sjobs.push_back(SearchJob{~id, id, layer, layer, -2});
+                    step_id.push_back(id); step_layer.push_back(layer);
+                }
+            const int nsteps = (int)sjobs.size();
+            std::vector<int> sid((size_t)nsteps * (size_t)k), sflag((size_t)nsteps);
+            std::vector<float> sd((size_t)nsteps * (size_t)k);
+            if (!dev_->search_batch(sjobs.data(), nsteps, k, k, sid.data(), sd.data(), sflag.data(), true, true)) { err = get_dev_error(); return false; }
+            std::vector<std::vector<NodeDist>> sres((size_t)nsteps);
+            for (int s2 = 0; s2 < nsteps; ++s2) {
+                if (sflag[(size_t)s2] != 0) { // handed back (NaN / -0 distance, heap overflow): this search on the lock-step path, same snapshot
+                    VecSource<RemoveSearchJob> ssrc;
+                    ssrc.jobs.resize(1);
+                    RemoveSearchJob &sj = ssrc.jobs[0];
+                    sj.g = &g; sj.capacity = (int)capacity_; sj.removed = step_id[(size_t)s2]; sj.layer = step_layer[(size_t)s2]; sj.k = k;
+                    if (!engine()->run(ssrc, 1)) { err = get_dev_error(); return false; }
+                    sres[(size_t)s2] = sj.result;
+                } else
+                    for (int i = 0; i < k && sid[(size_t)s2 * k + i] >= 0; ++i) sres[(size_t)s2].push_back(NodeDist{sid[(size_t)s2 * k + i], sd[(size_t)s2 * k + i]});
+            }
+            // (2) every affected node of every step re-linked from the snapshot, one launch
+            std::vector<int> j_aid, j_layer, j_rem, j_step, c_off((size_t)nsteps), c_cnt((size_t)nsteps), c_all;
+            for (int s2 = 0; s2 < nsteps; ++s2) {
+                c_off[(size_t)s2] = (int)c_all.size();
+                c_cnt[(size_t)s2] = (int)sres[(size_t)s2].size();
+                for (const NodeDist &nd : sres[(size_t)s2]) c_all.push_back(nd.id);
+                for (int a : in_of(step_id[(size_t)s2], step_layer[(size_t)s2])) {
+                    j_aid.push_back(a); j_layer.push_back(step_layer[(size_t)s2]); j_rem.push_back(step_id[(size_t)s2]); j_step.push_back(s2);
+                }
+            }
+            const int nj = (int)j_aid.size();
+            std::vector<int> sel((size_t)std::max(nj, 1) * (size_t)me), scnt((size_t)std::max(nj, 1)), sfl((size_t)std::max(nj, 1));
+            if (nj > 0 && !dev_->relink_batch(j_aid.data(), j_layer.data(), j_rem.data(), j_step.data(), nj, c_all.data(), c_off.data(), c_cnt.data(), nsteps, me,
+                                              sel.data(), scnt.data(), sfl.data(), me, true)) {
+                err = get_dev_error();
+                return false;
+            }
+            // (3) apply, member by member (GraphConnector.cs:55-66, :90-167)
+            for (int id : batch) g.removed[(size_t)id] = 1;
+            std::vector<int> recs;
+            int nrecs = 0;
+            const int rstride = g.stride0 + 1;
+            int jpos = 0;
+            for (int s2 = 0; s2 < nsteps; ++s2) {
+                const int id = step_id[(size_t)s2], layer = step_layer[(size_t)s2];
+                const int *rl = g.list(id, layer);
+                for (int e = 1; e <= rl[0]; ++e) erase_from(in_of(rl[e], layer), id); // DetachOutgoingReferences :277-288
+                const std::vector<int> affected = in_of(id, layer);
+                VecSource<AffectedJob> asrc;
+                asrc.jobs.resize(affected.size());
+                bool flagged = false;
+                for (size_t a = 0; a < affected.size(); ++a) {
+                    AffectedJob &aj = asrc.jobs[a];
+                    aj.g = &g; aj.aid = affected[a]; aj.layer = layer; aj.removed = id; aj.sc_cands = &sres[(size_t)s2];
+                    flagged = flagged || sfl[(size_t)(jpos + (int)a)] != 0;
+                }
+                if (!flagged) {
+                    for (size_t a = 0; a < affected.size(); ++a) {
+                        const size_t j = (size_t)jpos + a;
+                        asrc.jobs[a].gather();
+                        asrc.jobs[a].apply(std::vector<int>(sel.begin() + j * (size_t)me, sel.begin() + j * (size_t)me + scnt[j]));
+                    }
+                } else if (!affected.empty()) { // (LDS capacity): these re-links on the lock-step path, same candidates
+                    if (!engine()->run(asrc, (long long)affected.size())) { err = get_dev_error(); return false; }
+                }
+                jpos += (int)affected.size();
+                for (AffectedJob &aj : asrc.jobs) {
+                    for (int o : aj.in_remove) erase_from(in_of(o, layer), aj.aid);
+                    for (int w : aj.in_add) in_of(w, layer).push_back(aj.aid);
+                }
+                for (int a : affected) {
+                    const int *l = g.list(a, layer);
+                    recs.resize((size_t)(nrecs + 1) * (size_t)rstride, 0);
+                    int *r = recs.data() + (size_t)nrecs * (size_t)rstride;
+                    r[0] = a; r[1] = layer; r[2] = l[0];
+                    for (int e = 0; e < l[0]; ++e) r[3 + e] = l[1 + e];
+                    ++nrecs;
+                }
+                in_of(id, layer).clear();
+                if (layer == 0) g.retire(id); // GraphData.RemoveItem :124-128
+            }
+            if (nrecs > 0 && !dev_->patch_lists(recs.data(), nrecs, rstride)) { err = get_dev_error(); return false; }
+            rem.swap(next);
+        }
+        return true;
+    };
+    if (p_.remove_batch > 1 && on_device) { if (!remove_in_batches()) return -1; }
+    else
+        for (int t = 0; t < count; ++t)
+            if (!remove_one(ids[t])) return -1;
     in_valid_ = true;
     return 0;
 }

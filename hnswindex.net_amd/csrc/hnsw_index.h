@@ -27,6 +27,7 @@ struct Params {
     // backend
     int device = -1;         // -1: HNSW_MI355X_DEVICE or 0
     int insert_batch = 65536; // cap of a snapshot batch (which is also <= linked/16); 1 = strictly sequential inserts
+    int remove_batch = 1;     // > 1: hnsw_remove takes removals with disjoint neighbourhoods together (snapshot batches of up to this many)
     int search_slots = 16384;
     int host_threads = 0;    // 0: min(hardware threads, 16)
     int device_traversal = 1; // 1: graph-resident search kernel; 0: host lock-step traversal
@@ -123,6 +124,7 @@ private:
     int knn_query_lockstep(const int *which, int count, int k, int *out_ids, float *out_dists, std::string &err);
     int range_query_lockstep(const int *which, int count, float range, std::vector<std::vector<NodeDist>> &out, std::string &err);
     int range_query_device(int count, float range, std::vector<std::vector<NodeDist>> &out, std::string &err);
+    int remove_batched(const int *ids, int count, std::string &err);
 
     int metric_ = 0;
     int dim_ = 0; // fixed by the first add (the reference takes it from the arrays)

@@ -96,6 +96,12 @@ int hnsw_mi355x_set_device(int device);
  * default 65536; a batch also never exceeds 1/16 of the linked graph -- 1/4 of it during the first
  * min(65 536, final count / 16) inserts).  See DESIGN.md "Add". */
 int hnsw_mi355x_set_insert_batch(int max_batch);
+/* Pending: hnsw_remove's schedule.  1 (default): the ids one after the other, exactly HNSWIndex.Remove(int) per id.
+ * B > 1: the deterministic counterpart of Remove(List<int>) = Parallel.For under region locks (HNSWIndex.cs:95-101,
+ * GraphLocker.cs:28-72): removals whose neighbourhoods (the node, its out- and in-neighbours on every layer) are
+ * disjoint are taken together, up to B per batch out of the first 8 B remaining ids, all searching the graph as it
+ * stands before the batch; the others wait, in order; the entry point is always removed alone.  See DESIGN.md 9. */
+int hnsw_mi355x_set_remove_batch(int max_batch);
 /* Pending: number of concurrent search slots of the lock-step driver (default 16384) and
  * host worker threads (default: min(hardware threads, 16)). */
 int hnsw_mi355x_set_search_slots(int slots);

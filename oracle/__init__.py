@@ -54,6 +54,7 @@ def lib():
         L.orc_import_edges.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int, ct.c_int]
         L.orc_range_query.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_float, ct.c_int, _I, _I, _F]
         L.orc_remove.argtypes = [ct.c_void_p, _I, ct.c_int]
+        L.orc_remove_batched.argtypes = [ct.c_void_p, _I, ct.c_int, ct.c_int]
         L.orc_active_ids.argtypes = [ct.c_void_p, _I, ct.c_int]
         L.orc_length.argtypes = [ct.c_void_p]
         L.orc_set_remove_max_candidates.argtypes = [ct.c_void_p, ct.c_int]
@@ -276,6 +277,12 @@ class OracleIndex:
         a = _i32(ids).ravel()
         if lib().orc_remove(self._h, _pi(a), a.size) != 0:
             raise RuntimeError("orc_remove: removals disabled or invalid id")
+
+    def remove_batched(self, ids, batch):
+        """The builder's snapshot-batched removal schedule (hnsw_mi355x_set_remove_batch; NOT a reference code path)."""
+        a = _i32(ids).ravel()
+        if lib().orc_remove_batched(self._h, _pi(a), a.size, int(batch)) != 0:
+            raise RuntimeError("orc_remove_batched: removals disabled or invalid id")
 
     def active_ids(self):
         out = np.empty(max(1, self.count), dtype=np.int32)

@@ -1197,7 +1197,8 @@ static int in_list(const int *a, int n, int v)
     for (int i = 0; i < n; i++) if (a[i] == v) return 1;
     return 0;
 }
-static void remove_connections_at_layer(sctx_t *c, int removed, int layer) /* GraphConnector.cs:90-167 */
+/* pre / n_pre: the search result to use instead of searching now (the snapshot-batched schedule below), or NULL */
+static void remove_connections_at_layer_pre(sctx_t *c, int removed, int layer, const nd_t *pre, int n_pre) /* GraphConnector.cs:90-167 */
 {
     index_t *ix = c->ix;
     const int max_edges = max_edges_at(ix, layer);
@@ -1208,7 +1209,12 @@ static void remove_connections_at_layer(sctx_t *c, int removed, int layer) /* Gr
     int *affected = (int *)malloc(sizeof(int) * (size_t)(n_aff > 0 ? n_aff : 1));
     memcpy(affected, rn->in[layer].buf, sizeof(int) * (size_t)n_aff);
     nd_t *sc;
-    int n_sc = search_layer_f(c, removed, layer, ix->remove_max_candidates, item(ix, removed), &sc, removed); /* :96 */
+    int n_sc;
+    if (pre) {
+        n_sc = n_pre;
+        sc = (nd_t *)malloc(sizeof(nd_t) * (size_t)(n_pre > 0 ? n_pre : 1));
+        memcpy(sc, pre, sizeof(nd_t) * (size_t)n_pre);
+    } else n_sc = search_layer_f(c, removed, layer, ix->remove_max_candidates, item(ix, removed), &sc, removed); /* :96 */
     nd_t *cd = (nd_t *)malloc(sizeof(nd_t) * (size_t)(n_sc + max_edges + 2));
     int *old_ids = (int *)malloc(sizeof(int) * (size_t)(max_edges + 2));
     for (int a = 0; a < n_aff; a++) {
@@ -1242,6 +1248,111 @@ static void remove_connections_at_layer(sctx_t *c, int removed, int layer) /* Gr
         free(nw.buf);
     }
     free(cd); free(old_ids); free(sc); free(affected);
+}
+
+static void remove_connections_at_layer(sctx_t *c, int removed, int layer) { remove_connections_at_layer_pre(c, removed, layer, NULL, 0); }
+static void retire_item(index_t *ix, int id) /* GraphData.RemoveItem :124-128, ActiveSet.Remove :85-97 */
+{
+    ix->removed_stack[ix->n_removed_stack++] = id;
+    int idx = ix->sparse[id], last = --ix->count, last_id = ix->dense[last];
+    ix->dense[idx] = last_id;
+    ix->sparse[last_id] = idx;
+}
+
+/* Snapshot-batched removal -- NOT a reference code path: the deterministic counterpart of the reference's
+ * Remove(List) = Parallel.For under region locks (HNSWIndex.cs:95-101, GraphLocker.cs:28-72), which lets removals
+ * with disjoint neighbourhoods run concurrently in a scheduler-dependent order.  The builder's schedule
+ * (hnsw_mi355x_set_remove_batch(B), B > 1):
+ *   - the ids are taken in order; the current entry point is removed alone, by the sequential path;
+ *   - otherwise a batch is formed from the first 8 B remaining ids: an id joins (up to B) if its region -- itself,
+ *     its out-neighbours and its in-neighbours on every layer -- is disjoint from the regions already in the batch
+ *     and it is not the entry point; the others stay, in order, for later batches;
+ *   - every member is marked removed; every (member, layer) search runs on the graph as it stands before the
+ *     batch; then the members are unlinked in order with those search results.
+ * Disjoint regions make the unlinking steps independent of each other (no step reads a list another one writes),
+ * so the outcome is one the reference's locking admits. */
+ORC_API int orc_remove_batched(void *h, const int *ids_in, int n, int bmax)
+{
+    index_t *ix = (index_t *)h;
+    if (!ix) return 0;
+    if (!ix->allow_removals) return -1;
+    if (bmax < 1) bmax = 1;
+    for (int t = 0; t < n; t++) {
+        const int id = ids_in[t];
+        if (id < 0 || id >= ix->length || ix->nodes[id].is_removed || !ix->nodes[id].out) return -1;
+        for (int u = 0; u < t; u++) if (ids_in[u] == id) return -1;
+    }
+    sctx_t c = {ix, &ix->vis, 0};
+    int *rem = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1)), *next = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    int *batch = (int *)malloc(sizeof(int) * (size_t)bmax);
+    unsigned char *marked = (unsigned char *)calloc((size_t)ix->length + 1, 1);
+    memcpy(rem, ids_in, sizeof(int) * (size_t)n);
+    int nrem = n;
+    while (nrem > 0) {
+        if (rem[0] == ix->entry) { /* alone, sequentially (the entry point moves) */
+            int one = rem[0];
+            ix->n_eval += c.n_eval; c.n_eval = 0;
+            if (orc_remove(h, &one, 1) != 0) { free(rem); free(next); free(batch); free(marked); return -1; }
+            memmove(rem, rem + 1, sizeof(int) * (size_t)(nrem - 1));
+            nrem--;
+            continue;
+        }
+        const int window = nrem < 8 * bmax ? nrem : 8 * bmax;
+        int nb = 0, nn = 0;
+        for (int t = 0; t < window; t++) {
+            const int id = rem[t];
+            const node_t *nd = &ix->nodes[id];
+            int ok = id != ix->entry && nb < bmax && !marked[id];
+            for (int layer = 0; ok && layer <= nd->max_layer; layer++) {
+                for (int i = 0; ok && i < nd->out[layer].count; i++) ok = !marked[nd->out[layer].buf[i]];
+                for (int i = 0; ok && i < nd->in[layer].count; i++) ok = !marked[nd->in[layer].buf[i]];
+            }
+            if (!ok) { next[nn++] = id; continue; }
+            batch[nb++] = id;
+            marked[id] = 1;
+            for (int layer = 0; layer <= nd->max_layer; layer++) {
+                for (int i = 0; i < nd->out[layer].count; i++) marked[nd->out[layer].buf[i]] = 1;
+                for (int i = 0; i < nd->in[layer].count; i++) marked[nd->in[layer].buf[i]] = 1;
+            }
+        }
+        for (int t = window; t < nrem; t++) next[nn++] = rem[t];
+        /* clear the marks of this batch */
+        for (int b = 0; b < nb; b++) {
+            const node_t *nd = &ix->nodes[batch[b]];
+            marked[batch[b]] = 0;
+            for (int layer = 0; layer <= nd->max_layer; layer++) {
+                for (int i = 0; i < nd->out[layer].count; i++) marked[nd->out[layer].buf[i]] = 0;
+                for (int i = 0; i < nd->in[layer].count; i++) marked[nd->in[layer].buf[i]] = 0;
+            }
+        }
+        /* searches on the snapshot */
+        int nsteps = 0;
+        for (int b = 0; b < nb; b++) nsteps += ix->nodes[batch[b]].max_layer + 1;
+        nd_t **res = (nd_t **)malloc(sizeof(nd_t *) * (size_t)nsteps);
+        int *nres = (int *)malloc(sizeof(int) * (size_t)nsteps);
+        int sidx = 0;
+        for (int b = 0; b < nb; b++) {
+            const int id = batch[b];
+            for (int layer = ix->nodes[id].max_layer; layer >= 0; layer--, sidx++)
+                nres[sidx] = search_layer_f(&c, id, layer, ix->remove_max_candidates, item(ix, id), &res[sidx], id);
+        }
+        for (int b = 0; b < nb; b++) ix->nodes[batch[b]].is_removed = 1;
+        sidx = 0;
+        for (int b = 0; b < nb; b++) {
+            const int id = batch[b];
+            for (int layer = ix->nodes[id].max_layer; layer >= 0; layer--, sidx++) {
+                remove_connections_at_layer_pre(&c, id, layer, res[sidx], nres[sidx]);
+                free(res[sidx]);
+                if (layer == 0) retire_item(ix, id);
+            }
+        }
+        free(res); free(nres);
+        int *tmp = rem; rem = next; next = tmp;
+        nrem = nn;
+    }
+    free(rem); free(next); free(batch); free(marked);
+    ix->n_eval += c.n_eval;
+    return 0;
 }
 
 ORC_API int orc_remove(void *h, const int *ids, int n)

@@ -481,3 +481,40 @@ def test_import_graph_makes_an_identical_replica(Index, metric):
     with pytest.raises(RuntimeError, match="duplicate id"):
         fresh2.import_graph(x, lv, src.entry_point, bad)
 
+
+
+@pytest.mark.parametrize("metric,batch", [("sq_euclid", 64), ("ucosine", 16), ("sq_euclid_i8", 256)])
+def test_batched_removal_matches_its_cpu_restatement(Index, metric, batch):
+    # hnsw_mi355x_set_remove_batch(B): removals with disjoint neighbourhoods taken together (the deterministic
+    # counterpart of Remove(List) = Parallel.For under region locks, HNSWIndex.cs:95-101): graph, Ids() order, entry
+    # point, later queries and later adds equal the oracle's restatement of the same schedule
+    n, dim = 6000, 32
+    x = uniform(n, dim, 4242)
+    if metric == "ucosine":
+        x = normalize_f32(x)
+    ix = Index(dim, metric); ix.set_collection_size(n); ix.set_insert_batch(1024); ix.set_remove_batch(batch)
+    ids = ix.add(x)
+    ref = oracle.OracleIndex(dim, metric, collection_size=n); ref.add_batched(x, 1024)
+    assert ix.graph_hash() == ref.graph_hash()
+    rng = np.random.default_rng(99)
+    victims = rng.permutation(n)[:2500].astype(np.int32)
+    victims[7] = ref.entry_point if ref.entry_point not in victims[:7] else victims[7]   # the entry point goes alone
+    victims = np.array(list(dict.fromkeys(victims.tolist())), dtype=np.int32)
+    ix.reset_stats()
+    ix.remove(victims); ref.remove_batched(victims, batch)
+    assert ix.count == ref.count == n - victims.size
+    assert ix.ids().tolist() == ref.active_ids().tolist() and ix.entry_point == ref.entry_point
+    assert ix.graph_hash() == ref.graph_hash()
+    st = ix.stats()
+    assert st["search_launches"] < victims.size          # far fewer launches than removals: they went in batches
+    q = uniform(400, dim, 4243)
+    if metric == "ucosine":
+        q = normalize_f32(q)
+    a, b = ix.knn_query(q, 10), ref.knn_query(q, 10)
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
+    assert not np.isin(a[0], victims).any()
+    more = uniform(500, dim, 4244)
+    if metric == "ucosine":
+        more = normalize_f32(more)
+    c, d = ix.add(more), ref.add_batched(more, 1024)      # vacated slots reused (LIFO), same Add schedule on both
+    assert (c == d).all() and ix.graph_hash() == ref.graph_hash()
