@@ -246,3 +246,36 @@ def test_rng_skip_continues_an_imported_graph_exactly():
     a.add(more); b.add(more)
     assert b.graph_hash() == a.graph_hash()
 
+
+
+def test_batched_removal_schedule_of_the_oracle():
+    # orc_remove_batched (the builder's schedule, hnsw_mi355x_set_remove_batch): with B = 1 it IS the sequential
+    # Remove; with B > 1 the ids leave in another order and on a snapshot, but the same nodes are gone, nothing
+    # points at them any more, and every list stays within MaxEdges without duplicates
+    import numpy as np
+    rng = np.random.default_rng(5)
+    n, dim, M = 3000, 16, 8
+    x = rng.random((n, dim), dtype=np.float32)
+    victims = rng.permutation(n)[:900].astype(np.int32)
+
+    def build():
+        ix = oracle.OracleIndex(dim, "sq_euclid", max_edges=M, max_candidates=60, collection_size=n)
+        ix.add_batched(x, 256, threads=4)
+        return ix
+    seq, one, many = build(), build(), build()
+    victims[3] = seq.entry_point if seq.entry_point not in victims[:3] else victims[3]
+    victims = np.array(list(dict.fromkeys(victims.tolist())), dtype=np.int32)
+    seq.remove(victims); one.remove_batched(victims, 1); many.remove_batched(victims, 64)
+    assert one.graph_hash() == seq.graph_hash() and one.active_ids().tolist() == seq.active_ids().tolist()
+    assert many.count == seq.count == n - victims.size
+    assert sorted(many.active_ids().tolist()) == sorted(seq.active_ids().tolist())
+    gone = set(victims.tolist())
+    for i in many.active_ids().tolist():
+        for layer in range(many.max_layer(i) + 1):
+            e = many.edges(i, layer).tolist()
+            assert len(e) == len(set(e)) <= (2 * M if layer == 0 else M) and not (set(e) & gone) and i not in e
+    q = rng.random((100, dim), dtype=np.float32)
+    ids, _ = many.knn_query(q, 5)
+    assert not np.isin(ids, victims).any() and (ids >= 0).all()
+    with pytest.raises(RuntimeError):
+        many.remove_batched(victims[:1], 8)          # already removed
