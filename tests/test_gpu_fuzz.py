@@ -179,3 +179,29 @@ def test_visited_id_hash_table(Index, monkeypatch, sorted_top, cap, expect_handb
     got, want = ix.knn_query(q, 5), ref.knn_query(q, 5, threads=8)
     assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
     assert (ix.stats()["search_overflows"] > 0) == expect_handback
+
+
+@pytest.mark.parametrize("case_seed", range(4))
+def test_tie_heavy_batched_removal(Index, case_seed):
+    # the batched removal schedule on integer-grid data (equal distances and duplicate vectors everywhere): the exact
+    # two-heap search hands the re-link kernel the reference's candidate arrays, so Span.Sort's tie order follows
+    rng = np.random.default_rng(5000 + case_seed)
+    dim = int(rng.choice([4, 8, 16]))
+    metric = str(rng.choice(["sq_euclid", "cosine"]))
+    M = int(rng.integers(3, 14))
+    n = int(rng.integers(800, 2500))
+    x = rng.integers(0, 3, (n, dim)).astype(np.float32) + (1.0 if metric == "cosine" else 0.0)
+    B = int(rng.choice([2, 16, 128]))
+    seed = int(rng.integers(0, 1 << 30))
+    ref = oracle.OracleIndex(dim, metric, max_edges=M, max_candidates=40, collection_size=64, random_seed=seed)
+    ref.add_batched(x, 512)
+    ix = Index(dim, metric)
+    ix.set_collection_size(64); ix.set_max_edges(M); ix.set_max_candidates(40); ix.set_random_seed(seed); ix.set_insert_batch(512); ix.set_remove_batch(B)
+    ix.add(x)
+    assert ix.graph_hash() == ref.graph_hash()
+    victims = rng.permutation(n)[: n // 3].astype(np.int32)
+    ix.remove(victims); ref.remove_batched(victims, B)
+    assert ix.graph_hash() == ref.graph_hash() and ix.ids().tolist() == ref.active_ids().tolist() and ix.entry_point == ref.entry_point
+    q = x[rng.integers(0, n, 100)]
+    a, b = ix.knn_query(q, 5), ref.knn_query(q, 5)
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
