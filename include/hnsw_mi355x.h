@@ -100,7 +100,8 @@ int hnsw_mi355x_set_insert_batch(int max_batch);
  * B > 1: the deterministic counterpart of Remove(List<int>) = Parallel.For under region locks (HNSWIndex.cs:95-101,
  * GraphLocker.cs:28-72): removals whose neighbourhoods (the node, its out- and in-neighbours on every layer) are
  * disjoint are taken together, up to B per batch out of the first 8 B remaining ids, all searching the graph as it
- * stands before the batch; the others wait, in order; the entry point is always removed alone.  See DESIGN.md 9. */
+ * stands before the batch; the others wait, in order; the entry point is always removed alone.  With
+ * hnsw_mi355x_set_device_traversal(0) removals stay sequential whatever B says.  See DESIGN.md 9. */
 int hnsw_mi355x_set_remove_batch(int max_batch);
 /* Pending: number of concurrent search slots of the lock-step driver (default 16384) and
  * host worker threads (default: min(hardware threads, 16)). */
