@@ -117,6 +117,10 @@ lib.hnsw_mi355x_get_stats.restype = ct.c_int
 lib.hnsw_mi355x_get_stats.argtypes = [ct.c_void_p, ct.POINTER(Stats)]
 lib.hnsw_mi355x_set_profiling.restype = ct.c_int
 lib.hnsw_mi355x_set_profiling.argtypes = [ct.c_void_p, ct.c_int]
+lib.hnsw_mi355x_index_set_insert_batch.restype = ct.c_int
+lib.hnsw_mi355x_index_set_insert_batch.argtypes = [ct.c_void_p, ct.c_int]
+lib.hnsw_mi355x_exact_window_stats.restype = ct.c_int
+lib.hnsw_mi355x_exact_window_stats.argtypes = [ct.c_void_p, ct.POINTER(ct.c_uint64)]
 
 # ---- (B) hnswdev_* -------------------------------------------------------------------------
 lib.hnsw_mi355x_import_nodes.argtypes = [ct.c_void_p, _F, ct.c_int, ct.c_int, _I, ct.c_int]
@@ -244,8 +248,22 @@ class Index:
         self._check(lib.hnsw_mi355x_set_device(device))
 
     def set_insert_batch(self, max_batch: int):
-        """1 = strictly sequential inserts (the reference's HNSWIndex.Add(item) semantics)."""
+        """1 = strictly sequential inserts (the reference's HNSWIndex.Add(item) semantics); -W = the same graph
+        built through speculative windows of W items (see include/hnsw_mi355x.h)."""
         self._check(lib.hnsw_mi355x_set_insert_batch(max_batch))
+
+    def set_insert_batch_live(self, max_batch: int):
+        """The insert-batch knob on the index as it stands (pending like the others while nothing has been added)."""
+        if not self._h:
+            return self.set_insert_batch(max_batch)
+        self._check(lib.hnsw_mi355x_index_set_insert_batch(self._h, max_batch))
+
+    def exact_window_stats(self):
+        """Counters of the exact-window Add: rounds, searches run, items inserted alone, items linked through windows."""
+        out = (ct.c_uint64 * 4)()
+        if not self._h or lib.hnsw_mi355x_exact_window_stats(self._h, out) != 0:
+            return {"rounds": 0, "searches": 0, "alone": 0, "linked": 0}
+        return {"rounds": int(out[0]), "searches": int(out[1]), "alone": int(out[2]), "linked": int(out[3])}
 
     def set_remove_batch(self, max_batch: int):
         """1 (default): remove() takes the ids one after the other; B > 1: removals with disjoint neighbourhoods together."""

@@ -136,7 +136,11 @@ public:
         const int *sel0, *cnt0, *selU, *cntU, *flag;
         int sel_stride;
     };
-    bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res);
+    // read_log_cap > 0 (the reference-exact windowed Add): every job also records which adjacency lists its searches
+    // read -- *read_log = njobs records of read_log_cap ints [n, entries...], a marker -(layer + 1) in front of each
+    // layer's node ids, n > read_log_cap - 1 on overflow -- and the selected ids come back with the flags (one wait).
+    bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res, int read_log_cap = 0,
+                             const int **read_log = nullptr);
     // insert_search_batch brings back the flags only; this fetches the selected ids into the arrays `res`
     // names (the device-side link half never needs them on the host).
     bool fetch_insert_selections(const InsertResults *res);
@@ -263,6 +267,8 @@ private:
     size_t s_rl_cap_ = 0;
     int *s_order_ = nullptr; // insert search: processing order of a batch's jobs
     size_t s_order_cap_ = 0;
+    int *s_rlog_ = nullptr; // insert search: per-job read logs (exact-window Add)
+    size_t s_rlog_cap_ = 0;
     SearchHit *s_spill_ = nullptr;
     size_t s_spill_cap_ = 0;
     SearchHit *s_arena_ = nullptr; // range search: the launch's results, packed

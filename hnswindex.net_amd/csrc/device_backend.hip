@@ -195,7 +195,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_rlog_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -793,9 +793,12 @@ static bool jobs_valid(const SearchJob *jobs, int njobs, long long g_n, long lon
     return true;
 }
 
-bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res)
+bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res, int read_log_cap,
+                                 const int **read_log)
 {
     if (njobs <= 0) return true;
+    const bool windowed = read_log_cap > 0; // exact-window Add: read logs and selections come back with the flags, one wait
+    if (windowed && (!read_log || read_log_cap < 8 || njobs > (1 << 16))) { set_dev_error("insert_search_batch: bad read-log request"); return false; }
     if (!jobs || !res || k < 1 || n_upper < 0 || max_edges0 < 2) { set_dev_error("insert_search_batch: bad argument"); return false; }
     if (g_n_ <= 0) { set_dev_error("insert_search_batch: no graph uploaded"); return false; }
     for (int i = 0; i < njobs; ++i) {
@@ -824,9 +827,11 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         !grow_dev(&s_selU_, &s_selU_cap_, nU * sel_stride) || !grow_dev(&s_cntU_, &s_cntU_cap_, nU) ||
         !grow_dev(&s_iflag_, &s_iflag_cap_, (size_t)njobs))
         return false;
-    // pinned results: [sel0 | cnt0 | selU | cntU | flag | evals]
+    if (windowed && !grow_dev(&s_rlog_, &s_rlog_cap_, (size_t)njobs * (size_t)read_log_cap)) return false;
+    // pinned results: [sel0 | cnt0 | selU | cntU | flag | evals | read logs]
     const size_t b_sel0 = 4u * (size_t)njobs * sel_stride, b_cnt0 = 4u * (size_t)njobs, b_selU = 4u * nU * sel_stride, b_cntU = 4u * nU, b_flag = 4u * (size_t)njobs;
-    const size_t need = b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 16;
+    const size_t b_log = windowed ? 4u * (size_t)njobs * (size_t)read_log_cap : 0;
+    const size_t need = b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 16 + b_log;
     if (need > h_res_cap_) {
         if (h_res_) (void)hipHostFree(h_res_);
         h_res_ = nullptr; h_res_cap_ = 0;
@@ -838,6 +843,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     int *h_selU = reinterpret_cast<int *>(hb + b_sel0 + b_cnt0), *h_cntU = reinterpret_cast<int *>(hb + b_sel0 + b_cnt0 + b_selU);
     int *h_flag = reinterpret_cast<int *>(hb + b_sel0 + b_cnt0 + b_selU + b_cntU);
     unsigned long long *h_ev = reinterpret_cast<unsigned long long *>(hb + ((b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 7) & ~(size_t)7));
+    int *h_log = reinterpret_cast<int *>(reinterpret_cast<char *>(h_ev) + 8);
     // staging: [jobs | processing order]
     SearchJob *h_jobs = static_cast<SearchJob *>(pinned_stage((sizeof(SearchJob) + sizeof(int)) * (size_t)chunk));
     if (!h_jobs) return false;
@@ -871,7 +877,8 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
                        dim3(64), LDS, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
-                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order); \
+                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
+                       windowed ? s_rlog_ : (int *)nullptr, read_log_cap); \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
     do {                                                                                                                   \
@@ -898,6 +905,16 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
 #undef LAUNCH2
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        if (windowed) { // one launch (njobs <= chunk): everything the host validates with rides on the same wait
+            HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(h_sel0, s_sel_, b_sel0, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(h_cnt0, s_lcnt_, b_cnt0, hipMemcpyDeviceToHost, st));
+            if (n_upper > 0) {
+                HIP_OK(hipMemcpyAsync(h_selU, s_selU_, 4u * (size_t)n_upper * sel_stride, hipMemcpyDeviceToHost, st));
+                HIP_OK(hipMemcpyAsync(h_cntU, s_cntU_, 4u * (size_t)n_upper, hipMemcpyDeviceToHost, st));
+            }
+            HIP_OK(hipMemcpyAsync(h_log, s_rlog_, b_log, hipMemcpyDeviceToHost, st));
+        }
         HIP_OK(hipStreamSynchronize(st)); // the job staging buffer is reused by the next chunk
         stats_.search_launches++;
         stats_.search_evals += *h_ev;
@@ -917,8 +934,10 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     }
     // Only the flags come back now: the selections stay on the device, where the link half reads them
     // (link_batch_planned); a caller that links on the host fetches them (fetch_insert_selections).
-    HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
+    if (!windowed) {
+        HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
     for (int i = 0; i < njobs; ++i) {
         if (h_flag[i] == 2) { stats_.search_repeats++; h_flag[i] = 0; }
         stats_.search_overflows += (uint64_t)(h_flag[i] != 0);
@@ -926,9 +945,10 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     last_insert_jobs_ = njobs <= chunk ? njobs : 0; // a single launch left everything in place
     last_insert_upper_ = n_upper;
     last_insert_stride_ = sel_stride;
-    fetch_njobs_ = njobs;
+    fetch_njobs_ = windowed ? 0 : njobs;
     fetch_nupper_ = n_upper;
     *res = InsertResults{h_sel0, h_cnt0, h_selU, h_cntU, h_flag, sel_stride};
+    if (windowed) *read_log = h_log;
     return true;
 }
 

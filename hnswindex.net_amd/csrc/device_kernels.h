@@ -757,13 +757,33 @@ __device__ unsigned long long g_phase_link[12];
 #define PH_FLUSH_LINK() do {} while (0)
 #endif
 
+// Read log of the reference-exact windowed Add (hnsw_index.cpp "exact window"): the adjacency lists one insert's
+// searches READ -- the node whose out-edges a descent pass scans (GraphNavigator.cs:65) and every candidate a
+// beam search expands (:152-156) -- in order, a marker -(layer + 1) in front of each layer's entries.  These
+// lists (and the stored rows, which never change) are all a search depends on, so a result computed on an older
+// snapshot of the graph is still the sequential one while none of them has been written since.  p == nullptr
+// (every other caller): nothing is recorded and the code folds away.  n keeps counting beyond cap: the host
+// sees the overflow.
+struct ReadLog {
+    int *p;
+    int n, cap;
+    __device__ __forceinline__ void put(int v, int lane)
+    {
+        if (p) {
+            if (lane == 0 && n < cap) p[n] = v;
+            n++;
+        }
+    }
+    __device__ __forceinline__ void layer(int l, int lane) { put(-(l + 1), lane); }
+};
+
 // FindEntryPoint / FindEntryAtLayer (GraphNavigator.cs:27-82): greedy descent from jb.entry at
 // jb.entry_layer down to (not including) jb.search_layer.  Leaves the entry of the search layer
 // in `best` and its distance in `cur` (both wave-uniform).
 template <int METRIC>
 __device__ __forceinline__ void descend(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                         const GraphView &G, const SearchJob jb, const SearchLds &L, int lane, int &best, float &cur,
-                                        unsigned long long &evals)
+                                        unsigned long long &evals, ReadLog &RL)
 {
     int *nbuf = L.nbuf;
     float *dbuf = L.dbuf;
@@ -778,10 +798,12 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
     evals += 1;
     for (int layer = jb.entry_layer; layer > jb.search_layer; --layer) {
         bool changed = true;
+        RL.layer(layer, lane);
         while (changed) { // :60
             changed = false;
             const int *l = G.list(best, layer);
             const int n = l[0];
+            RL.put(best, lane);
             __syncthreads();
             for (int i = lane; i < n; i += 64) nbuf[i] = l[1 + i]; // :65 span taken once per pass
             __syncthreads();
@@ -980,7 +1002,7 @@ template <int METRIC, int NS, bool HASHED>
 __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                                 const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet<HASHED> &V,
                                                 const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals,
-                                                bool overlap)
+                                                bool overlap, ReadLog &RL)
 {
     int *nbuf = L.nbuf;
     float *dbuf = L.dbuf;
@@ -988,9 +1010,10 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     PH_DECL();
     int best;
     float cur;
-    descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals);
+    descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals, RL);
     // ---- SearchLayer (GraphNavigator.cs:123-189) ----
     const int layer = jb.search_layer;
+    RL.layer(layer, lane);
     SortedTop<NS> T;
 #pragma unroll
     for (int t = 0; t < NS; ++t) { T.key[t] = 0u; T.id[t] = 0; }
@@ -1011,6 +1034,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         const HEnt c = T.at(pos);
         if (c.id & kDoubt) { tie = true; break; } // the reference may be expanding its twin instead
         T.mark(pos, lane);
+        RL.put(c.id & kIdMask, lane);
         PH(1);
         int n, nb_a = 0, nb_b = 0;
         if (c.id == pre_id) {
@@ -1179,7 +1203,8 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
 template <int METRIC, bool HASHED>
 __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                          const GraphView &G, const SearchJob jb, int k, int cand_cap, ND *spill, int spill_cap,
-                                         VisitedSet<HASHED> &V, const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals)
+                                         VisitedSet<HASHED> &V, const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals,
+                                         ReadLog &RL)
 {
     const LdsHeap top{L.top};
     const SpillHeap cand{L.cand, cand_cap, spill};
@@ -1198,10 +1223,12 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
     evals += 1;
     for (int layer = jb.entry_layer; layer > jb.search_layer; --layer) {
         bool changed = true;
+        RL.layer(layer, lane);
         while (changed) { // :60
             changed = false;
             const int *l = G.list(best, layer);
             const int n = l[0];
+            RL.put(best, lane);
             __syncthreads();
             for (int i = lane; i < n; i += 64) nbuf[i] = l[1 + i]; // :65 span taken once per pass
             __syncthreads();
@@ -1216,6 +1243,7 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
     }
     // ---- SearchLayer (GraphNavigator.cs:123-189) ----
     const int layer = jb.search_layer;
+    RL.layer(layer, lane);
     int top_n = 0, cand_n = 0;
     bool overflow = false; // also raised for NaN / -0 distances (see f2key)
     bool hash_full = false;
@@ -1242,6 +1270,7 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
     while (cand_n > 0 && !overflow) {
         HEnt c = heap_pop<true>(cand, cand_n);          // :146
         if (c.key > far_key && top_n >= k) break;       // :147-150
+        RL.put(c.id, lane);
         int n, nb_a = 0, nb_b = 0; // this lane's neighbour ids (list positions lane and lane + 64)
         if (c.id == pre_id) {
             n = __builtin_amdgcn_readlane(pre_a, 0);
@@ -1799,11 +1828,12 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
     unsigned long long evals = 0;
     int top_n = 0;
     bool repeated = false;
+    ReadLog RL{nullptr, 0, 0};
     if constexpr (NS > 0) {
         if (jb.aux != -2) {
         bool tie = false;
         // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
-        const bool ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap);
+        const bool ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL);
         if (!(ok1 && tie)) {
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
             // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
@@ -1826,7 +1856,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         repeated = true;
         }
     }
-    const bool ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
+    const bool ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL);
     if (jb.aux == -2) { // SearchLayer's own return value: topCandidates.ToArray(), the heap's array (BinaryHeap.cs:41-44)
         __syncthreads();
         for (int r = lane; r < k_out; r += 64) {
@@ -1964,7 +1994,8 @@ graph_range_kernel(const float *__restrict__ rows, const double *__restrict__ ro
         unsigned long long evals = 0;
         int best;
         float cur;
-        descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals); // FindEntryPointQuery; :268 reuses its distance
+        ReadLog RL{nullptr, 0, 0};
+        descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals, RL); // FindEntryPointQuery; :268 reuses its distance
         if (lane == 0) (void)V.first_visit(best);                                  // :279
         V.seen += 1;
         int count = 0, head = 0;
@@ -2078,7 +2109,8 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                            int cand_cap, ND *__restrict__ spill, int spill_cap, int max_edges0, VisitedSet<HASHED> &V,
                            int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
-                           unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap_and_flags)
+                           unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap_and_flags,
+                           int *__restrict__ read_log, int read_log_cap)
 {
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
@@ -2092,6 +2124,8 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
     unsigned long long evals = 0;
     bool ok = true, repeat = false;
+    // exact-window Add: record [n, entries...] of this job's read log (n beyond the capacity = overflow)
+    ReadLog RL{read_log ? read_log + (size_t)job * read_log_cap + 1 : nullptr, 0, read_log_cap - 1};
 #ifdef EXP_PHASE_CLOCKS
     const long long ph_j0 = __builtin_readcyclecounter();
 #endif
@@ -2099,12 +2133,13 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     for (int layer = first_layer; layer >= 0 && ok; --layer) {
         if (layer != first_layer) V.clear(lane); // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
         int top_n = 0;
+        const int rl_n0 = RL.n;
         const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
         bool exact = NS == 0;
         if constexpr (NS > 0) {
             bool tie = false;
             const unsigned long long ev0 = evals;
-            ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap); // Span.Sort consumes all
+            ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap, RL); // Span.Sort consumes all
             if (!ok) break;
             // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
             // then returns them in HEAP order, Heuristic.cs:13-18): this layer again, exact traversal
@@ -2113,11 +2148,12 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                 repeat = true;
                 evals = ev0;
                 top_n = 0;
+                RL.n = rl_n0; // the same lists are read again
                 V.clear(lane);
             }
         }
         if (exact) {
-            ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals);
+            ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL);
             if (!ok) break;
         }
 #ifdef EXP_PHASE_CLOCKS
@@ -2144,6 +2180,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     }
     if (lane == 0) {
         out_flag[job] = ok ? (repeat ? 2 : 0) : 1; // 2: informational (a layer was answered by the exact traversal)
+        if (read_log) read_log[(size_t)job * read_log_cap] = RL.n;
         atomicAdd(eval_counter, evals);
 #ifdef EXP_PHASE_CLOCKS
         atomicAdd(&g_phase[9], (unsigned long long)(__builtin_readcyclecounter() - ph_j0)); // whole insert job
@@ -2160,7 +2197,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
                            int *__restrict__ vis_tab, int vis_tab_cap, int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
                            unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap,
-                           const int *__restrict__ order)
+                           const int *__restrict__ order, int *__restrict__ read_log, int read_log_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -2177,7 +2214,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         // order of processing changes nothing else.
         if (order) job = __builtin_amdgcn_readfirstlane(order[job]);
         insert_job<METRIC, NS, HASHED>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
-                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap);
+                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap, read_log, read_log_cap);
         V.clear(lane);
     }
 }
@@ -2670,7 +2707,7 @@ __global__ void sqrt_rn_kernel(const double *in, double *out, int n)
         const float *__restrict__, const double *__restrict__, int, const int *__restrict__, int, const int64_t *__restrict__,   \
         const int *__restrict__, int, const SearchJob *__restrict__, int, int, ND *__restrict__, int, int, unsigned *__restrict__, \
         long long, int *__restrict__, int, int *__restrict__, int *__restrict__, int *__restrict__, int *__restrict__, int,      \
-        int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int, const int *__restrict__);
+        int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int, const int *__restrict__, int *__restrict__, int);
 #define HNSW_DECLARE_TRAVERSAL(M, NS, H) HNSW_SEARCH_SIGNATURE(extern, M, NS, H) HNSW_INSERT_SIGNATURE(extern, M, NS, H)
 #define HNSW_DEFINE_TRAVERSAL(M, NS, H) HNSW_SEARCH_SIGNATURE(, M, NS, H) HNSW_INSERT_SIGNATURE(, M, NS, H)
 #define HNSW_DEFINE_SEARCH(M, NS, H) HNSW_SEARCH_SIGNATURE(, M, NS, H)

@@ -215,6 +215,20 @@ API int hnsw_mi355x_knn_query_resident(void *h, int k, int *out_ids, float *out_
     if (static_cast<HnswIndex *>(h)->knn_query_resident(k, out_ids, out_dists, err) < 0) { set_error(err); return -1; }
     return 0;
 }
+API int hnsw_mi355x_index_set_insert_batch(void *h, int max_batch)
+{
+    if (!h || max_batch == 0 || max_batch == -1) { set_error("insert batch must be >= 1, or -W with W >= 2"); return -1; }
+    LOCK_INDEX(h);
+    static_cast<HnswIndex *>(h)->set_insert_batch(max_batch);
+    return 0;
+}
+API int hnsw_mi355x_exact_window_stats(void *h, uint64_t out[4])
+{
+    if (!h || !out) return -1;
+    LOCK_INDEX(h);
+    static_cast<HnswIndex *>(h)->exact_window_stats(out);
+    return 0;
+}
 API int hnsw_mi355x_dim(void *h)
 {
     if (!h) return 0;

@@ -931,6 +931,151 @@ bool HnswIndex::insert_batch(const std::vector<int> &bid, std::string &err)
     return link_half_lockstep(bid, sel, err);
 }
 
+
+// ---- reference-exact Add at window speed ------------------------------------------------------
+// HNSWIndex.Add(item) one item after the other (HNSWIndex.cs:55-65) is the only Add whose graph the reference
+// defines (its own determinism recipe, bindings/__tests__/parameters_test.py:65-68), and it is a chain: item
+// j searches the graph that items < j left behind.  But a search depends on nothing except the stored rows
+// (immutable) and the adjacency lists it READS: the node a descent pass scans (GraphNavigator.cs:65) and the
+// candidates a beam search expands (:152-156); RelativeNeighborPruning reads rows only (Heuristic.cs:23-40).
+// And linking item i WRITES only its own lists (which no search on an older graph can reach) and the lists of
+// the neighbours it selected (back-edge append + PruneOverflow, GraphConnector.cs:196-214).  So:
+//   * W consecutive items search ONE snapshot in one launch, each recording the lists it read;
+//   * the items are then taken in order: item j's result is the sequential one iff none of the lists it read
+//     has been written since its snapshot (by an item < j) -- it is linked -- otherwise the round ends;
+//   * the next round searches again whatever is no longer valid (the frontier item always is, and its search on
+//     the exact graph is valid by definition: at least one item per round) plus new items up to W; results that
+//     are still valid are kept.
+// Items whose level exceeds the top layer go alone (they move the entry point, which every search reads,
+// GraphConnector.cs:27-41), and so do items the device hands back (NaN / -0 distances).  The links of a
+// round's prefix are one launch of the batched link half: appends grouped per list in item order, which is
+// the sequential order.  The graph is the sequential one by construction; the GPU tests hold it to the CPU restatement's sequential Add.
+bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W, bool background, std::string &err)
+{
+    const int m = (int)fresh.size();
+    const int M2 = 2 * p_.max_edges;
+    const int log_cap = std::max(1024, 8 * p_.max_candidates);
+    W = std::max(2, W);
+    struct Spec {
+        int t = -1;              // position in `fresh` this slot holds
+        bool has = false, overflow = false, handback = false;
+        uint32_t snap = 0;       // items linked (seq_) when the search ran
+        std::vector<std::vector<int>> sel; // per layer
+        std::vector<int> r0;     // layer-0 lists read
+        std::vector<uint64_t> rU; // upper-layer lists read: layer << 32 | node
+    };
+    std::vector<Spec> spec((size_t)W);
+    if (mod0_.size() < (size_t)graph_.length) mod0_.resize((size_t)graph_.length, 0u);
+    auto reads_clean = [&](const Spec &s) {
+        for (int v : s.r0) if (mod0_[(size_t)v] > s.snap) return false;
+        for (uint64_t k : s.rU) { auto it = modU_.find(k); if (it != modU_.end() && it->second > s.snap) return false; }
+        return true;
+    };
+    auto valid = [&](const Spec &s, uint32_t cur) { return s.has && !s.handback && (s.snap == cur || (!s.overflow && reads_clean(s))); };
+    std::vector<int> to_search, bid;
+    std::vector<SearchJob> jobs;
+    std::vector<int> upper_base;
+    while (p < m) {
+        if (graph_.entry < 0) { graph_.entry = fresh[(size_t)p++]; continue; } // GraphConnector.cs:28-33
+        const int top = graph_.top_layer();
+        Spec &sf = spec[(size_t)(p % W)];
+        if (graph_.level[(size_t)fresh[(size_t)p]] > top || (sf.t == p && sf.handback)) { // alone: entry-point lock (:36-41) / exact host path
+            bid.assign(1, fresh[(size_t)p]);
+            if (background && !dev_->upload_rows_wait((long long)bid.back() + 1)) { err = get_dev_error(); return false; }
+            if (!insert_batch(bid, err)) return false;
+            if (graph_.level[(size_t)bid[0]] > top) graph_.entry = bid[0];
+            ++p;
+            ++seq_;
+            for (Spec &s : spec) s.t = -1; // what that insert wrote is not tracked: nothing speculative survives it
+            ++xw_alone_;
+            continue;
+        }
+        int hi = std::min(m, p + W);
+        for (int t = p + 1; t < hi; ++t) if (graph_.level[(size_t)fresh[(size_t)t]] > top) { hi = t; break; }
+        const uint32_t R = seq_;
+        to_search.clear();
+        for (int t = p; t < hi; ++t) {
+            Spec &s = spec[(size_t)(t % W)];
+            if (s.t != t) { s.t = t; s.has = false; s.handback = false; }
+            if (!valid(s, R) && !s.handback) to_search.push_back(t);
+        }
+        if (!to_search.empty()) {
+            if (background && !dev_->upload_rows_wait((long long)fresh[(size_t)to_search.back()] + 1)) { err = get_dev_error(); return false; }
+            { Tick t(g_pt.sync_graph); if (!sync_graph(err)) return false; }
+            Tick t_all(g_pt.search_half);
+            const int n = (int)to_search.size(), ep = graph_.entry;
+            jobs.resize((size_t)n);
+            upper_base.assign((size_t)n, -1);
+            int n_upper = 0;
+            for (int i = 0; i < n; ++i) {
+                const int id = fresh[(size_t)to_search[(size_t)i]];
+                const int l0 = std::min(graph_.level[(size_t)id], top); // GraphConnector.cs:176
+                if (l0 > 0) { upper_base[(size_t)i] = n_upper; n_upper += l0; }
+                jobs[(size_t)i] = SearchJob{~id, ep, top, l0, upper_base[(size_t)i]};
+            }
+            Device::InsertResults res{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+            const int *rlog = nullptr;
+            if (!dev_->insert_search_batch(jobs.data(), n, p_.max_candidates, M2, n_upper, &res, log_cap, &rlog)) { err = get_dev_error(); return false; }
+            xw_searches_ += (uint64_t)n;
+            for (int i = 0; i < n; ++i) {
+                Spec &s = spec[(size_t)(to_search[(size_t)i] % W)];
+                s.has = true;
+                s.snap = R;
+                s.handback = res.flag[i] != 0;
+                const int l0 = jobs[(size_t)i].search_layer;
+                s.sel.resize((size_t)l0 + 1);
+                for (int layer = 0; layer <= l0; ++layer) {
+                    const int *ids; int cnt;
+                    if (layer == 0) { ids = res.sel0 + (size_t)i * res.sel_stride; cnt = res.cnt0[i]; }
+                    else { const size_t u = (size_t)(upper_base[(size_t)i] + layer - 1); ids = res.selU + u * res.sel_stride; cnt = res.cntU[u]; }
+                    if (s.handback) cnt = 0;
+                    s.sel[(size_t)layer].assign(ids, ids + cnt);
+                }
+                const int *lg = rlog + (size_t)i * log_cap;
+                s.overflow = lg[0] < 0 || lg[0] > log_cap - 1;
+                s.r0.clear();
+                s.rU.clear();
+                if (!s.overflow) {
+                    int layer = 0;
+                    for (int e = 1; e <= lg[0]; ++e) {
+                        const int v = lg[e];
+                        if (v < 0) layer = -v - 1;
+                        else if (layer == 0) s.r0.push_back(v);
+                        else s.rU.push_back(((uint64_t)(uint32_t)layer << 32) | (uint32_t)v);
+                    }
+                }
+            }
+        }
+        // the valid prefix, in item order
+        bid.clear();
+        uint32_t cur = R;
+        int t = p;
+        Selection sel;
+        for (; t < hi; ++t) {
+            Spec &s = spec[(size_t)(t % W)];
+            if (!valid(s, cur)) break;
+            ++cur;
+            for (size_t layer = 0; layer < s.sel.size(); ++layer)
+                for (int nb : s.sel[layer]) {
+                    if (layer == 0) mod0_[(size_t)nb] = cur;
+                    else modU_[((uint64_t)layer << 32) | (uint32_t)nb] = cur;
+                }
+            bid.push_back(fresh[(size_t)t]);
+            sel.own.push_back(std::move(s.sel));
+            s.t = -1;
+        }
+        ++xw_rounds_;
+        if (bid.empty()) continue; // the frontier item was handed back: next iteration takes it alone
+        sel.n = (int)bid.size();
+        sel.has_own.assign(bid.size(), 1);
+        if (!link_half_device(bid, sel, err)) return false;
+        xw_linked_ += (uint64_t)bid.size();
+        seq_ = cur;
+        p = t;
+    }
+    return true;
+}
+
 int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::string &err)
 {
     if (failed(err)) return -1;
@@ -988,9 +1133,12 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
     if (g_pt.on) g_pt.add_upload += now_s() - t_nodes0;
     // GraphConnector.ConnectNewNode (:24-47), batched
     const int m = (int)fresh.size();
-    const int bmax = std::max(1, p_.insert_batch);
+    const int bmax = std::max(1, p_.insert_batch); // a negative cap selects the exact window below (1 where that cannot run)
     int p = 0;
     std::vector<int> bid;
+    if (p_.insert_batch < 0 && m >= 2 && !any_reused && p_.device_traversal && dev_->traversal_fits(p_.max_candidates, true, p_.max_edges)) {
+        if (!insert_exact_window(fresh, p, std::min(-p_.insert_batch, 4096), background, err)) { if (background) (void)dev_->upload_rows_wait(-1); return fail(err, err); }
+    }
     while (p < m) {
         if (graph_.entry < 0) { graph_.entry = fresh[(size_t)p++]; continue; } // :28-33
         const int top = graph_.top_layer();

@@ -26,7 +26,8 @@ struct Params {
     bool allow_removals = true;
     // backend
     int device = -1;         // -1: HNSW_MI355X_DEVICE or 0
-    int insert_batch = 65536; // cap of a snapshot batch (which is also <= linked/16); 1 = strictly sequential inserts
+    int insert_batch = 65536; // cap of a snapshot batch (which is also <= linked/16); 1 = strictly sequential inserts;
+                              // -W = the sequential graph through speculative windows of W items (insert_exact_window)
     int remove_batch = 1;     // > 1: hnsw_remove takes removals with disjoint neighbourhoods together (snapshot batches of up to this many)
     int search_slots = 16384;
     int host_threads = 0;    // 0: min(hardware threads, 16)
@@ -72,6 +73,8 @@ public:
     const Graph &graph() { std::string e; (void)refresh_host_lists(e); return graph_; }
     Device *device() { return dev_.get(); }
     uint64_t graph_hash();
+    void set_insert_batch(int v) { p_.insert_batch = v; }
+    void exact_window_stats(uint64_t out[4]) const { out[0] = xw_rounds_; out[1] = xw_searches_; out[2] = xw_alone_; out[3] = xw_linked_; }
     void set_profiling(bool on) { profiling_ = on; if (dev_) dev_->set_profiling(on); }
 
     // One caller at a time per index: the reference promises that operations of one type may
@@ -98,6 +101,7 @@ private:
     bool ensure_dim(int dim, std::string &err);
     bool ensure_capacity(long long need, std::string &err);
     bool insert_batch(const std::vector<int> &bid, std::string &err);
+    bool insert_exact_window(const std::vector<int> &fresh, int &p, int W, bool background, std::string &err);
     // Selected neighbour ids per (batch item, layer).  Device results are read in place from the
     // context's pinned buffers (layer 0: slot = item; layer L >= 1: slot upper_base[item] + L - 1);
     // items processed on the host (lock-step mode, hand-backs) carry their own lists.
@@ -147,6 +151,12 @@ private:
     std::vector<std::vector<int>> in0_;
     std::unordered_map<uint64_t, std::vector<int>> inU_;
     bool in_valid_ = false;
+    // exact-window Add: per adjacency list the sequence number of the last insert that wrote it (0 = never);
+    // seq_ = inserts linked so far.  Only compared within one Add call; monotone across calls.
+    std::vector<uint32_t> mod0_;
+    std::unordered_map<uint64_t, uint32_t> modU_;
+    uint32_t seq_ = 0;
+    uint64_t xw_rounds_ = 0, xw_searches_ = 0, xw_alone_ = 0, xw_linked_ = 0; // exact-window statistics (hnsw_mi355x_exact_window_stats)
     bool host_lists_stale_ = false; // the HBM mirror holds newer neighbour lists than graph_ (device-linked Add)
     long long dev_pool_len_ = 0;    // pool ints already mirrored
     std::vector<int> grp_of_node0_; // link half: group index per layer-0 neighbour (-1 = none)

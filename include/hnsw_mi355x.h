@@ -94,8 +94,20 @@ int hnsw_set_allow_removals(bool allow_removals);        /* :268 */
 int hnsw_mi355x_set_device(int device);
 /* Pending: cap on the snapshot batch of hnsw_add (1 = strictly sequential inserts;
  * default 65536; a batch also never exceeds 1/16 of the linked graph -- 1/4 of it during the first
- * min(65 536, final count / 16) inserts).  See DESIGN.md "Add". */
+ * min(65 536, final count / 16) inserts).  See DESIGN.md "Add".
+ * max_batch = -W (W >= 2): the graph of strictly sequential inserts -- HNSWIndex.Add(item) per item,
+ * src/HNSWIndex/HNSWIndex.cs:55-65 -- built through speculative windows: W consecutive items search one
+ * snapshot and record the adjacency lists they read; in item order, an item whose lists nobody has written since
+ * is linked, the first one that is not ends the round and searches again.  Same graph as max_batch = 1, bit for
+ * bit (DESIGN.md "exact window"). */
 int hnsw_mi355x_set_insert_batch(int max_batch);
+/* The same knob on an existing index (takes effect with the next hnsw_add): lets one index be continued under
+ * another schedule, as bench.py's add_modes do. */
+int hnsw_mi355x_index_set_insert_batch(void *handle, int max_batch);
+/* Counters of the exact-window schedule since the index was created: out[0] rounds (dependent search launches),
+ * out[1] insert searches run (>= items: the re-searched ones count again), out[2] items inserted alone (entry-point
+ * moves, hand-backs), out[3] items linked through windows. */
+int hnsw_mi355x_exact_window_stats(void *handle, uint64_t out[4]);
 /* Pending: hnsw_remove's schedule.  1 (default): the ids one after the other, exactly HNSWIndex.Remove(int) per id.
  * B > 1: the deterministic counterpart of Remove(List<int>) = Parallel.For under region locks (HNSWIndex.cs:95-101,
  * GraphLocker.cs:28-72): removals whose neighbourhoods (the node, its out- and in-neighbours on every layer) are

@@ -86,6 +86,10 @@ def lib():
         L.orc_heap_script.argtypes = [ct.c_int, _I, _F, ct.c_int, _I, _F, _I, _I]
         L.orc_search_layer.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, _F, _I, _F]
         L.orc_find_entry_point.argtypes = [ct.c_void_p, ct.c_int, _F]
+        L.orc_access_log.argtypes = [ct.c_void_p, ct.c_longlong]
+        L.orc_access_log.restype = None
+        L.orc_access_log_fetch.argtypes = [ct.c_void_p, ct.POINTER(ct.c_int64), ct.c_longlong]
+        L.orc_access_log_fetch.restype = ct.c_longlong
         _lib = L
     return _lib
 
@@ -223,6 +227,18 @@ class OracleIndex:
         ids = np.empty(a.shape[0], dtype=np.int32)
         lib().orc_add_batched_mt(self._h, _pf(a), a.shape[0], _pi(ids), int(max_batch), int(threads))
         return ids
+
+    def access_log(self, cap):
+        """Record which adjacency lists the sequential Add reads / writes from now on (cap entries; 0 = off)."""
+        lib().orc_access_log(self._h, int(cap))
+
+    def access_log_fetch(self):
+        """(kind, layer, node) arrays of the recorded entries: kind 0 read, 1 write, 2 item start."""
+        n = lib().orc_access_log_fetch(self._h, None, 0)
+        out = np.empty(max(1, n), dtype=np.int64)
+        lib().orc_access_log_fetch(self._h, out.ctypes.data_as(ct.POINTER(ct.c_int64)), n)
+        out = out[:n]
+        return (out >> 60).astype(np.int32), ((out >> 40) & 0xFFFFF).astype(np.int32), (out & 0xFFFFFFFF).astype(np.int64)
 
     def rng_skip(self, n):
         """Advance the level generator by n draws (after import_graph: one per imported node)."""

@@ -586,9 +586,20 @@ typedef struct {
     visited_t *vis_pool;    /* per-thread lists of the threaded batched Add, kept across calls */
     int n_vis_pool;
     uint64_t n_eval;        /* distance evaluations (SURVEY 8d N_eval) */
+    /* optional access log of the single-threaded Add (tools/window_sim.py): which adjacency lists an insert's
+     * searches read and which its links write.  Entry = kind << 60 | layer << 40 | node; kind 0 read, 1 write,
+     * 2 "item `node` starts". */
+    int64_t *alog;
+    size_t alog_n, alog_cap;
 } index_t;
 
 typedef struct { index_t *ix; visited_t *vis; uint64_t n_eval; } sctx_t;
+
+static inline void alog_put(index_t *ix, int kind, int layer, int node)
+{
+    if (!ix->alog || ix->alog_n >= ix->alog_cap) return;
+    ix->alog[ix->alog_n++] = ((int64_t)kind << 60) | ((int64_t)layer << 40) | (int64_t)(uint32_t)node;
+}
 
 /* Vectors as they arrive at the API (n x udim floats) -> what the index stores and measures (n x dim):
  * themselves, or their int8 records.  *tmp must be freed by the caller (NULL when nothing was made). */
@@ -648,6 +659,7 @@ static int find_entry_at_layer(sctx_t *c, int layer, int start, const float *q)
         const edges_t *e = &ix->nodes[best].out[layer];
         const int *conn = e->buf;
         int n = e->count;
+        alog_put(ix, 0, layer, best);
         for (int i = 0; i < n; i++) {
             int cand = conn[i];
             float d = dist_iq(c, cand, q); /* :70 */
@@ -698,6 +710,7 @@ static int search_layer_f(sctx_t *c, int entry_id, int layer, int k, const float
         nd_t closest = heap_pop(&cand);                         /* :146 */
         if (closest.dist > farthest && top.count >= k) break;   /* :147 */
         const edges_t *e = &ix->nodes[closest.id].out[layer];
+        alog_put(ix, 0, layer, closest.id);
         for (int i = 0; i < e->count; ++i) {
             int nb = e->buf[i];
             if (visited_has(c->vis, nb)) continue;              /* :161 */
@@ -829,7 +842,15 @@ static int connect_at_layer(sctx_t *c, int cur_id, int best_peer, int layer)
         node_t *nb = &ix->nodes[nb_id];
         if (ix->allow_removals) edges_add(&nb->in[layer], cur_id); /* :204 */
         edges_add(&nb->out[layer], cur_id);                        /* :207 */
-        if (nb->out[layer].count > max_edges_at(ix, layer)) prune_overflow(c, nb_id, layer); /* :209-212 */
+        if (nb->out[layer].count > max_edges_at(ix, layer)) {      /* :209-212 */
+            prune_overflow(c, nb_id, layer);
+            if (ix->alog) { /* kind 3: the prune turned the new item away and kept everything else (the list is the same set) */
+                const edges_t *e = &ix->nodes[nb_id].out[layer];
+                int has = 0;
+                for (int t = 0; t < e->count; t++) has |= e->buf[t] == cur_id;
+                alog_put(ix, (!has && e->count == max_edges_at(ix, layer)) ? 3 : 1, layer, nb_id);
+            }
+        } else alog_put(ix, 1, layer, nb_id);
     }
     return first; /* :216 */
 }
@@ -902,6 +923,7 @@ static int add_one(sctx_t *c, const float *v)
     int id = alloc_node(ix, v);
     if (id < 0) return -1;
     if (ix->entry < 0) { ix->entry = id; return id; } /* GraphConnector.cs:28-33 */
+    alog_put(ix, 2, 0, id);
     node_t *cur = &ix->nodes[id];
     int top = ix->nodes[ix->entry].max_layer; /* GetTopLayer :195-198 */
     int new_ep = cur->max_layer > top;        /* :36 */
@@ -1428,6 +1450,7 @@ ORC_API void orc_free(void *h)
     visited_free(&ix->vis);
     for (int t = 0; t < ix->n_vis_pool; t++) visited_free(&ix->vis_pool[t]);
     free(ix->vis_pool);
+    free(ix->alog);
     free(ix);
 }
 
@@ -1615,6 +1638,22 @@ ORC_API int orc_get_edges(void *h, int id, int layer, int incoming, int *out, in
     int n = e->count < cap ? e->count : cap;
     memcpy(out, e->buf, sizeof(int) * (size_t)n);
     return e->count;
+}
+/* access log (see index_t.alog): cap entries are recorded from now on; 0 turns it off */
+ORC_API void orc_access_log(void *h, long long cap)
+{
+    index_t *ix = (index_t *)h;
+    free(ix->alog);
+    ix->alog = cap > 0 ? (int64_t *)malloc(sizeof(int64_t) * (size_t)cap) : NULL;
+    ix->alog_n = 0;
+    ix->alog_cap = ix->alog ? (size_t)cap : 0;
+}
+ORC_API long long orc_access_log_fetch(void *h, int64_t *out, long long cap)
+{
+    index_t *ix = (index_t *)h;
+    long long n = (long long)ix->alog_n < cap ? (long long)ix->alog_n : cap;
+    if (out && n > 0) memcpy(out, ix->alog, sizeof(int64_t) * (size_t)n);
+    return (long long)ix->alog_n;
 }
 ORC_API uint64_t orc_n_eval(void *h) { return ((index_t *)h)->n_eval; }
 ORC_API void orc_reset_n_eval(void *h) { ((index_t *)h)->n_eval = 0; }
