@@ -163,6 +163,9 @@ public:
     bool link_batch_begin(int set, const int *rows, int nrows, int row_stride, const int *g_node, const int *g_layer, const int *g_off,
                           const int *g_items, int ngroups, int max_edges0, int list_stride, bool want_lists = true);
     bool link_batch_finish(int set, const int **out_lists);
+    // Dry run of n single appends [node, layer, item] on the mirror as it stands (graph_link_dry_kernel): changed[i] = 1
+    // when list (node, layer) would hold another sequence of ids afterwards.  Nothing is written.  Synchronous.
+    bool link_dry_run(const int *jobs3, int n, int max_edges0, int *changed);
     // Link half of the batch whose insert_search_batch just ran (its jobs and selections are still on
     // the device): own lists, grouping of the back-edge appends and the appends / prunes, all on the
     // device, nothing copied back.  Requires that no job of that batch was handed back.
@@ -269,6 +272,8 @@ private:
     size_t s_order_cap_ = 0;
     int *s_rlog_ = nullptr; // insert search: per-job read logs (exact-window Add)
     size_t s_rlog_cap_ = 0;
+    int *s_dry_ = nullptr;  // link_dry_run: [jobs | flags]
+    size_t s_dry_cap_ = 0;
     SearchHit *s_spill_ = nullptr;
     size_t s_spill_cap_ = 0;
     SearchHit *s_arena_ = nullptr; // range search: the launch's results, packed

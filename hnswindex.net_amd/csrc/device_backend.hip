@@ -195,7 +195,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_rlog_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_rlog_, (void *)s_dry_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -1107,6 +1107,46 @@ bool Device::link_batch_begin(int set, const int *rows, int nrows, int row_strid
     }
     HIP_OK(hipEventRecord((hipEvent_t)ls.ev_done, st));
     ls.busy = true;
+    return true;
+}
+
+bool Device::link_dry_run(const int *jobs3, int n, int max_edges0, int *changed)
+{
+    if (n <= 0) return true;
+    if (!jobs3 || !changed || max_edges0 + 1 > nbcap()) { set_dev_error("link_dry_run: bad argument"); return false; }
+    if (g_n_ <= 0) { set_dev_error("link_dry_run: no graph uploaded"); return false; }
+    for (int i = 0; i < n; ++i) { // a bad id must be an error return, never a GPU fault
+        const int nb = jobs3[3 * i], layer = jobs3[3 * i + 1], item = jobs3[3 * i + 2];
+        if (nb < 0 || nb >= g_n_ || item < 0 || item >= g_n_ || layer < 0) { set_dev_error("link_dry_run: job outside the graph"); return false; }
+    }
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    if (!ensure_search_scratch(1, 1, 0, 16)) return false;
+    if (!grow_dev(&s_dry_, &s_dry_cap_, (size_t)n * 4)) return false;
+    int *h = static_cast<int *>(pinned_stage(sizeof(int) * (size_t)n * 4 + 16));
+    if (!h) return false;
+    unsigned long long *h_ev = reinterpret_cast<unsigned long long *>(h + (((size_t)n * 4 + 1) & ~(size_t)1));
+    memcpy(h, jobs3, sizeof(int) * (size_t)n * 3);
+    HIP_OK(hipMemcpyAsync(s_dry_, h, sizeof(int) * (size_t)n * 3, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
+    const int k_cap = nbcap();
+    const size_t lds = ((search_lds_bytes(k_cap, 0, pitch_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
+#define LAUNCH(M)                                                                                                          \
+    hipLaunchKernelGGL(graph_link_dry_kernel<M>, dim3(n), dim3(64), lds, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_,   \
+                       g_upper_, g_pool_, g_strideU_, s_dry_, max_edges0, k_cap, s_dry_ + (size_t)n * 3, s_evals_, nbcap(), g_tested0_, g_testedU_)
+    if (metric_ == M_SQ) LAUNCH(M_SQ);
+    else if (metric_ == M_COS) LAUNCH(M_COS);
+    else if (metric_ == M_I8) LAUNCH(M_I8);
+    else LAUNCH(M_UCOS);
+#undef LAUNCH
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(h + (size_t)n * 3, s_dry_ + (size_t)n * 3, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    memcpy(changed, h + (size_t)n * 3, sizeof(int) * (size_t)n);
+    stats_.search_launches++;
+    stats_.search_evals += *h_ev;
+    stats_.link_evals += *h_ev;
     return true;
 }
 

@@ -2340,7 +2340,7 @@ __device__ __forceinline__ void link_group(const float *__restrict__ rows, const
                   int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
                   int node, int layer, NextItem next_item, int max_edges0, int k_cap, int *__restrict__ out_list,
                   unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU,
-                  unsigned char *smem)
+                  unsigned char *smem, int *__restrict__ dry_changed = nullptr)
 {
     const SearchLds L = carve_lds(smem, k_cap, 0, dim, nbcap);
     // shortcut scratch behind the common carve-up: distances of up to kNewMax new entries to every
@@ -2451,6 +2451,14 @@ __device__ __forceinline__ void link_group(const float *__restrict__ rows, const
             __syncthreads();
         }
     }
+    if (dry_changed) { // dry run (exact-window Add): nothing is written; would the list read differently afterwards?
+        bool diff = cnt != l[0];
+        for (int i = lane; i < cnt && !diff; i += 64) diff = L.nbuf[i] != l[1 + i];
+        const bool any_diff = __ballot(diff) != 0ull;
+        if (lane == 0) { *dry_changed = any_diff ? 1 : 0; atomicAdd(eval_counter, evals); }
+        __syncthreads();
+        return;
+    }
     if (lane == 0) { l[0] = cnt; *tested_p = tested; if (out_list) out_list[0] = cnt; }
     for (int i = lane; i < cnt; i += 64) { l[1 + i] = L.nbuf[i]; if (out_list) out_list[1 + i] = L.nbuf[i]; }
     if (lane == 0) atomicAdd(eval_counter, evals);
@@ -2474,6 +2482,26 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
     link_group<METRIC>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, g_node[g], g_layer[g],
                        [&]() { return t < t_end ? g_items[t++] : -1; }, max_edges0, k_cap,
                        out_lists ? out_lists + (size_t)g * list_stride : (int *)nullptr, eval_counter, nbcap, tested0, testedU, smem);
+}
+
+// Dry run of single appends (exact-window Add): job g = (node, layer, item) -- would appending `item` to that list,
+// with PruneOverflow if it overflows (GraphConnector.cs:207-212), leave a list that READS differently (another
+// sequence of ids)?  A full list whose prune turns the new item away comes out as the very same sequence (the
+// earlier entries are a greedy output: ascending, mutually tested), and three out of four appends into a grown
+// graph end that way: for every search that read the list, such an append never happened.  Writes nothing.
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+graph_link_dry_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, int *__restrict__ adj0,
+                      int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
+                      const int *__restrict__ jobs3, int max_edges0, int k_cap, int *__restrict__ out_changed,
+                      unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int g = blockIdx.x;
+    int item = jobs3[3 * g + 2];
+    link_group<METRIC>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs3[3 * g], jobs3[3 * g + 1],
+                       [&]() { const int r = item; item = -1; return r; }, max_edges0, k_cap, (int *)nullptr, eval_counter, nbcap,
+                       tested0, testedU, smem, out_changed + g);
 }
 
 // ---- the same with the grouping done on the device (no host work between the insert search and

@@ -963,6 +963,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         std::vector<std::vector<int>> sel; // per layer
         std::vector<int> r0;     // layer-0 lists read
         std::vector<uint64_t> rU; // upper-layer lists read: layer << 32 | node
+        int dry_at = 0;          // this round's first dry-run job of the item
     };
     std::vector<Spec> spec((size_t)W);
     if (mod0_.size() < (size_t)graph_.length) mod0_.resize((size_t)graph_.length, 0u);
@@ -972,9 +973,11 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         return true;
     };
     auto valid = [&](const Spec &s, uint32_t cur) { return s.has && !s.handback && (s.snap == cur || (!s.overflow && reads_clean(s))); };
-    std::vector<int> to_search, bid;
+    std::vector<int> to_search, bid, dry_jobs, dry_flag;
     std::vector<SearchJob> jobs;
     std::vector<int> upper_base;
+    static const bool dry_env = [] { const char *e = std::getenv("HNSW_MI355X_XW_DRY"); return !e || std::atoi(e) != 0; }();
+    const bool dry_run_ = dry_env;
     while (p < m) {
         if (graph_.entry < 0) { graph_.entry = fresh[(size_t)p++]; continue; } // GraphConnector.cs:28-33
         const int top = graph_.top_layer();
@@ -1046,6 +1049,23 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
                 }
             }
         }
+        // Which back-edge appends would change a list at all?  A full list whose PruneOverflow turns the new item
+        // away reads exactly as before (graph_link_dry_kernel), and for the searches that read it that append never
+        // happened.  One dry run per round for every result in the window, on the graph as it stands now: the answer
+        // for an append is exact while nothing else has changed that list since -- the prefix loop below falls back
+        // to "changed" for a list an earlier item of this round did change.
+        if (dry_run_) {
+            dry_jobs.clear();
+            for (int t = p; t < hi; ++t) {
+                Spec &s = spec[(size_t)(t % W)];
+                s.dry_at = (int)(dry_jobs.size() / 3);
+                if (!s.has || s.handback) continue;
+                for (size_t layer = 0; layer < s.sel.size(); ++layer)
+                    for (int nb : s.sel[layer]) { dry_jobs.push_back(nb); dry_jobs.push_back((int)layer); dry_jobs.push_back(fresh[(size_t)t]); }
+            }
+            dry_flag.resize(dry_jobs.size() / 3);
+            if (!dry_jobs.empty() && !dev_->link_dry_run(dry_jobs.data(), (int)dry_flag.size(), M2, dry_flag.data())) { err = get_dev_error(); return false; }
+        }
         // the valid prefix, in item order
         bid.clear();
         uint32_t cur = R;
@@ -1055,10 +1075,19 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
             Spec &s = spec[(size_t)(t % W)];
             if (!valid(s, cur)) break;
             ++cur;
+            int e = s.dry_at;
             for (size_t layer = 0; layer < s.sel.size(); ++layer)
                 for (int nb : s.sel[layer]) {
-                    if (layer == 0) mod0_[(size_t)nb] = cur;
-                    else modU_[((uint64_t)layer << 32) | (uint32_t)nb] = cur;
+                    const bool predicted_same = dry_run_ && dry_flag[(size_t)e] == 0;
+                    ++e;
+                    if (layer == 0) {
+                        if (predicted_same && mod0_[(size_t)nb] <= R) continue; // untouched this round, and the append leaves it as it is
+                        mod0_[(size_t)nb] = cur;
+                    } else {
+                        const uint64_t key = ((uint64_t)layer << 32) | (uint32_t)nb;
+                        if (predicted_same) { auto it = modU_.find(key); if (it == modU_.end() || it->second <= R) continue; }
+                        modU_[key] = cur;
+                    }
                 }
             bid.push_back(fresh[(size_t)t]);
             sel.own.push_back(std::move(s.sel));
