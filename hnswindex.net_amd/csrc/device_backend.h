@@ -57,6 +57,8 @@ struct SearchJob {
     int entry_layer;  // layer the descent starts at (== search_layer: no descent)
     int search_layer; // layer of the beam search
     int aux;          // insert search: index of the item's first upper-layer output slot (-1: none)
+    int stop_layer;   // insert search: the last layer this job searches (0 = all the way down; the exact-window Add
+                      // runs the upper layers of a multi-layer item ahead of time, and its layer 0 as a job of its own)
 };
 struct SearchHit {
     int id;
@@ -139,8 +141,14 @@ public:
     // read_log_cap > 0 (the reference-exact windowed Add): every job also records which adjacency lists its searches
     // read -- *read_log = njobs records of read_log_cap ints [n, entries...], a marker -(layer + 1) in front of each
     // layer's node ids, n > read_log_cap - 1 on overflow -- and the selected ids come back with the flags (one wait).
-    bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res, int read_log_cap = 0,
-                             const int **read_log = nullptr);
+    // The dry run of every selected entry's back-edge append (graph_link_dry_sel_kernel) follows in the same stream:
+    // dry0 / dryU, shaped like sel0 / selU, 0 = the append would leave that neighbour's list reading as it does.
+    struct WindowExtras {
+        int read_log_cap;       // in
+        const int *upper_owner; // in: job index per upper-layer output slot (n_upper)
+        const int *read_log, *dry0, *dryU; // out: pinned, valid until the next call
+    };
+    bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res, WindowExtras *win = nullptr);
     // insert_search_batch brings back the flags only; this fetches the selected ids into the arrays `res`
     // names (the device-side link half never needs them on the host).
     bool fetch_insert_selections(const InsertResults *res);
@@ -274,6 +282,8 @@ private:
     size_t s_rlog_cap_ = 0;
     int *s_dry_ = nullptr;  // link_dry_run: [jobs | flags]
     size_t s_dry_cap_ = 0;
+    int *s_wdry_ = nullptr; // windowed insert search: [upper_owner | dry0 | dryU]
+    size_t s_wdry_cap_ = 0;
     SearchHit *s_spill_ = nullptr;
     size_t s_spill_cap_ = 0;
     SearchHit *s_arena_ = nullptr; // range search: the launch's results, packed

@@ -195,7 +195,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_rlog_, (void *)s_dry_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_rlog_, (void *)s_dry_, (void *)s_wdry_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -793,18 +793,19 @@ static bool jobs_valid(const SearchJob *jobs, int njobs, long long g_n, long lon
     return true;
 }
 
-bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res, int read_log_cap,
-                                 const int **read_log)
+bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res, WindowExtras *win)
 {
     if (njobs <= 0) return true;
-    const bool windowed = read_log_cap > 0; // exact-window Add: read logs and selections come back with the flags, one wait
-    if (windowed && (!read_log || read_log_cap < 8 || njobs > (1 << 16))) { set_dev_error("insert_search_batch: bad read-log request"); return false; }
+    const bool windowed = win != nullptr; // exact-window Add: read logs, selections and dry-run flags come back with the job flags, one wait
+    const int read_log_cap = windowed ? win->read_log_cap : 0;
+    if (windowed && (read_log_cap < 8 || njobs > (1 << 16) || (n_upper > 0 && !win->upper_owner))) { set_dev_error("insert_search_batch: bad window request"); return false; }
     if (!jobs || !res || k < 1 || n_upper < 0 || max_edges0 < 2) { set_dev_error("insert_search_batch: bad argument"); return false; }
     if (g_n_ <= 0) { set_dev_error("insert_search_batch: no graph uploaded"); return false; }
     for (int i = 0; i < njobs; ++i) {
         const SearchJob &j = jobs[i];
         if (j.qref >= 0) { set_dev_error("insert_search_batch: qref must name a stored row"); return false; }
         if (j.search_layer > 0 && (j.aux < 0 || j.aux + j.search_layer > n_upper)) { set_dev_error("insert_search_batch: upper-layer slot out of range"); return false; }
+        if (j.stop_layer < 0 || j.stop_layer > j.search_layer || (!windowed && j.stop_layer != 0)) { set_dev_error("insert_search_batch: bad stop layer"); return false; }
     }
     if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("insert_search_batch: job outside the uploaded graph / rows"); return false; }
     const int cand_cap = cand_lds_cap(k, pitch_, true, nbcap());
@@ -828,10 +829,12 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         !grow_dev(&s_iflag_, &s_iflag_cap_, (size_t)njobs))
         return false;
     if (windowed && !grow_dev(&s_rlog_, &s_rlog_cap_, (size_t)njobs * (size_t)read_log_cap)) return false;
-    // pinned results: [sel0 | cnt0 | selU | cntU | flag | evals | read logs]
+    // pinned results: [sel0 | cnt0 | selU | cntU | flag | evals | read logs | dry0 | dryU]
     const size_t b_sel0 = 4u * (size_t)njobs * sel_stride, b_cnt0 = 4u * (size_t)njobs, b_selU = 4u * nU * sel_stride, b_cntU = 4u * nU, b_flag = 4u * (size_t)njobs;
     const size_t b_log = windowed ? 4u * (size_t)njobs * (size_t)read_log_cap : 0;
-    const size_t need = b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 16 + b_log;
+    const size_t b_dry = windowed ? b_sel0 + b_selU : 0;
+    if (windowed && !grow_dev(&s_wdry_, &s_wdry_cap_, nU + (b_sel0 + b_selU) / 4u)) return false;
+    const size_t need = b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 16 + b_log + b_dry;
     if (need > h_res_cap_) {
         if (h_res_) (void)hipHostFree(h_res_);
         h_res_ = nullptr; h_res_cap_ = 0;
@@ -906,6 +909,27 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         if (windowed) { // one launch (njobs <= chunk): everything the host validates with rides on the same wait
+            int *d_owner = s_wdry_, *d_dry0 = s_wdry_ + nU, *d_dryU = d_dry0 + (size_t)njobs * sel_stride;
+            if (n_upper > 0) {
+                memcpy(h_log + b_log / 4u, win->upper_owner, 4u * (size_t)n_upper); // staged behind the logs (the dry flags land there afterwards)
+                HIP_OK(hipMemcpyAsync(d_owner, h_log + b_log / 4u, 4u * (size_t)n_upper, hipMemcpyHostToDevice, st));
+            }
+            HIP_OK(hipMemsetAsync(d_dry0, 0x01, b_dry, st)); // every flag non-zero ("changed") unless the kernel says otherwise
+            const int k_cap = nbcap();
+            const size_t lds_link = ((search_lds_bytes(k_cap, 0, pitch_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
+            const int grid = (njobs + n_upper) * sel_stride;
+#define LAUNCH_DRY(M)                                                                                                          \
+    hipLaunchKernelGGL(graph_link_dry_sel_kernel<M>, dim3(grid), dim3(64), lds_link, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
+                       g_upper_, g_pool_, g_strideU_, s_jobs_, s_iflag_, s_sel_, s_lcnt_, s_selU_, s_cntU_, sel_stride, d_owner, njobs, max_edges0, \
+                       k_cap, d_dry0, d_dryU, s_evals_, nbcap(), g_tested0_, g_testedU_, g_n_)
+            if (metric_ == M_SQ) LAUNCH_DRY(M_SQ);
+            else if (metric_ == M_COS) LAUNCH_DRY(M_COS);
+            else if (metric_ == M_I8) LAUNCH_DRY(M_I8);
+            else LAUNCH_DRY(M_UCOS);
+#undef LAUNCH_DRY
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(h_log + b_log / 4u, d_dry0, b_dry, hipMemcpyDeviceToHost, st));
             HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
             HIP_OK(hipMemcpyAsync(h_sel0, s_sel_, b_sel0, hipMemcpyDeviceToHost, st));
             HIP_OK(hipMemcpyAsync(h_cnt0, s_lcnt_, b_cnt0, hipMemcpyDeviceToHost, st));
@@ -948,7 +972,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     fetch_njobs_ = windowed ? 0 : njobs;
     fetch_nupper_ = n_upper;
     *res = InsertResults{h_sel0, h_cnt0, h_selU, h_cntU, h_flag, sel_stride};
-    if (windowed) *read_log = h_log;
+    if (windowed) { win->read_log = h_log; win->dry0 = h_log + b_log / 4u; win->dryU = win->dry0 + (size_t)njobs * sel_stride; }
     return true;
 }
 

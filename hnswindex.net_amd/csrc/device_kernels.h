@@ -1002,7 +1002,7 @@ template <int METRIC, int NS, bool HASHED>
 __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                                 const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet<HASHED> &V,
                                                 const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals,
-                                                bool overlap, ReadLog &RL)
+                                                bool overlap, ReadLog &RL, bool *order_tie_out = nullptr)
 {
     int *nbuf = L.nbuf;
     float *dbuf = L.dbuf;
@@ -1192,8 +1192,12 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     }
     __syncthreads();
     top_n_out = top_n;
-    if (T.adjacent_equal(min(top_n, ordered_prefix), lane)) tie = true; // (iii)
     if (T.any_flagged(top_n, lane, kDoubt)) tie = true;                  // (i) left unresolved
+    // (iii): the SET is the reference's, only its order among equal distances is open.  A caller that can tell
+    // whether that order shows in what it makes of the list asks for this case separately (insert_job).
+    const bool order_tie = T.adjacent_equal(min(top_n, ordered_prefix), lane);
+    if (order_tie_out) *order_tie_out = order_tie && !tie;
+    else if (order_tie) tie = true;
     tie_out = tie;
     return !unsafe && !hash_full;
 }
@@ -2129,46 +2133,70 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
 #ifdef EXP_PHASE_CLOCKS
     const long long ph_j0 = __builtin_readcyclecounter();
 #endif
-    const int first_layer = jb.search_layer;
-    for (int layer = first_layer; layer >= 0 && ok; --layer) {
+    const int first_layer = jb.search_layer, last_layer = jb.stop_layer;
+    for (int layer = first_layer; layer >= last_layer && ok; --layer) {
         if (layer != first_layer) V.clear(lane); // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
         int top_n = 0;
         const int rl_n0 = RL.n;
         const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
-        bool exact = NS == 0;
+        bool exact = NS == 0, order_tie = false;
+        const unsigned long long ev0 = evals;
         if constexpr (NS > 0) {
             bool tie = false;
-            const unsigned long long ev0 = evals;
-            ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap, RL); // Span.Sort consumes all
+            ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap, RL, &order_tie); // Span.Sort consumes all
             if (!ok) break;
             // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
             // then returns them in HEAP order, Heuristic.cs:13-18): this layer again, exact traversal
-            if (tie || top_n < max_edges) {
-                exact = true;
-                repeat = true;
-                evals = ev0;
-                top_n = 0;
-                RL.n = rl_n0; // the same lists are read again
-                V.clear(lane);
+            exact = tie || top_n < max_edges;
+        }
+        int rc = 0;
+        for (;;) {
+            if (exact) {
+                if constexpr (NS > 0) {
+                    repeat = true;
+                    evals = ev0;
+                    top_n = 0;
+                    RL.n = rl_n0; // the same lists are read again
+                    V.clear(lane);
+                }
+                ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL);
+                if (!ok) break;
             }
-        }
-        if (exact) {
-            ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL);
-            if (!ok) break;
-        }
 #ifdef EXP_PHASE_CLOCKS
-        const long long ph_h0 = __builtin_readcyclecounter();
+            const long long ph_h0 = __builtin_readcyclecounter();
 #endif
-        // the candidate heap's LDS area is idle now: the grouped heuristic borrows it
-        const int rc = relative_neighbor_pruning<METRIC, NS == 8>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact,
+            // the candidate heap's LDS area is idle now: the grouped heuristic borrows it
+            rc = relative_neighbor_pruning<METRIC, NS == 8>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact,
 #ifdef HNSW_NO_GROUPED
-                                                         nullptr, 0);
+                                                            nullptr, 0);
 #else
-                                                         reinterpret_cast<float *>(L.cand), sizeof(ND) * (size_t)cand_cap, (overlap_and_flags & 2) != 0);
+                                                            reinterpret_cast<float *>(L.cand), sizeof(ND) * (size_t)cand_cap, (overlap_and_flags & 2) != 0);
 #endif
 #ifdef EXP_PHASE_CLOCKS
-        if (lane == 0) atomicAdd(&g_phase[8], (unsigned long long)(__builtin_readcyclecounter() - ph_h0)); // heuristic cycles
+            if (lane == 0) atomicAdd(&g_phase[8], (unsigned long long)(__builtin_readcyclecounter() - ph_h0)); // heuristic cycles
 #endif
+            if (exact || !order_tie) break;
+            // Equal distances somewhere in the ascending candidate list, and nothing else open: the SET is the
+            // reference's, but Span.Sort (Heuristic.cs:22) leaves such a group in an order only the heap array knows.
+            // The greedy pass (:23-40) shows that order only if two members of a group get past the ids accepted before
+            // the group (one may then turn the other away, or both enter the list in that order).  A member that was NOT
+            // accepted just now, with no member of its group accepted before it, was turned away by ids of smaller
+            // distance -- in any order.  So when every member but the last of each group was rejected, the outcome is
+            // the reference's whatever its order was (one candidate in seven is accepted on uniform data: most groups
+            // are harmless -- 2.1 % of the inserts at C2 used to start over, a third of a percent still do).
+            __syncthreads();
+            bool shows = false;
+            for (int p0 = 0; p0 < top_n; p0 += 64) {
+                const int pp = p0 + lane;
+                if (pp >= 1 && pp < top_n && __float_as_uint(L.top[pp].dist) == __float_as_uint(L.top[pp - 1].dist)) {
+                    const int first = L.top[pp - 1].id;
+                    for (int a = 0; a < rc; ++a) shows = shows || L.acc[a] == first;
+                }
+            }
+            if (__ballot(shows) == 0ull) break;
+            exact = true;
+        }
+        if (!ok) break;
         int *osel = layer == 0 ? out_sel0 + (size_t)job * sel_stride : out_selU + (size_t)(jb.aux + layer - 1) * sel_stride;
         for (int i = lane; i < rc; i += 64) osel[i] = L.acc[i];
         if (lane == 0) { if (layer == 0) out_cnt0[job] = rc; else out_cntU[jb.aux + layer - 1] = rc; }
@@ -2502,6 +2530,47 @@ graph_link_dry_kernel(const float *__restrict__ rows, const double *__restrict__
     link_group<METRIC>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs3[3 * g], jobs3[3 * g + 1],
                        [&]() { const int r = item; item = -1; return r; }, max_edges0, k_cap, (int *)nullptr, eval_counter, nbcap,
                        tested0, testedU, smem, out_changed + g);
+}
+
+// The same for the selections an insert search just left on the device (no host step in between): block b stands
+// for entry b % sel_stride of selection row b / sel_stride -- rows [0, njobs) are the jobs' layer-0 selections,
+// row njobs + u is upper slot u, whose job is upper_owner[u].  out0 / outU (same shape as the selections) are
+// preset to 1 by the host; rows a job did not produce (stop_layer), handed-back jobs and entries beyond the
+// count keep that.
+template <int METRIC>
+__global__ void __launch_bounds__(64)
+graph_link_dry_sel_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, int *__restrict__ adj0,
+                          int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
+                          const SearchJob *__restrict__ jobs, const int *__restrict__ flag, const int *__restrict__ sel0,
+                          const int *__restrict__ cnt0, const int *__restrict__ selU, const int *__restrict__ cntU, int sel_stride,
+                          const int *__restrict__ upper_owner, int njobs, int max_edges0, int k_cap, int *__restrict__ out0,
+                          int *__restrict__ outU, unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0,
+                          int *__restrict__ testedU, long long n_nodes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int r = blockIdx.x / sel_stride, e = blockIdx.x % sel_stride;
+    int job, layer, cnt;
+    const int *sel;
+    int *out;
+    if (r < njobs) {
+        job = r; layer = 0;
+        if (jobs[job].stop_layer > 0) return;
+        cnt = cnt0[r]; sel = sel0 + (size_t)r * sel_stride; out = out0 + (size_t)r * sel_stride;
+    } else {
+        const int u = r - njobs;
+        job = upper_owner[u];
+        if (job < 0 || job >= njobs) return;
+        layer = u - jobs[job].aux + 1;
+        if (layer < 1 || layer > jobs[job].search_layer || layer < jobs[job].stop_layer) return;
+        cnt = cntU[u]; sel = selU + (size_t)u * sel_stride; out = outU + (size_t)u * sel_stride;
+    }
+    if (flag[job] == 1 || e >= cnt || cnt > (layer == 0 ? max_edges0 : (max_edges0 >> 1))) return;
+    const int nb = sel[e];
+    int item = ~jobs[job].qref;
+    if (nb < 0 || nb >= n_nodes || item < 0 || item >= n_nodes) return;
+    link_group<METRIC>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, nb, layer,
+                       [&]() { const int x = item; item = -1; return x; }, max_edges0, k_cap, (int *)nullptr, eval_counter, nbcap,
+                       tested0, testedU, smem, out + e);
 }
 
 // ---- the same with the grouping done on the device (no host work between the insert search and

@@ -946,99 +946,162 @@ bool HnswIndex::insert_batch(const std::vector<int> &bid, std::string &err)
 //   * the next round searches again whatever is no longer valid (the frontier item always is, and its search on
 //     the exact graph is valid by definition: at least one item per round) plus new items up to W; results that
 //     are still valid are kept.
+// What counts as a write.  In a grown graph the lists are full and three out of four back-edge appends end in a
+// PruneOverflow that turns the new item away and keeps everything else: the list then reads exactly as before
+// (same ids, same order -- its entries are a greedy output, ascending and mutually tested), and for every search
+// that read it the append never happened.  The launch that searches an item therefore also DRY-RUNS its appends
+// (graph_link_dry_sel_kernel, same code as the link kernel, nothing written); the prediction for a list is exact
+// while nothing has changed that list since, and is otherwise replaced by "changed".  16 items per round instead
+// of 5 on the 1M x 128 graph.
+// Every job of a launch is ONE beam search long.  A multi-layer item (one in sixteen) would make its launch twice
+// as long, so its upper layers are searched ahead of time (they read upper-layer lists only, which are rarely
+// written) as soon as the item comes within kAhead windows of the frontier, and its layer 0 -- entered at the
+// upper layers' selected[0] (GraphConnector.cs:179,216) -- is a job of its own in a later round.  Only a frontier
+// item that still lacks its upper layers runs all of them in one job.
 // Items whose level exceeds the top layer go alone (they move the entry point, which every search reads,
 // GraphConnector.cs:27-41), and so do items the device hands back (NaN / -0 distances).  The links of a
-// round's prefix are one launch of the batched link half: appends grouped per list in item order, which is
-// the sequential order.  The graph is the sequential one by construction; the GPU tests hold it to the CPU restatement's sequential Add.
+// round's prefix are one launch of the batched link half -- appends grouped per list in item order, which is
+// the sequential order -- enqueued without waiting: the next round's searches follow in the same stream.  The
+// graph is the sequential one by construction; the GPU tests hold it to the CPU restatement's sequential Add.
 bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W, bool background, std::string &err)
 {
     const int m = (int)fresh.size();
     const int M2 = 2 * p_.max_edges;
     const int log_cap = std::max(1024, 8 * p_.max_candidates);
     W = std::max(2, W);
-    struct Spec {
-        int t = -1;              // position in `fresh` this slot holds
-        bool has = false, overflow = false, handback = false;
-        uint32_t snap = 0;       // items linked (seq_) when the search ran
-        std::vector<std::vector<int>> sel; // per layer
-        std::vector<int> r0;     // layer-0 lists read
-        std::vector<uint64_t> rU; // upper-layer lists read: layer << 32 | node
-        int dry_at = 0;          // this round's first dry-run job of the item
+    constexpr int kAhead = 4; // upper layers are searched up to kAhead windows ahead of the frontier
+    const int ring = W * (1 + kAhead);
+    struct Part { // one half of an item's search: the upper layers (with the descent) or layer 0
+        bool has = false, overflow = false;
+        uint32_t snap = 0; // items linked (seq_) when the search ran
     };
-    std::vector<Spec> spec((size_t)W);
+    struct Spec {
+        int t = -1;      // position in `fresh` this slot holds
+        int l0 = 0;      // min(level, top): layers l0 .. 1 are the upper part
+        bool handback = false;
+        Part up, lo;     // for a single-layer item `up` is the descent alone, searched together with `lo`
+        std::vector<std::vector<int>> sel;   // per layer
+        std::vector<std::vector<char>> same; // per layer and entry: the dry run says the append leaves that list as it reads
+        std::vector<int> r0;      // layer-0 lists read
+        std::vector<uint64_t> rU; // upper-layer lists read: layer << 32 | node
+    };
+    std::vector<Spec> spec((size_t)ring);
     if (mod0_.size() < (size_t)graph_.length) mod0_.resize((size_t)graph_.length, 0u);
-    auto reads_clean = [&](const Spec &s) {
-        for (int v : s.r0) if (mod0_[(size_t)v] > s.snap) return false;
-        for (uint64_t k : s.rU) { auto it = modU_.find(k); if (it != modU_.end() && it->second > s.snap) return false; }
+    auto modU_at = [&](uint64_t k) -> uint32_t { auto it = modU_.find(k); return it == modU_.end() ? 0u : it->second; };
+    auto up_valid = [&](const Spec &s, uint32_t cur) {
+        if (!s.up.has || s.handback) return false;
+        if (s.up.snap == cur) return true;
+        if (s.up.overflow) return false;
+        for (uint64_t k : s.rU) if (modU_at(k) > s.up.snap) return false;
         return true;
     };
-    auto valid = [&](const Spec &s, uint32_t cur) { return s.has && !s.handback && (s.snap == cur || (!s.overflow && reads_clean(s))); };
-    std::vector<int> to_search, bid, dry_jobs, dry_flag;
+    auto lo_valid = [&](const Spec &s, uint32_t cur) {
+        if (!s.lo.has || s.handback) return false;
+        if (s.lo.snap == cur) return true;
+        if (s.lo.overflow) return false;
+        for (int v : s.r0) if (mod0_[(size_t)v] > s.lo.snap) return false;
+        return true;
+    };
+    enum { kFull = 0, kUpper = 1, kLower = 2 };
+    struct Todo { int t, kind; };
+    std::vector<Todo> todo;
+    std::vector<int> bid, upper_base, upper_owner;
     std::vector<SearchJob> jobs;
-    std::vector<int> upper_base;
-    static const bool dry_env = [] { const char *e = std::getenv("HNSW_MI355X_XW_DRY"); return !e || std::atoi(e) != 0; }();
-    const bool dry_run_ = dry_env;
+    static const bool dry_on = [] { const char *e = std::getenv("HNSW_MI355X_XW_DRY"); return !e || std::atoi(e) != 0; }();
+    static const bool stage_on = [] { const char *e = std::getenv("HNSW_MI355X_XW_STAGE"); return !e || std::atoi(e) != 0; }();
+    // links in flight: two staging sets, finished when their set is needed again and before anything returns
+    bool pend[2] = {false, false};
+    int next_set = 0;
+    auto finish = [&](int set) -> bool {
+        if (!pend[set]) return true;
+        pend[set] = false;
+        Tick t(g_pt.link_dev);
+        if (!dev_->link_batch_finish(set, nullptr)) { err = get_dev_error(); return false; }
+        return true;
+    };
+    struct Drain { std::function<void()> f; ~Drain() { f(); } } drain{[&] { std::string e2; for (int s2 = 0; s2 < 2; ++s2) if (pend[s2]) { pend[s2] = false; (void)dev_->link_batch_finish(s2, nullptr); } }};
     while (p < m) {
         if (graph_.entry < 0) { graph_.entry = fresh[(size_t)p++]; continue; } // GraphConnector.cs:28-33
         const int top = graph_.top_layer();
-        Spec &sf = spec[(size_t)(p % W)];
-        if (graph_.level[(size_t)fresh[(size_t)p]] > top || (sf.t == p && sf.handback)) { // alone: entry-point lock (:36-41) / exact host path
-            bid.assign(1, fresh[(size_t)p]);
-            if (background && !dev_->upload_rows_wait((long long)bid.back() + 1)) { err = get_dev_error(); return false; }
-            if (!insert_batch(bid, err)) return false;
-            if (graph_.level[(size_t)bid[0]] > top) graph_.entry = bid[0];
-            ++p;
-            ++seq_;
-            for (Spec &s : spec) s.t = -1; // what that insert wrote is not tracked: nothing speculative survives it
-            ++xw_alone_;
-            continue;
+        {
+            Spec &sf = spec[(size_t)(p % ring)];
+            if (graph_.level[(size_t)fresh[(size_t)p]] > top || (sf.t == p && sf.handback)) { // alone: entry-point lock (:36-41) / exact host path
+                if (!finish(0) || !finish(1)) return false;
+                bid.assign(1, fresh[(size_t)p]);
+                if (background && !dev_->upload_rows_wait((long long)bid.back() + 1)) { err = get_dev_error(); return false; }
+                if (!insert_batch(bid, err)) return false;
+                if (graph_.level[(size_t)bid[0]] > top) graph_.entry = bid[0];
+                ++p;
+                ++seq_;
+                for (Spec &s : spec) s.t = -1; // what that insert wrote is not tracked: nothing speculative survives it
+                ++xw_alone_;
+                continue;
+            }
         }
-        int hi = std::min(m, p + W);
-        for (int t = p + 1; t < hi; ++t) if (graph_.level[(size_t)fresh[(size_t)t]] > top) { hi = t; break; }
+        int hi = std::min(m, p + W), hi_up = std::min(m, p + ring);
+        for (int t = p + 1; t < hi_up; ++t) if (graph_.level[(size_t)fresh[(size_t)t]] > top) { hi_up = t; break; }
+        hi = std::min(hi, hi_up);
+        if (!stage_on) hi_up = hi;
         const uint32_t R = seq_;
-        to_search.clear();
-        for (int t = p; t < hi; ++t) {
-            Spec &s = spec[(size_t)(t % W)];
-            if (s.t != t) { s.t = t; s.has = false; s.handback = false; }
-            if (!valid(s, R) && !s.handback) to_search.push_back(t);
+        // ---- what has to be searched (again) ----
+        todo.clear();
+        for (int t = p; t < hi_up; ++t) {
+            Spec &s = spec[(size_t)(t % ring)];
+            const int l0 = std::min(graph_.level[(size_t)fresh[(size_t)t]], top); // GraphConnector.cs:176
+            if (t >= hi && l0 == 0) continue; // beyond the window only upper layers are searched ahead
+            if (s.t != t) { s.t = t; s.l0 = l0; s.handback = false; s.up = Part{}; s.lo = Part{}; }
+            if (s.handback) continue;
+            const bool uv = up_valid(s, R);
+            if (l0 == 0 || !stage_on) { if (!uv || !lo_valid(s, R)) todo.push_back(Todo{t, kFull}); continue; }
+            if (!uv) { s.lo.has = false; todo.push_back(Todo{t, t == p ? kFull : kUpper}); continue; } // layer 0 enters where the upper layers end
+            if (t < hi && !lo_valid(s, R)) todo.push_back(Todo{t, kLower});
         }
-        if (!to_search.empty()) {
-            if (background && !dev_->upload_rows_wait((long long)fresh[(size_t)to_search.back()] + 1)) { err = get_dev_error(); return false; }
+        if (!todo.empty()) {
+            int max_t = 0;
+            for (const Todo &d : todo) max_t = std::max(max_t, d.t);
+            if (background && !dev_->upload_rows_wait((long long)fresh[(size_t)max_t] + 1)) { err = get_dev_error(); return false; }
             { Tick t(g_pt.sync_graph); if (!sync_graph(err)) return false; }
             Tick t_all(g_pt.search_half);
-            const int n = (int)to_search.size(), ep = graph_.entry;
+            const int n = (int)todo.size(), ep = graph_.entry;
             jobs.resize((size_t)n);
             upper_base.assign((size_t)n, -1);
-            int n_upper = 0;
+            upper_owner.clear();
             for (int i = 0; i < n; ++i) {
-                const int id = fresh[(size_t)to_search[(size_t)i]];
-                const int l0 = std::min(graph_.level[(size_t)id], top); // GraphConnector.cs:176
-                if (l0 > 0) { upper_base[(size_t)i] = n_upper; n_upper += l0; }
-                jobs[(size_t)i] = SearchJob{~id, ep, top, l0, upper_base[(size_t)i]};
+                const Spec &s = spec[(size_t)(todo[(size_t)i].t % ring)];
+                const int id = fresh[(size_t)todo[(size_t)i].t], kind = todo[(size_t)i].kind;
+                if (kind == kLower) { jobs[(size_t)i] = SearchJob{~id, s.sel[1][0], 0, 0, -1, 0}; continue; } // :179 bestPeer = selected[0] of the layer above
+                if (s.l0 > 0) { upper_base[(size_t)i] = (int)upper_owner.size(); upper_owner.insert(upper_owner.end(), (size_t)s.l0, i); }
+                jobs[(size_t)i] = SearchJob{~id, ep, top, s.l0, upper_base[(size_t)i], kind == kUpper ? 1 : 0}; // FindEntryPoint from the top (:174)
             }
+            const int n_upper = (int)upper_owner.size();
             Device::InsertResults res{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-            const int *rlog = nullptr;
-            if (!dev_->insert_search_batch(jobs.data(), n, p_.max_candidates, M2, n_upper, &res, log_cap, &rlog)) { err = get_dev_error(); return false; }
+            Device::WindowExtras win{log_cap, upper_owner.data(), nullptr, nullptr, nullptr};
+            if (!dev_->insert_search_batch(jobs.data(), n, p_.max_candidates, M2, n_upper, &res, &win)) { err = get_dev_error(); return false; }
             xw_searches_ += (uint64_t)n;
             for (int i = 0; i < n; ++i) {
-                Spec &s = spec[(size_t)(to_search[(size_t)i] % W)];
-                s.has = true;
-                s.snap = R;
-                s.handback = res.flag[i] != 0;
-                const int l0 = jobs[(size_t)i].search_layer;
-                s.sel.resize((size_t)l0 + 1);
-                for (int layer = 0; layer <= l0; ++layer) {
-                    const int *ids; int cnt;
-                    if (layer == 0) { ids = res.sel0 + (size_t)i * res.sel_stride; cnt = res.cnt0[i]; }
-                    else { const size_t u = (size_t)(upper_base[(size_t)i] + layer - 1); ids = res.selU + u * res.sel_stride; cnt = res.cntU[u]; }
-                    if (s.handback) cnt = 0;
+                Spec &s = spec[(size_t)(todo[(size_t)i].t % ring)];
+                const int kind = todo[(size_t)i].kind;
+                if (res.flag[i] != 0) { s.handback = true; continue; }
+                s.sel.resize((size_t)s.l0 + 1);
+                s.same.resize((size_t)s.l0 + 1);
+                const int lfrom = kind == kLower ? 0 : s.l0, lto = kind == kUpper ? 1 : 0;
+                bool bad = false;
+                for (int layer = lfrom; layer >= lto; --layer) {
+                    const int *ids, *dry; int cnt;
+                    if (layer == 0) { ids = res.sel0 + (size_t)i * res.sel_stride; dry = win.dry0 + (size_t)i * res.sel_stride; cnt = res.cnt0[i]; }
+                    else { const size_t u = (size_t)(upper_base[(size_t)i] + layer - 1); ids = res.selU + u * res.sel_stride; dry = win.dryU + u * res.sel_stride; cnt = res.cntU[u]; }
+                    if (cnt < 1 || cnt > (layer == 0 ? M2 : M2 / 2)) { bad = true; break; }
                     s.sel[(size_t)layer].assign(ids, ids + cnt);
+                    s.same[(size_t)layer].resize((size_t)cnt);
+                    for (int e = 0; e < cnt; ++e) s.same[(size_t)layer][(size_t)e] = dry_on && dry[e] == 0;
                 }
-                const int *lg = rlog + (size_t)i * log_cap;
-                s.overflow = lg[0] < 0 || lg[0] > log_cap - 1;
-                s.r0.clear();
-                s.rU.clear();
-                if (!s.overflow) {
+                if (bad) { err = "exact window: the device returned an impossible selection count"; return false; }
+                // the read log: upper-layer entries belong to the upper part, layer-0 entries to the lower part
+                const int *lg = win.read_log + (size_t)i * log_cap;
+                const bool overflow = lg[0] < 0 || lg[0] > log_cap - 1;
+                if (kind != kLower) { s.rU.clear(); s.up = Part{true, overflow, R}; }
+                if (kind != kUpper) { s.r0.clear(); s.lo = Part{true, overflow, R}; }
+                if (!overflow) {
                     int layer = 0;
                     for (int e = 1; e <= lg[0]; ++e) {
                         const int v = lg[e];
@@ -1049,59 +1112,102 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
                 }
             }
         }
-        // Which back-edge appends would change a list at all?  A full list whose PruneOverflow turns the new item
-        // away reads exactly as before (graph_link_dry_kernel), and for the searches that read it that append never
-        // happened.  One dry run per round for every result in the window, on the graph as it stands now: the answer
-        // for an append is exact while nothing else has changed that list since -- the prefix loop below falls back
-        // to "changed" for a list an earlier item of this round did change.
-        if (dry_run_) {
-            dry_jobs.clear();
-            for (int t = p; t < hi; ++t) {
-                Spec &s = spec[(size_t)(t % W)];
-                s.dry_at = (int)(dry_jobs.size() / 3);
-                if (!s.has || s.handback) continue;
-                for (size_t layer = 0; layer < s.sel.size(); ++layer)
-                    for (int nb : s.sel[layer]) { dry_jobs.push_back(nb); dry_jobs.push_back((int)layer); dry_jobs.push_back(fresh[(size_t)t]); }
-            }
-            dry_flag.resize(dry_jobs.size() / 3);
-            if (!dry_jobs.empty() && !dev_->link_dry_run(dry_jobs.data(), (int)dry_flag.size(), M2, dry_flag.data())) { err = get_dev_error(); return false; }
-        }
-        // the valid prefix, in item order
+        // ---- the valid prefix, in item order ----
         bid.clear();
         uint32_t cur = R;
         int t = p;
         Selection sel;
         for (; t < hi; ++t) {
-            Spec &s = spec[(size_t)(t % W)];
-            if (!valid(s, cur)) break;
+            Spec &s = spec[(size_t)(t % ring)];
+            if (s.t != t || !up_valid(s, cur) || !lo_valid(s, cur)) break;
             ++cur;
-            int e = s.dry_at;
-            for (size_t layer = 0; layer < s.sel.size(); ++layer)
-                for (int nb : s.sel[layer]) {
-                    const bool predicted_same = dry_run_ && dry_flag[(size_t)e] == 0;
-                    ++e;
+            for (size_t layer = 0; layer < s.sel.size(); ++layer) {
+                const uint32_t snap = layer == 0 ? s.lo.snap : s.up.snap; // the dry run saw the graph of that snapshot
+                for (size_t e = 0; e < s.sel[layer].size(); ++e) {
+                    const int nb = s.sel[layer][e];
                     if (layer == 0) {
-                        if (predicted_same && mod0_[(size_t)nb] <= R) continue; // untouched this round, and the append leaves it as it is
+                        if (s.same[layer][e] && mod0_[(size_t)nb] <= snap) continue; // unchanged since, and the append leaves it as it reads
                         mod0_[(size_t)nb] = cur;
                     } else {
                         const uint64_t key = ((uint64_t)layer << 32) | (uint32_t)nb;
-                        if (predicted_same) { auto it = modU_.find(key); if (it == modU_.end() || it->second <= R) continue; }
+                        if (s.same[layer][e] && modU_at(key) <= snap) continue;
                         modU_[key] = cur;
                     }
                 }
+            }
             bid.push_back(fresh[(size_t)t]);
             sel.own.push_back(std::move(s.sel));
             s.t = -1;
         }
         ++xw_rounds_;
-        if (bid.empty()) continue; // the frontier item was handed back: next iteration takes it alone
+        if (bid.empty()) continue; // the frontier item was handed back: the next iteration takes it alone
         sel.n = (int)bid.size();
-        sel.has_own.assign(bid.size(), 1);
-        if (!link_half_device(bid, sel, err)) return false;
+        if (!finish(next_set)) return false;
+        if (!link_prefix_begin(bid, sel, next_set, err)) return false;
+        pend[next_set] = true;
+        next_set ^= 1;
         xw_linked_ += (uint64_t)bid.size();
         seq_ = cur;
         p = t;
     }
+    return finish(0) && finish(1);
+}
+
+// The link half of one exact-window prefix (items `bid` in order, their selections in sel.own): own lists and the
+// back-edge appends grouped per (neighbour, layer) list in item order, enqueued on staging set `set` without waiting.
+bool HnswIndex::link_prefix_begin(const std::vector<int> &bid, const Selection &sel, int set, std::string &err)
+{
+    const int n = (int)bid.size();
+    const int M2 = 2 * p_.max_edges, row_stride = 3 + M2, list_stride = graph_.stride0;
+    host_lists_stale_ = true;
+    std::vector<int> &rows = lk_rows_, &g_node = lk_node_, &g_layer = lk_layer_, &g_cnt = lk_cnt_;
+    std::vector<int> &g_off = lk_off_, &g_items = lk_items_, &fill = lk_fill_;
+    std::vector<std::pair<int, int>> &seq = lk_seq_; // (group, item id) in append order
+    if ((int)grp_of_node0_.size() < graph_.length) grp_of_node0_.resize((size_t)graph_.length, -1);
+    {
+        Tick t(g_pt.collect);
+        rows.clear(); g_node.clear(); g_layer.clear(); g_cnt.clear(); seq.clear();
+        std::unordered_map<uint64_t, int> upper_groups;
+        for (int i = 0; i < n; ++i) {
+            const int id = bid[(size_t)i];
+            const std::vector<std::vector<int>> &own = sel.own[(size_t)i];
+            for (int layer = (int)own.size() - 1; layer >= 0; --layer) {
+                const std::vector<int> &sp = own[(size_t)layer];
+                const int sc = (int)sp.size();
+                const size_t r0 = rows.size(); // currNode.OutEdges[layer] = selected (GraphConnector.cs:192)
+                rows.resize(r0 + (size_t)row_stride);
+                rows[r0] = id; rows[r0 + 1] = layer; rows[r0 + 2] = sc;
+                std::memcpy(rows.data() + r0 + 3, sp.data(), sizeof(int) * (size_t)sc);
+                for (int e = 0; e < sc; ++e) { // neighbor.OutEdges[layer].Add(currNode.Id) (:207), grouped per list
+                    const int nb = sp[(size_t)e];
+                    int gi;
+                    if (layer == 0) {
+                        gi = grp_of_node0_[(size_t)nb];
+                        if (gi < 0) { gi = (int)g_node.size(); grp_of_node0_[(size_t)nb] = gi; g_node.push_back(nb); g_layer.push_back(0); g_cnt.push_back(0); }
+                    } else {
+                        const uint64_t key = ((uint64_t)(uint32_t)nb << 8) | (uint64_t)(uint32_t)layer;
+                        auto it = upper_groups.find(key);
+                        if (it == upper_groups.end()) { gi = (int)g_node.size(); upper_groups.emplace(key, gi); g_node.push_back(nb); g_layer.push_back(layer); g_cnt.push_back(0); }
+                        else gi = it->second;
+                    }
+                    g_cnt[(size_t)gi]++;
+                    seq.emplace_back(gi, id);
+                }
+            }
+        }
+        for (size_t g = 0; g < g_node.size(); ++g) if (g_layer[g] == 0) grp_of_node0_[(size_t)g_node[g]] = -1;
+        const int G = (int)g_node.size();
+        g_off.resize((size_t)G + 1);
+        g_items.resize(seq.size());
+        fill.assign((size_t)G, 0);
+        g_off[0] = 0;
+        for (int g = 0; g < G; ++g) g_off[(size_t)g + 1] = g_off[(size_t)g] + g_cnt[(size_t)g];
+        for (const auto &pr : seq) g_items[(size_t)(g_off[(size_t)pr.first] + fill[(size_t)pr.first]++)] = pr.second;
+    }
+    Tick t(g_pt.link_dev);
+    g_pt.rounds++;
+    if (!dev_->link_batch_begin(set, rows.data(), (int)(rows.size() / (size_t)row_stride), row_stride, g_node.data(), g_layer.data(),
+                                g_off.data(), g_items.data(), (int)g_node.size(), M2, list_stride, false)) { err = get_dev_error(); return false; }
     return true;
 }
 

@@ -122,6 +122,7 @@ private:
     bool search_half_device(const std::vector<int> &bid, Selection &sel, std::string &err);
     bool link_half_lockstep(const std::vector<int> &bid, const Selection &sel, std::string &err);
     bool link_half_device(const std::vector<int> &bid, const Selection &sel, std::string &err);
+    bool link_prefix_begin(const std::vector<int> &bid, const Selection &sel, int set, std::string &err);
     bool sync_graph(std::string &err);
     bool refresh_host_lists(std::string &err);
     int knn_query_device(const float *queries, int count, int k, int *out_ids, float *out_dists, std::string &err);
