@@ -88,7 +88,7 @@ lib.hnsw_get_last_error_utf8.restype = ct.c_int
 lib.hnsw_get_last_error_utf8.argtypes = [ct.c_void_p, ct.c_int]
 
 # ---- additions ---------------------------------------------------------------------------
-for _name in ("hnsw_mi355x_count", "hnsw_mi355x_length", "hnsw_mi355x_entry_point", "hnsw_mi355x_reset_stats"):
+for _name in ("hnsw_mi355x_count", "hnsw_mi355x_length", "hnsw_mi355x_entry_point", "hnsw_mi355x_reset_stats", "hnsw_mi355x_resident_count"):
     getattr(lib, _name).restype = ct.c_int
     getattr(lib, _name).argtypes = [ct.c_void_p]
 lib.hnsw_mi355x_set_queries.restype = ct.c_int
@@ -158,13 +158,14 @@ METRICS = {"sq_euclid": 0, "cosine": 1, "ucosine": 2, "sq_euclid_i8": 3}
 
 
 def last_error() -> str:
-    """bindings.py:122-128 `_last_error`."""
-    n = lib.hnsw_get_last_error_utf8(None, 0)
-    if n <= 0:
+    """The library's last error message (what the reference's `_last_error` returns, bindings.py:122-128):
+    hnsw_get_last_error_utf8 reports the byte count it needs when asked with no buffer."""
+    need = int(lib.hnsw_get_last_error_utf8(None, 0))
+    if need < 1:
         return ""
-    buf = ct.create_string_buffer(n + 1)
-    lib.hnsw_get_last_error_utf8(buf, len(buf))
-    return buf.value.decode("utf-8")
+    raw = (ct.c_char * (need + 1))()
+    lib.hnsw_get_last_error_utf8(raw, need + 1)
+    return bytes(raw).split(b"\0", 1)[0].decode("utf-8", "replace")
 
 
 def _dev_error() -> str:
@@ -174,15 +175,15 @@ def _dev_error() -> str:
 
 
 def _as_2d_f32(x: npt.ArrayLike, dim_expected=None):
-    """bindings.py:131-139."""
-    a = np.asarray(x, dtype=np.float32)
-    if a.ndim == 1:
-        a = a.reshape(1, -1)
-    if a.ndim != 2:
+    """One vector or a batch of them as a C-contiguous float32 matrix (n, dim) -- the input contract of the
+    reference's wrapper (bindings.py:131-139): a single vector becomes a batch of one, anything else that is not
+    two-dimensional or has the wrong row length is a ValueError."""
+    m = np.atleast_2d(np.asarray(x, dtype=np.float32))
+    if m.ndim > 2 or np.ndim(x) == 0:
         raise ValueError("expected a 2D array of shape (n, dim) or a 1D vector")
-    if dim_expected is not None and a.shape[1] != dim_expected:
-        raise ValueError(f"expected dim={dim_expected}, got {a.shape[1]}")
-    return a if a.flags["C_CONTIGUOUS"] else np.ascontiguousarray(a)
+    if dim_expected is not None and m.shape[1] != dim_expected:
+        raise ValueError(f"expected dim={dim_expected}, got {m.shape[1]}")
+    return np.require(m, dtype=np.float32, requirements="C")
 
 
 class Index:
@@ -340,12 +341,13 @@ class Index:
     # ---- measurement aid: query set resident in HBM across calls ----
     def set_resident_queries(self, queries: npt.ArrayLike):
         q = _as_2d_f32(queries, self.dim)
-        self._resident_n = int(q.shape[0])
-        if lib.hnsw_mi355x_set_queries(self._h, q.ctypes.data_as(_F), self._resident_n, self.dim) < 0:
+        if lib.hnsw_mi355x_set_queries(self._h, q.ctypes.data_as(_F), int(q.shape[0]), self.dim) < 0:
             raise RuntimeError(last_error())
 
     def knn_query_resident(self, k: int):
-        n = self._resident_n
+        n = int(lib.hnsw_mi355x_resident_count(self._h)) if self._h else 0  # asked, not remembered: knn_query / range_query replace the set
+        if n <= 0:
+            raise RuntimeError("no resident query set: call set_resident_queries first (range_query discards it)")
         ids = np.empty((n, k), dtype=np.int32)
         dists = np.empty((n, k), dtype=np.float32)
         if lib.hnsw_mi355x_knn_query_resident(self._h, k, ids.ctypes.data_as(_I), dists.ctypes.data_as(_F)) < 0:

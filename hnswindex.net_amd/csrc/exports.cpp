@@ -207,6 +207,12 @@ API int hnsw_mi355x_set_queries(void *h, const float *queries, int count, int di
     if (static_cast<HnswIndex *>(h)->set_resident_queries(queries, count, dim, err) < 0) { set_error(err); return -1; }
     return 0;
 }
+API int hnsw_mi355x_resident_count(void *h)
+{
+    if (!h) return 0;
+    LOCK_INDEX(h);
+    return static_cast<HnswIndex *>(h)->resident_count();
+}
 API int hnsw_mi355x_knn_query_resident(void *h, int k, int *out_ids, float *out_dists)
 {
     if (!h || !out_ids || !out_dists) return -1;

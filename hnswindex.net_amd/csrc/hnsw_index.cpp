@@ -1485,6 +1485,7 @@ int HnswIndex::range_query(const float *queries, int count, int dim, float range
     if (failed(err)) return -1;
     if (count <= 0 || graph_.entry < 0) return 0; // HNSWIndex.cs:146
     if (!ensure_dim(dim, err)) return -1;
+    resident_queries_ = 0; // the resident set is replaced: a later knn_query_resident must not answer for these rows
     if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; }
     if (p_.device_traversal && dev_->traversal_fits(1, false, p_.max_edges)) return range_query_device(count, range, out, err);
     return range_query_lockstep(nullptr, count, range, out, err);
@@ -1501,10 +1502,14 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
     if (count <= 0) return 0;
     if (failed(err)) return -1;
     if (!refresh_host_lists(err)) return -1;
-    for (int t = 0; t < count; ++t) {
-        const int id = ids[t];
-        if (id < 0 || id >= graph_.length || graph_.removed[(size_t)id]) { err = "System.IndexOutOfRangeException: hnsw_remove: id " + std::to_string(id) + " is not in the index"; return -1; }
-        for (int u = 0; u < t; ++u) if (ids[u] == id) { err = "System.ArgumentException: hnsw_remove: duplicate id " + std::to_string(id); return -1; }
+    {
+        std::vector<unsigned char> listed((size_t)graph_.length, 0); // duplicates in O(count)
+        for (int t = 0; t < count; ++t) {
+            const int id = ids[t];
+            if (id < 0 || id >= graph_.length || graph_.removed[(size_t)id]) { err = "System.IndexOutOfRangeException: hnsw_remove: id " + std::to_string(id) + " is not in the index"; return -1; }
+            if (listed[(size_t)id]) { err = "System.ArgumentException: hnsw_remove: duplicate id " + std::to_string(id); return -1; }
+            listed[(size_t)id] = 1;
+        }
     }
     Graph &g = graph_;
     // in-edge sets: layer 0 by node, upper layers by (node, layer)
@@ -1782,10 +1787,13 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
         }
         return true;
     };
-    if (p_.remove_batch > 1 && on_device) { if (!remove_in_batches()) return -1; }
+    // From here on the graph changes step by step (flags, host lists, then the HBM mirror): a device failure in the
+    // middle leaves a node flagged removed but still linked and the mirror out of step with the host lists, so -- as
+    // for a failed Add -- the index refuses every later call with the original message.
+    if (p_.remove_batch > 1 && on_device) { if (!remove_in_batches()) { graph_dirty_ = true; return fail("Remove: " + err, err); } }
     else
         for (int t = 0; t < count; ++t)
-            if (!remove_one(ids[t])) return -1;
+            if (!remove_one(ids[t])) { graph_dirty_ = true; return fail("Remove: " + err, err); }
     in_valid_ = true;
     return 0;
 }

@@ -67,6 +67,7 @@ public:
     int import_edges(int layer, const int *counts, const int *edges, int stride, std::string &err);
 
     int count() const { return graph_.count; }
+    int resident_count() const { return resident_queries_; }
     int dim() const { return dim_; }
     // The host copy of the graph.  After a device-linked Add the neighbour lists live in the HBM
     // mirror only and are fetched back here on demand.
@@ -94,7 +95,7 @@ private:
     bool failed(std::string &err) const { if (failed_msg_.empty()) return false; err = failed_msg_; return true; }
     int fail(const std::string &why, std::string &err)
     {
-        failed_msg_ = "HNSWIndex MI355X backend: the index is unusable after a failed Add (" + why + ")";
+        failed_msg_ = "HNSWIndex MI355X backend: the index is unusable after a failed Add / Remove (" + why + ")";
         err = failed_msg_;
         return -1;
     }

@@ -138,11 +138,19 @@ def replicate_index(ix, rows, max_edges: int, src: int = 0, group=None, device=N
     stride0, strideU = 2 * max_edges + 2, max_edges + 2
     if rank == src:
         lv = ix.levels()
-        head = np.array([lv.size, ix.entry_point, int(lv.max()) + 1, ix.dim], dtype=np.int64)
+        # A replica is rebuilt from levels, entry point and out-edges alone: removed slots, the slot-reuse stack and
+        # the draws they cost cannot travel that way, so a source that ever removed anything (length != count) or is
+        # empty is refused -- by a status word every rank reads before any payload, so that all of them raise together.
+        status = 0 if (lv.size > 0 and ix.count == lv.size) else (1 if lv.size == 0 else 2)
+        head = np.array([lv.size, ix.entry_point, (int(lv.max()) + 1) if lv.size else 0, ix.dim, status], dtype=np.int64)
     else:
         lv, head = None, None
-    head = bcast(head, (4,), np.int64)
-    n, entry, nlayers, dim = (int(v) for v in head)
+    head = bcast(head, (5,), np.int64)
+    n, entry, nlayers, dim, status = (int(v) for v in head)
+    if status != 0:
+        raise RuntimeError("replicate_index: the source index is empty" if status == 1 else
+                           "replicate_index: the source index has removed slots (Length != Count); a replica built from "
+                           "levels and edges would differ in Count, graph hash and later Add ids")
     lv = bcast(lv, (n,), np.int32)
     if broadcast_rows:
         rows = bcast(rows if rank == src else None, (n, dim), np.float32)

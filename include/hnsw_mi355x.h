@@ -128,6 +128,9 @@ int hnsw_mi355x_set_device_traversal(int enabled);
  * (out arrays: count x k). */
 int hnsw_mi355x_set_queries(void *handle, const float *queries, int count, int dim);
 int hnsw_mi355x_knn_query_resident(void *handle, int k, int *out_ids, float *out_dists);
+/* Rows of the query set currently resident (hnsw_knn_query leaves its own queries resident, hnsw_range_query leaves
+ * none): the out arrays of hnsw_mi355x_knn_query_resident must hold this many rows of k. */
+int hnsw_mi355x_resident_count(void *handle);
 
 /* Graph introspection for parity checks (reads host state only). */
 int hnsw_mi355x_count(void *handle);   /* HNSWIndex.Count: live items */
