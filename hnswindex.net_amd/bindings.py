@@ -52,7 +52,8 @@ class Stats(ct.Structure):
                 ("link_launches", ct.c_uint64), ("link_evals", ct.c_uint64), ("link_timed_launches", ct.c_uint64),
                 ("link_timed_evals", ct.c_uint64), ("link_kernel_ms", ct.c_double), ("visited_hash_launches", ct.c_uint64),
                 ("range_launches", ct.c_uint64), ("range_evals", ct.c_uint64), ("range_timed_launches", ct.c_uint64),
-                ("range_timed_evals", ct.c_uint64), ("range_kernel_ms", ct.c_double), ("range_handbacks", ct.c_uint64)]
+                ("range_timed_evals", ct.c_uint64), ("range_kernel_ms", ct.c_double), ("range_handbacks", ct.c_uint64),
+                ("replica_bytes", ct.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -77,7 +78,7 @@ lib.hnsw_free_results.argtypes = [ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_
 for _name in ("hnsw_set_collection_size", "hnsw_set_max_edges", "hnsw_set_max_candidates",
               "hnsw_set_remove_max_candidates", "hnsw_set_random_seed", "hnsw_set_min_nn",
               "hnsw_mi355x_set_device", "hnsw_mi355x_set_insert_batch", "hnsw_mi355x_set_remove_batch", "hnsw_mi355x_set_search_slots",
-              "hnsw_mi355x_set_host_threads", "hnsw_mi355x_set_device_traversal"):
+              "hnsw_mi355x_set_host_threads", "hnsw_mi355x_set_device_traversal", "hnsw_mi355x_set_devices"):
     getattr(lib, _name).restype = ct.c_int
     getattr(lib, _name).argtypes = [ct.c_int]
 lib.hnsw_set_distribution_rate.restype = ct.c_int
@@ -119,6 +120,10 @@ lib.hnsw_mi355x_set_profiling.restype = ct.c_int
 lib.hnsw_mi355x_set_profiling.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnsw_mi355x_index_set_insert_batch.restype = ct.c_int
 lib.hnsw_mi355x_index_set_insert_batch.argtypes = [ct.c_void_p, ct.c_int]
+lib.hnsw_mi355x_device_count.restype = ct.c_int
+lib.hnsw_mi355x_device_count.argtypes = [ct.c_void_p]
+lib.hnsw_mi355x_get_stats_at.restype = ct.c_int
+lib.hnsw_mi355x_get_stats_at.argtypes = [ct.c_void_p, ct.c_int, ct.POINTER(Stats)]
 lib.hnsw_mi355x_exact_window_stats.restype = ct.c_int
 lib.hnsw_mi355x_exact_window_stats.argtypes = [ct.c_void_p, ct.POINTER(ct.c_uint64)]
 
@@ -247,6 +252,16 @@ class Index:
     # ---- backend knobs (not in the reference) ----
     def set_device(self, device: int):
         self._check(lib.hnsw_mi355x_set_device(device))
+
+    def set_devices(self, n: int):
+        """Device contexts of the index: knn_query shards its queries over n GPUs inside this process (include/hnsw_mi355x.h)."""
+        self._check(lib.hnsw_mi355x_set_devices(n))
+
+    def stats_at(self, context: int):
+        st = Stats()
+        if not self._h or lib.hnsw_mi355x_get_stats_at(self._h, context, ct.byref(st)) != 0:
+            raise RuntimeError(last_error() or "no such device context")
+        return st.as_dict()
 
     def set_insert_batch(self, max_batch: int):
         """1 = strictly sequential inserts (the reference's HNSWIndex.Add(item) semantics); -W = the same graph

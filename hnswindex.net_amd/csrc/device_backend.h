@@ -85,6 +85,15 @@ public:
     bool upload_rows_wait(long long upto);
     // Replaces the resident query set (nq x dim); norms for cosine computed on device.
     bool set_queries(const float *queries, int nq);
+    // ---- replicas (query sharding over the GPUs of one node, one context per GPU in one process) ----
+    // Makes this context a replica of `src`: stored rows (only those it does not hold yet when `rows_from` >= 0 says
+    // where they start to differ), per-row norms and the whole graph mirror, copied device to device
+    // (hipMemcpyPeerAsync: over xGMI between two GPUs).  pool_len: used ints of src's upper-layer pool.
+    bool clone_from(Device *src, long long pool_len);
+    // Rows [first, first + n) of src's resident query set land at [at, at + n) of this context's (which is grown to
+    // `total` rows and then counts `total` queries): the lock-step fallback gathers every shard on the primary.
+    bool adopt_queries(Device *src, long long first, long long n, long long at, long long total);
+    int ordinal() const { return device_; }
 
     StepBuffers *alloc_step(int nslots, int stride);
     void free_step(StepBuffers *sb);

@@ -477,6 +477,89 @@ StepBuffers *Device::alloc_step(int nslots, int stride)
     return sb;
 }
 
+bool Device::clone_from(Device *src, long long pool_len)
+{
+    if (!src || src == this || src->dim_ != dim_ || src->metric_ != metric_ || src->pitch_ != pitch_) { set_dev_error("clone_from: contexts differ in shape"); return false; }
+    if (pool_len < 0 || pool_len > src->g_pool_cap_) { set_dev_error("clone_from: bad pool length"); return false; }
+    if (!src->sync()) return false; // what is copied must have landed
+    if (!reserve(src->capacity_)) return false;
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    const long long have = std::min(n_rows_hw_, src->n_rows_hw_); // rows never change once uploaded (slot reuse re-clones: see HnswIndex)
+    const long long more = src->n_rows_hw_ - have;
+    if (more > 0) {
+        HIP_OK(hipMemcpyPeerAsync(d_rows_ + (size_t)have * pitch_, device_, src->d_rows_ + (size_t)have * pitch_, src->device_, (size_t)more * pitch_ * sizeof(float), st));
+        if (metric_ == M_COS) HIP_OK(hipMemcpyPeerAsync(d_row_sn_ + have, device_, src->d_row_sn_ + have, src->device_, (size_t)more * sizeof(double), st));
+    }
+    const long long n = src->g_n_;
+    if (n > g_cap_n_ || src->g_stride0_ != g_stride0_) {
+        for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_tested0_}) if (p) HIP_OK(hipFree(p));
+        g_adj0_ = nullptr; g_level_ = nullptr; g_upper_ = nullptr; g_tested0_ = nullptr;
+        const long long cap = std::max<long long>(src->g_cap_n_, std::max<long long>(n, 1024));
+        HIP_OK(hipMalloc(&g_adj0_, sizeof(int) * (size_t)cap * src->g_stride0_));
+        HIP_OK(hipMalloc(&g_level_, sizeof(int) * (size_t)cap));
+        HIP_OK(hipMalloc(&g_upper_, sizeof(int64_t) * (size_t)cap));
+        HIP_OK(hipMalloc(&g_tested0_, sizeof(int) * (size_t)cap));
+        g_cap_n_ = cap;
+    }
+    if (pool_len > g_pool_cap_) {
+        if (g_pool_) HIP_OK(hipFree(g_pool_));
+        if (g_testedU_) HIP_OK(hipFree(g_testedU_));
+        g_pool_ = nullptr; g_testedU_ = nullptr;
+        const long long cap = std::max<long long>(pool_len * 2, 4096);
+        HIP_OK(hipMalloc(&g_pool_, sizeof(int) * (size_t)cap));
+        HIP_OK(hipMalloc(&g_testedU_, sizeof(int) * (size_t)cap));
+        g_pool_cap_ = cap;
+    }
+    g_n_ = n; g_stride0_ = src->g_stride0_; g_strideU_ = src->g_strideU_;
+    if (n > 0) {
+        HIP_OK(hipMemcpyPeerAsync(g_adj0_, device_, src->g_adj0_, src->device_, sizeof(int) * (size_t)n * g_stride0_, st));
+        HIP_OK(hipMemcpyPeerAsync(g_level_, device_, src->g_level_, src->device_, sizeof(int) * (size_t)n, st));
+        HIP_OK(hipMemcpyPeerAsync(g_upper_, device_, src->g_upper_, src->device_, sizeof(int64_t) * (size_t)n, st));
+    }
+    if (pool_len > 0) HIP_OK(hipMemcpyPeerAsync(g_pool_, device_, src->g_pool_, src->device_, sizeof(int) * (size_t)pool_len, st));
+    // a replica only answers queries: the link kernel's pruning history is not carried over
+    if (g_tested0_) HIP_OK(hipMemsetAsync(g_tested0_, 0, sizeof(int) * (size_t)g_cap_n_, st));
+    if (g_testedU_) HIP_OK(hipMemsetAsync(g_testedU_, 0, sizeof(int) * (size_t)g_pool_cap_, st));
+    HIP_OK(hipStreamSynchronize(st));
+    n_rows_hw_ = src->n_rows_hw_;
+    stats_.replica_bytes += (uint64_t)more * pitch_ * sizeof(float) + sizeof(int) * ((uint64_t)n * g_stride0_ + (uint64_t)n * 3 + (uint64_t)pool_len);
+    return true;
+}
+
+bool Device::adopt_queries(Device *src, long long first, long long n, long long at, long long total)
+{
+    if (!src || src->dim_ != dim_ || src->metric_ != metric_ || first < 0 || n < 0 || first + n > src->n_queries_ || at < 0 || at + n > total) {
+        set_dev_error("adopt_queries: bad argument");
+        return false;
+    }
+    if (!src->sync()) return false;
+    if (!bind()) return false;
+    hipStream_t st = S(stream_);
+    if (total > q_capacity_) { // grow, keeping what is resident
+        float *nq = nullptr;
+        double *nsn = nullptr;
+        const long long cap = std::max<long long>(total, 1024);
+        HIP_OK(hipMalloc(&nq, (size_t)cap * pitch_ * sizeof(float)));
+        if (metric_ == M_COS) HIP_OK(hipMalloc(&nsn, (size_t)cap * sizeof(double)));
+        if (d_queries_ && n_queries_ > 0) {
+            HIP_OK(hipMemcpyAsync(nq, d_queries_, (size_t)n_queries_ * pitch_ * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (nsn) HIP_OK(hipMemcpyAsync(nsn, d_q_sn_, (size_t)n_queries_ * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_OK(hipStreamSynchronize(st));
+        }
+        if (d_queries_) HIP_OK(hipFree(d_queries_));
+        if (d_q_sn_) HIP_OK(hipFree(d_q_sn_));
+        d_queries_ = nq; d_q_sn_ = nsn; q_capacity_ = cap;
+    }
+    if (n > 0 && src != this) {
+        HIP_OK(hipMemcpyPeerAsync(d_queries_ + (size_t)at * pitch_, device_, src->d_queries_ + (size_t)first * pitch_, src->device_, (size_t)n * pitch_ * sizeof(float), st));
+        if (metric_ == M_COS) HIP_OK(hipMemcpyPeerAsync(d_q_sn_ + at, device_, src->d_q_sn_ + first, src->device_, (size_t)n * sizeof(double), st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
+    n_queries_ = total;
+    return true;
+}
+
 void Device::free_step(StepBuffers *sb)
 {
     if (!sb) return;

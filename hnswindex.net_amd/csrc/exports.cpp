@@ -183,6 +183,7 @@ SETTER(hnsw_mi355x_set_remove_batch, remove_batch, int)
 SETTER(hnsw_mi355x_set_search_slots, search_slots, int)
 SETTER(hnsw_mi355x_set_host_threads, host_threads, int)
 SETTER(hnsw_mi355x_set_device_traversal, device_traversal, int)
+SETTER(hnsw_mi355x_set_devices, devices, int)
 
 API int hnsw_set_distribution_rate(float dist_rate) // :247 -- crosses the ABI as float, widened to double
 {
@@ -368,11 +369,28 @@ API int hnsw_mi355x_get_stats(void *h, hnswdev_stats *out)
     d->get_stats(out);
     return 0;
 }
+API int hnsw_mi355x_device_count(void *h)
+{
+    if (!h) return 0;
+    LOCK_INDEX(h);
+    return static_cast<HnswIndex *>(h)->device_count();
+}
+API int hnsw_mi355x_get_stats_at(void *h, int context, hnswdev_stats *out)
+{
+    if (!h || !out) return -1;
+    LOCK_INDEX(h);
+    hnsw::Device *d = static_cast<HnswIndex *>(h)->device_at(context);
+    if (!d) { std::memset(out, 0, sizeof(*out)); return context >= 0 && context < static_cast<HnswIndex *>(h)->device_count() ? 0 : -1; }
+    d->get_stats(out);
+    return 0;
+}
 API int hnsw_mi355x_reset_stats(void *h)
 {
     if (!h) return -1;
     LOCK_INDEX(h);
-    if (hnsw::Device *d = static_cast<HnswIndex *>(h)->device()) d->reset_stats();
+    HnswIndex *ix = static_cast<HnswIndex *>(h);
+    for (int g = 0; g < ix->device_count(); ++g)
+        if (hnsw::Device *d = ix->device_at(g)) d->reset_stats();
     return 0;
 }
 API int hnsw_mi355x_set_profiling(void *h, int enabled)

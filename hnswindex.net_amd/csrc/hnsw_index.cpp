@@ -631,9 +631,13 @@ HnswIndex *HnswIndex::create(int metric, const Params &p, std::string &err)
     }
     if (dev < 0 || dev >= ndev) { err = "HNSWIndex MI355X backend: device ordinal out of range"; return nullptr; }
     if (p.max_edges < 1) { err = "MaxEdges must be >= 1"; return nullptr; }
+    int devices = p.devices;
+    if (devices <= 0) { const char *e = std::getenv("HNSW_MI355X_DEVICES"); devices = e ? std::atoi(e) : 1; }
+    if (devices < 1 || devices > 64) { err = "HNSWIndex MI355X backend: device contexts must be between 1 and 64"; return nullptr; }
     HnswIndex *ix = new HnswIndex();
     ix->metric_ = metric;
     ix->p_ = p;
+    ix->p_.devices = devices;
     ix->device_ordinal_ = dev;
     ix->graph_.configure(p.max_edges);
     // RandomSeed < 0 means an unseeded Random() in the reference (GraphData.cs:42); a
@@ -659,6 +663,7 @@ HnswIndex::~HnswIndex()
         fprintf(stderr, "[hnsw trace] batches=%ld sync_graph=%.3fs search_half=%.3fs collect=%.3fs link_host=%.3fs link_dev=%.3fs (rounds=%ld prune_jobs=%ld) | query: set_queries=%.3fs dev=%.3fs post=%.3fs\n",
                 g_pt.batches, g_pt.sync_graph, g_pt.search_half, g_pt.collect, g_pt.link_host, g_pt.link_dev, g_pt.rounds, g_pt.prune_jobs, g_pt.set_queries, g_pt.query_dev, g_pt.post);
     engine_.reset(); // before the device it allocates from
+    replicas_.clear();
     dev_.reset();
 }
 
@@ -1215,6 +1220,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
 {
     if (failed(err)) return -1;
     in_valid_ = false;
+    ++graph_epoch_;
     if (!ensure_dim(dim, err)) return -1;
     Tick t_total(g_pt.add_total);
     double t_nodes0 = g_pt.on ? now_s() : 0;
@@ -1248,7 +1254,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
         fresh.push_back(ids[(size_t)i]);
     }
     if (g_pt.on) { g_pt.add_nodes += now_s() - t_nodes0; t_nodes0 = now_s(); }
-    if (any_reused) graph_dirty_ = true; // existing rows of the HBM mirror changed: full re-upload
+    if (any_reused) { graph_dirty_ = true; replicas_.clear(); } // existing rows of the HBM mirror changed: full re-upload, replicas from scratch
     // rows -> HBM (id == row index)
     // A large Add starts linking as soon as its first rows are resident: the rest is uploaded by a helper
     // thread on its own stream while the first (small, latency-bound) batches run, and every batch waits
@@ -1381,10 +1387,62 @@ int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *o
     return knn_query_resident(k, out_ids, out_dists, err);
 }
 
+// The device contexts 1 .. devices - 1 (created on first use; more contexts than GPUs share them round robin --
+// a rehearsal of the sharded path on a box with fewer GPUs), and with `clone` their rows + graph mirror brought up
+// to date from the primary, every replica copying on its own stream at the same time.
+bool HnswIndex::ensure_replicas(bool clone, std::string &err)
+{
+    const int n = p_.devices;
+    if ((int)replicas_.size() != n - 1) {
+        replicas_.clear();
+        const int ndev = std::max(1, hnswdev_device_count());
+        for (int g = 1; g < n; ++g) {
+            Device *d = Device::create((device_ordinal_ + g) % ndev, dim_, metric_, capacity_);
+            if (!d) { err = get_dev_error(); replicas_.clear(); return false; }
+            d->set_profiling(profiling_);
+            replicas_.emplace_back(d);
+        }
+        replica_epoch_.assign((size_t)std::max(0, n - 1), 0);
+    }
+    if (!clone) return true;
+    std::vector<int> stale;
+    for (int g = 1; g < n; ++g) if (replica_epoch_[(size_t)g - 1] != graph_epoch_) stale.push_back(g);
+    if (stale.empty()) return true;
+    std::vector<std::string> errs(stale.size());
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < stale.size(); ++i)
+        th.emplace_back([&, i] { if (!replicas_[(size_t)stale[i] - 1]->clone_from(dev_.get(), dev_pool_len_)) errs[i] = get_dev_error().empty() ? "replica copy failed" : get_dev_error(); });
+    for (auto &t : th) t.join();
+    for (size_t i = 0; i < stale.size(); ++i) {
+        if (!errs[i].empty()) { err = errs[i]; return false; }
+        replica_epoch_[(size_t)stale[i] - 1] = graph_epoch_;
+    }
+    return true;
+}
+
 int HnswIndex::set_resident_queries(const float *queries, int count, int dim, std::string &err)
 {
     if (!ensure_dim(dim, err)) return -1;
     Tick t(g_pt.set_queries);
+    sharded_resident_ = false;
+    const int n = p_.devices;
+    if (n > 1 && p_.device_traversal && count >= n) { // every context takes its shard (uploaded side by side)
+        if (!ensure_replicas(false, err)) return -1;
+        shard_lo_.assign((size_t)n + 1, 0);
+        for (int g = 0; g <= n; ++g) shard_lo_[(size_t)g] = (long long)count * g / n;
+        std::vector<std::string> errs((size_t)n);
+        std::vector<std::thread> th;
+        for (int g = 0; g < n; ++g)
+            th.emplace_back([&, g] {
+                const long long lo = shard_lo_[(size_t)g], hi = shard_lo_[(size_t)g + 1];
+                if (!context(g)->set_queries(queries + (size_t)lo * (size_t)dim, (int)(hi - lo))) errs[(size_t)g] = get_dev_error().empty() ? "set_queries failed" : get_dev_error();
+            });
+        for (auto &t2 : th) t2.join();
+        for (const std::string &e : errs) if (!e.empty()) { err = e; resident_queries_ = 0; return -1; }
+        sharded_resident_ = true;
+        resident_queries_ = count;
+        return 0;
+    }
     if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; }
     resident_queries_ = count;
     return 0;
@@ -1399,9 +1457,49 @@ int HnswIndex::knn_query_resident(int k, int *out_ids, float *out_dists, std::st
         for (long long j = 0; j < (long long)count * std::max(k, 0); ++j) { out_ids[j] = -1; out_dists[j] = std::numeric_limits<float>::quiet_NaN(); }
         return 0;
     }
-    if (p_.device_traversal && dev_->traversal_fits(std::max(p_.min_nn, k), false, p_.max_edges))
-        return knn_query_device(nullptr, count, k, out_ids, out_dists, err);
+    const bool fits = p_.device_traversal && dev_->traversal_fits(std::max(p_.min_nn, k), false, p_.max_edges);
+    if (sharded_resident_) {
+        if (fits) return knn_query_sharded(k, out_ids, out_dists, err);
+        // the host traversal runs on the primary alone: it needs the whole set there
+        for (int g = 1; g < p_.devices; ++g)
+            if (!dev_->adopt_queries(context(g), 0, shard_lo_[(size_t)g + 1] - shard_lo_[(size_t)g], shard_lo_[(size_t)g], count)) { err = get_dev_error(); return -1; }
+        sharded_resident_ = false;
+    }
+    if (fits) return knn_query_device(nullptr, count, k, out_ids, out_dists, err);
     return knn_query_lockstep(nullptr, count, k, out_ids, out_dists, err);
+}
+
+// One traversal launch per context, side by side: context g answers its shard of the resident queries on its replica
+// and writes rows [lo_g, hi_g) of the caller's arrays.  Each query's traversal is what the single-device path runs, so
+// the answer is bit for bit the same.  Whatever a kernel hands back is answered by the exact host traversal on the primary.
+int HnswIndex::knn_query_sharded(int k, int *out_ids, float *out_dists, std::string &err)
+{
+    if (!sync_graph(err)) return -1;
+    if (!ensure_replicas(true, err)) return -1;
+    const int n = p_.devices, count = resident_queries_;
+    const int ef = std::max(p_.min_nn, k);
+    const int ep = graph_.entry, top = graph_.top_layer();
+    std::vector<int> flag((size_t)count);
+    std::vector<std::string> errs((size_t)n);
+    std::vector<std::thread> th;
+    { Tick t(g_pt.query_dev);
+    for (int g = 0; g < n; ++g)
+        th.emplace_back([&, g] {
+            const long long lo = shard_lo_[(size_t)g], hi = shard_lo_[(size_t)g + 1];
+            const int cnt = (int)(hi - lo);
+            std::vector<SearchJob> jobs((size_t)cnt);
+            for (int i = 0; i < cnt; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0, -1, 0};
+            if (cnt > 0 && !context(g)->search_batch(jobs.data(), cnt, ef, k, out_ids + (size_t)lo * k, out_dists + (size_t)lo * k, flag.data() + lo))
+                errs[(size_t)g] = get_dev_error().empty() ? "search_batch failed" : get_dev_error();
+        });
+    for (auto &t2 : th) t2.join(); }
+    for (const std::string &e : errs) if (!e.empty()) { err = e; return -1; }
+    std::vector<int> redo;
+    for (int i = 0; i < count; ++i) if (flag[(size_t)i]) redo.push_back(i);
+    if (redo.empty()) return 0;
+    for (int g = 1; g < n; ++g) // the exact host traversal names queries by their global index on the primary
+        if (!dev_->adopt_queries(context(g), 0, shard_lo_[(size_t)g + 1] - shard_lo_[(size_t)g], shard_lo_[(size_t)g], count)) { err = get_dev_error(); return -1; }
+    return knn_query_lockstep(redo.data(), (int)redo.size(), k, out_ids, out_dists, err);
 }
 
 // Host lock-step range search for the queries listed in `which` (nullptr: all `count` queries).
@@ -1501,6 +1599,7 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
     if (!p_.allow_removals) { err = "System.InvalidOperationException: Removals are disabled in this index instance."; return -1; } // :85-86
     if (count <= 0) return 0;
     if (failed(err)) return -1;
+    ++graph_epoch_;
     if (!refresh_host_lists(err)) return -1;
     {
         std::vector<unsigned char> listed((size_t)graph_.length, 0); // duplicates in O(count)
@@ -1869,6 +1968,7 @@ int HnswIndex::import_nodes(const float *rows, int n, int dim, const int *levels
 {
     if (failed(err)) return -1;
     in_valid_ = false;
+    ++graph_epoch_;
     if (!rows || !levels || n <= 0 || dim <= 0) { err = "System.ArgumentException: hnsw_mi355x_import_nodes: bad argument"; return -1; }
     if (graph_.length != 0) { err = "System.InvalidOperationException: hnsw_mi355x_import_nodes: the index already holds items"; return -1; }
     if (entry_point < 0 || entry_point >= n) { err = "System.ArgumentException: hnsw_mi355x_import_nodes: entry point outside the nodes"; return -1; }
@@ -1890,6 +1990,7 @@ int HnswIndex::import_edges(int layer, const int *counts, const int *edges, int 
 {
     if (failed(err)) return -1;
     in_valid_ = false;
+    ++graph_epoch_;
     if (!counts || !edges || layer < 0 || stride < 1) { err = "System.ArgumentException: hnsw_mi355x_import_edges: bad argument"; return -1; }
     if (graph_.length <= 0) { err = "System.InvalidOperationException: hnsw_mi355x_import_edges: call hnsw_mi355x_import_nodes first"; return -1; }
     if (!refresh_host_lists(err)) return -1;

@@ -32,6 +32,7 @@ struct Params {
     int search_slots = 16384;
     int host_threads = 0;    // 0: min(hardware threads, 16)
     int device_traversal = 1; // 1: graph-resident search kernel; 0: host lock-step traversal
+    int devices = 0;          // 0: HNSW_MI355X_DEVICES or 1; > 1: KnnQuery shards its queries over this many device contexts (replicas of rows + graph)
 };
 
 class HnswIndex {
@@ -68,6 +69,8 @@ public:
 
     int count() const { return graph_.count; }
     int resident_count() const { return resident_queries_; }
+    int device_count() const { return p_.devices; }
+    Device *device_at(int g) { return g == 0 ? dev_.get() : (g - 1 < (int)replicas_.size() ? replicas_[(size_t)g - 1].get() : nullptr); }
     int dim() const { return dim_; }
     // The host copy of the graph.  After a device-linked Add the neighbour lists live in the HBM
     // mirror only and are fetched back here on demand.
@@ -76,7 +79,7 @@ public:
     uint64_t graph_hash();
     void set_insert_batch(int v) { p_.insert_batch = v; }
     void exact_window_stats(uint64_t out[4]) const { out[0] = xw_rounds_; out[1] = xw_searches_; out[2] = xw_alone_; out[3] = xw_linked_; }
-    void set_profiling(bool on) { profiling_ = on; if (dev_) dev_->set_profiling(on); }
+    void set_profiling(bool on) { profiling_ = on; if (dev_) dev_->set_profiling(on); for (auto &r : replicas_) r->set_profiling(on); }
 
     // One caller at a time per index: the reference promises that operations of one type may
     // overlap on an index (/root/reference/README.md:64-65; BatchKnnQuery / Add(List) are
@@ -125,6 +128,19 @@ private:
     bool link_half_device(const std::vector<int> &bid, const Selection &sel, std::string &err);
     bool link_prefix_begin(const std::vector<int> &bid, const Selection &sel, int set, std::string &err);
     bool sync_graph(std::string &err);
+    // ---- query sharding over several devices inside one process (hnsw_mi355x_set_devices) ----
+    // BatchKnnQuery is a Parallel.For over independent read-only searches (HNSWIndex.cs:129-137): with n contexts,
+    // context g answers queries [g nq / n, (g + 1) nq / n) on its own replica of the rows and the graph mirror and
+    // writes its slice of the caller's arrays.  The primary (dev_) builds; replicas are brought up to date device to
+    // device (Device::clone_from) when the graph has changed since they were last used.
+    std::vector<std::unique_ptr<Device>> replicas_; // contexts 1 .. devices - 1
+    std::vector<uint64_t> replica_epoch_;
+    uint64_t graph_epoch_ = 1;                       // bumped by everything that changes rows or lists
+    std::vector<long long> shard_lo_;                // resident query set: shard bounds (devices + 1 entries)
+    bool sharded_resident_ = false;
+    Device *context(int g) { return g == 0 ? dev_.get() : replicas_[(size_t)g - 1].get(); }
+    bool ensure_replicas(bool clone, std::string &err);
+    int knn_query_sharded(int k, int *out_ids, float *out_dists, std::string &err);
     bool refresh_host_lists(std::string &err);
     int knn_query_device(const float *queries, int count, int k, int *out_ids, float *out_dists, std::string &err);
     int knn_query_lockstep(const int *which, int count, int k, int *out_ids, float *out_dists, std::string &err);

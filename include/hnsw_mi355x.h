@@ -123,6 +123,19 @@ int hnsw_mi355x_set_host_threads(int threads);
  * 0 = traversal on the host, distances batched to the device step by step.  Same results. */
 int hnsw_mi355x_set_device_traversal(int enabled);
 
+/* Pending: number of device contexts of the next index (default: HNSW_MI355X_DEVICES, else 1).  With n > 1,
+ * hnsw_knn_query -- BatchKnnQuery, a Parallel.For over independent searches, src/HNSWIndex/HNSWIndex.cs:129-137 via
+ * bindings/HNSWIndex.Native/HNSWIndexExports.cs:119-149 -- shards its queries over n GPUs of the node inside this
+ * one process: context g (device ordinal hnsw_mi355x_set_device + g, modulo the devices present) holds a replica of
+ * the rows and of the graph mirror, copied device to device (hipMemcpyPeerAsync over xGMI) whenever the graph has
+ * changed, answers queries [g nq / n, (g + 1) nq / n) and writes that slice of the caller's out arrays.  Same ids and
+ * distance bits as one device.  Add / Remove / RangeQuery run on the first context. */
+int hnsw_mi355x_set_devices(int n);
+int hnsw_mi355x_device_count(void *handle);
+/* hnswdev_stats of context `context` (0 = the primary). */
+struct hnswdev_stats;
+int hnsw_mi355x_get_stats_at(void *handle, int context, struct hnswdev_stats *out);
+
 /* Measurement aid: hnsw_mi355x_set_queries uploads a query set (count x dim) once; every later
  * hnsw_mi355x_knn_query_resident(k) is hnsw_knn_query on that set with the inputs already in HBM
  * (out arrays: count x k). */
@@ -216,6 +229,7 @@ typedef struct hnswdev_stats {
     uint64_t range_launches, range_evals, range_timed_launches, range_timed_evals;
     double range_kernel_ms;
     uint64_t range_handbacks;       /* range traversals handed back (more results than a wave's list holds, visited table full) */
+    uint64_t replica_bytes;         /* bytes this context received from another one (rows + graph mirror of a replica) */
 } hnswdev_stats;
 
 /* All return 0 on success, < 0 on error (message via hnswdev_ctx_last_error / hnswdev_last_error).

@@ -1,0 +1,94 @@
+"""GPU tier: query sharding over several device contexts INSIDE the library (hnsw_mi355x_set_devices) -- what a C#
+host reaches through P/Invoke of the unchanged hnsw_knn_query (/root/reference/bindings/HNSWIndex.Native/
+HNSWIndexExports.cs:119-149 -> BatchKnnQuery, /root/reference/src/HNSWIndex/HNSWIndex.cs:129-137).  The GPU box
+has one GPU: contexts beyond the devices present share them, which rehearses replica copies (device to device),
+shard bounds, concurrent launches from several host threads and the hand-back path; ids and distance bits must
+equal the single-context answer and the oracle's."""
+import numpy as np
+import pytest
+
+import oracle
+from common import normalize_f32, uniform
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Index():
+    import hnswindex
+    assert hnswindex.net_amd.lib.hnswdev_device_count() > 0, "GPU tier needs a HIP device"
+    return hnswindex.Index
+
+
+def _index(Index, x, metric, devices, **kw):
+    ix = Index(x.shape[1], metric)
+    ix.set_collection_size(kw.get("collection", x.shape[0])); ix.set_min_nn(kw.get("min_nn", 32)); ix.set_devices(devices)
+    ix.add(x)
+    return ix
+
+
+@pytest.mark.parametrize("metric", ["sq_euclid", "cosine", "ucosine", "sq_euclid_i8"])
+@pytest.mark.parametrize("devices", [1, 2, 3])
+def test_sharded_answers_equal_one_context_and_the_oracle(Index, metric, devices):
+    n, dim = 6000, 64
+    x, q = uniform(n, dim, 3), uniform(1001, dim, 4)          # 1001: shards of unequal size
+    if metric == "ucosine":
+        x, q = normalize_f32(x), normalize_f32(q)
+    ix = _index(Index, x, metric, devices)
+    ids, d = ix.knn_query(q, 10)
+    ref = oracle.OracleIndex(dim, metric, min_nn=32, collection_size=n)
+    ref.import_graph(x, ix.levels(), ix.entry_point, [ix.export_edges(l, 34 if l == 0 else 18) for l in range(int(ix.levels().max()) + 1)])
+    rids, rd = ref.knn_query(q, 10)
+    assert (ids == rids).all() and d.tobytes() == rd.tobytes()
+    if devices > 1:
+        assert ix.stats_at(1)["replica_bytes"] > 0 and ix.stats_at(1)["search_launches"] >= 1
+        # fewer queries than contexts: answered by the primary alone
+        a, b = ix.knn_query(q[:1], 5)
+        assert (a == rids[:1, :5]).all()
+
+
+def test_replicas_follow_adds_and_removals(Index):
+    n, dim = 4000, 32
+    x, q = uniform(n + 1500, dim, 8), uniform(700, dim, 9)
+    one = _index(Index, x[:n], "sq_euclid", 1, collection=n + 1500)
+    two = _index(Index, x[:n], "sq_euclid", 2, collection=n + 1500)
+    for ix in (one, two):
+        ix.knn_query(q, 10)                                  # replicas exist and are current
+        ix.add(x[n:n + 1000])                                # ... and stale again
+    a, b = one.knn_query(q, 10), two.knn_query(q, 10)
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes() and (a[0] >= n).any()
+    rm = np.arange(0, n, 5, dtype=np.int32)
+    for ix in (one, two):
+        ix.remove(rm)
+        ix.add(x[n + 1000:])                                 # slot reuse rewrites rows: replicas are rebuilt
+    a, b = one.knn_query(q, 10), two.knn_query(q, 10)
+    assert one.graph_hash() == two.graph_hash()
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
+    r1, r2 = one.range_query(q[:50], float(np.median(a[1][:, 3]))), two.range_query(q[:50], float(np.median(a[1][:, 3])))
+    assert all(u.tolist() == v.tolist() for u, v in zip(r1[0], r2[0]))
+    a, b = one.knn_query(q, 7), two.knn_query(q, 7)          # range_query replaced the resident set on the primary
+    assert (a[0] == b[0]).all()
+
+
+def test_hand_backs_are_answered_on_the_primary(Index):
+    # NaN / -0 distances make the kernels hand jobs back to the exact host traversal, which names queries by their
+    # global index on the primary: the shards are gathered there first
+    n, dim = 1500, 16
+    x = uniform(n, dim, 5)
+    q = uniform(300, dim, 6)
+    q[7, 3] = np.nan; q[150, 0] = np.nan; q[299, 5] = np.nan     # one in every shard of three
+    one, three = _index(Index, x, "sq_euclid", 1), _index(Index, x, "sq_euclid", 3)
+    a, b = one.knn_query(q, 10), three.knn_query(q, 10)
+    assert (a[0] == b[0]).all()
+    assert a[1].view(np.uint32)[~np.isnan(a[1])].tobytes() == b[1].view(np.uint32)[~np.isnan(b[1])].tobytes()
+    assert three.stats()["search_overflows"] + three.stats_at(1)["search_overflows"] + three.stats_at(2)["search_overflows"] >= 3
+
+
+def test_resident_set_is_sharded_too(Index):
+    n, dim = 5000, 48
+    x, q = uniform(n, dim, 13), uniform(2048, dim, 14)
+    one, two = _index(Index, x, "sq_euclid", 1), _index(Index, x, "sq_euclid", 2)
+    one.set_resident_queries(q); two.set_resident_queries(q)
+    for k in (10, 3):
+        a, b = one.knn_query_resident(k), two.knn_query_resident(k)
+        assert a[0].shape == (2048, k) and (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
