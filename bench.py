@@ -3,16 +3,19 @@
 bench.py -- BASELINE.json metric on MI355X: batched KnnQuery/sec and Add/sec on
 1M x 128 float32, sq_euclid, M=16, efConstruction=200, efSearch=128, k=10, with recall@10.
 
-A "step" is one pass of the hot path over one batch of synthetic queries: every rank runs one
-batched KnnQuery on its shard of the batch, then one all-gather of the per-shard top-k (RCCL) when
-N > 1.  Vector matrix, graph and query set are resident in HBM before the timed region (`value`);
-the same step through the reference's own `hnsw_knn_query` export, which is handed host buffers
-every call, is reported beside it (`boundary_call_queries_per_sec`).  Timed: exactly K steps between
-(barrier + cuda.synchronize) pairs, max over ranks.  One JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of synthetic queries THROUGH THE REFERENCE'S OWN EXPORT
+`hnsw_knn_query` (host buffers in, host buffers out, a different query set every step -- the sets rotate):
+every rank runs it on its shard of the batch, then one all-gather of the per-shard top-k (RCCL) when N > 1.
+Vector matrix and graph are resident in HBM before the timed region; the queries are not (that is the boundary
+a drop-in caller sees).  The same step with the query set already resident in HBM is reported beside it
+(`resident_queries_per_sec`).  Timed: exactly K steps between (barrier + cuda.synchronize) pairs, max over ranks.
+One JSON line on rank 0.  `--sharding native`: ONE process, the library itself shards the call over N GPUs.
 
-The Add half of the metric is reported four ways (all on the same 1M index):
+The Add half of the metric is reported five ways (all on the same 1M index):
   add_per_sec            the build: hnsw_add of the whole set, default schedule (snapshot batches)
   add_modes.sequential   B = 1: the reference's HNSWIndex.Add(item), one call per item
+  add_modes.exact_window the SAME graph as B = 1 (the only Add whose graph the reference defines) through
+                         speculative windows with read-set validation, one call for the whole sample
   add_modes.bounded      B = host-core count: what a Parallel.For on that host can hold in flight
   add_modes.batched      one large batch on the built index
 each beside the CPU restatement running the SAME schedule on the same vectors (graph hashes compared),
@@ -36,7 +39,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-PROFILE_ROUND = "r2"
+PROFILE_ROUND = "r3"
 
 
 def parse():
@@ -61,6 +64,12 @@ def parse():
     p.add_argument("--recall-queries", type=int, default=1000)
     p.add_argument("--cpu-queries", type=int, default=4000, help="bounded cpu_baseline sample (all-cores leg)")
     p.add_argument("--seq-adds", type=int, default=2000, help="sample of sequential (B=1) inserts into the built index, GPU and CPU")
+    p.add_argument("--window-adds", type=int, default=8000, help="sample inserted through the exact window (same graph as B=1), GPU; the CPU adds them one at a time")
+    p.add_argument("--window", type=int, default=64, help="items per speculative window of the exact-window Add")
+    p.add_argument("--query-sets", type=int, default=4, help="distinct query sets the timed steps rotate through (fresh host buffers every step)")
+    p.add_argument("--sharding", choices=["ranks", "native"], default="ranks",
+                   help="N > 1: ranks = one process per GPU, torch.distributed over RCCL (what the driver launches); native = ONE process, "
+                        "hnsw_knn_query shards over N device contexts inside the library (hnsw_mi355x_set_devices)")
     p.add_argument("--bounded-adds", type=int, default=4096, help="sample inserted in calls of B = host cores, GPU and CPU")
     p.add_argument("--batched-adds", type=int, default=32768, help="sample inserted as one batch, GPU and CPU (all cores)")
     p.add_argument("--recall-study-n", type=int, default=32768, help="index size of the bounded-concurrency recall comparison (0 = skip)")
@@ -120,9 +129,10 @@ def recall_of(x, q, k, metric, got_ids):
     return float(np.mean([len(set(gt[i]) & set(got_ids[i])) / k for i in range(q.shape[0])]))
 
 
-def new_index(a, dev_index, capacity, insert_batch):
+def new_index(a, dev_index, capacity, insert_batch, devices=1):
     from hnswindex import Index
     ix = Index(a.dim, a.metric)
+    ix.set_devices(devices)
     ix.set_collection_size(capacity)       # avoid the doubling resize (GraphData.cs:98-111)
     ix.set_max_edges(a.max_edges)
     ix.set_max_candidates(a.ef_construction)
@@ -151,12 +161,16 @@ def relaunch_for_gpus(a):
 
 def main():
     a = parse()
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+    native = a.sharding == "native" and a.gpus > 1
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not native:
         relaunch_for_gpus(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
+    ndev_native = a.gpus if native else 1
+    if native and world != 1:
+        raise SystemExit("bench.py: --sharding native is one process (no launcher): python bench.py --gpus N --sharding native")
+    if world != a.gpus and not native:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     import torch
@@ -168,6 +182,9 @@ def main():
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
+    if native and torch.cuda.device_count() < a.gpus and os.environ.get("BENCH_ALLOW_SHARED_GPUS") != "1":
+        raise SystemExit(f"bench.py: --sharding native --gpus {a.gpus} but {torch.cuda.device_count()} GPUs visible "
+                         "(BENCH_ALLOW_SHARED_GPUS=1 lets contexts share a GPU: a rehearsal, not a measurement)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
@@ -182,7 +199,7 @@ def main():
 
     # ---------------- setup (untimed): data, index build, resident queries ----------------
     x = make_data(a.n, a.dim, 65537, a.metric, a.data)
-    extra_total = a.seq_adds + a.bounded_adds + a.batched_adds
+    extra_total = a.seq_adds + a.window_adds + a.bounded_adds + a.batched_adds
     # process warm-up (untimed): a throw-away index loads the library's code objects and creates the HIP
     # context once -- 0.15 s on the first launch of every kernel family, which is not Add throughput
     if not a.no_process_warmup:
@@ -190,7 +207,7 @@ def main():
         warm.add(x[:4096])
         warm.knn_query(x[:64], a.k)
         del warm
-    ix = new_index(a, dev_index, a.n + extra_total, a.insert_batch)
+    ix = new_index(a, dev_index, a.n + extra_total, a.insert_batch, ndev_native)
     ix.set_profiling(True)                 # HIP events around the build kernels too (roofline_add)
     barrier()
     t0 = time.perf_counter()
@@ -218,46 +235,50 @@ def main():
         dist.all_gather_into_tensor(hs, h63)
         replicas_identical = bool((hs == hs[0]).all().item())
 
-    nq_total = a.nq * world if a.scaling == "weak" else a.nq
-    q_all = make_data(nq_total, a.dim, 65538, a.metric, a.data)  # queries distinct from the base vectors
-
-    # this rank's shard of the query set is uploaded ONCE, before the timed region: the timed steps
-    # start with their inputs resident in HBM (per-step PCIe traffic: the k ids + distances back)
+    nshards = world * ndev_native
+    nq_total = a.nq * nshards if a.scaling == "weak" else a.nq
+    # R distinct query sets (all distinct from the base vectors): every timed step hands the export fresh host buffers
+    R = max(1, a.query_sets)
+    q_sets = [make_data(nq_total, a.dim, 65538 + 1000 * r, a.metric, a.data) for r in range(R)]
+    q_all = q_sets[0]
     lo, hi = dmod.shard_bounds(nq_total, world, rank)
-    ix.set_resident_queries(q_all[lo:hi])
+    per_gpu = (hi - lo) // ndev_native
 
-    # one all-gather of the packed top-k leaves the full result on every GPU; rank 0 copies it to its
-    # host (pinned buffer, returned as views) -- SURVEY.md 8e
-    def step():
+    # THE STEP: the reference's export hnsw_knn_query (HNSWIndexExports.cs:119-149) on host buffers; with several ranks one
+    # all-gather of the packed top-k leaves the full result on every GPU and rank 0 copies it to its host -- SURVEY.md 8e
+    def step(s):
+        return dmod.knn_query_sharded(ix.knn_query, q_sets[s % R], a.k, dst_rank=0, copy=False)
+
+    def step_resident():  # the same work with this rank's shard of set 0 uploaded once, before the timed region
         return dmod.knn_query_sharded(lambda qs, k: ix.knn_query_resident(k), q_all, a.k, dst_rank=0, copy=False)
 
-    def step_boundary():  # the same work through hnsw_knn_query: queries handed over as host buffers every call
-        return dmod.knn_query_sharded(ix.knn_query, q_all, a.k, dst_rank=0, copy=False)
-
-    for _ in range(a.warmup):
-        step()
+    for s_ in range(a.warmup):
+        step(s_)
     ix.set_profiling(True)                 # HIP events around every traversal launch, on its stream
     ix.reset_stats()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        res_ids, res_d = step()
+    for s_ in range(a.steps):
+        res_ids, res_d = step(a.warmup + s_)
     barrier()
     dt = time.perf_counter() - t0
+    last_set = (a.warmup + a.steps - 1) % R
     if res_ids is not None:  # views of the exchange buffer: keep them past the next call
         res_ids, res_d = np.array(res_ids), np.array(res_d)
     st = ix.stats()
+    st_all = [ix.stats_at(g) for g in range(ndev_native)] if native else [st]
     ix.set_profiling(False)
-    step_boundary()
+    ix.set_resident_queries(q_all[lo:hi])
+    step_resident()
     barrier()
     t0 = time.perf_counter()
     nb_steps = max(2, min(5, a.steps))
     for _ in range(nb_steps):
-        step_boundary()
+        step_resident()
     barrier()
-    dt_boundary = (time.perf_counter() - t0) / nb_steps
+    dt_resident = (time.perf_counter() - t0) / nb_steps
     small = None
-    if world == 1 and 0 < a.small_batch < hi - lo:  # the same step on C4's per-GPU shard size: launch fill / tail effects
+    if world == 1 and not native and 0 < a.small_batch < hi - lo:  # the same step on C4's per-GPU shard size: launch fill / tail effects
         ix.set_resident_queries(q_all[:a.small_batch])
         ix.knn_query_resident(a.k)
         ix.set_profiling(True)
@@ -271,13 +292,17 @@ def main():
         ss = ix.stats()
         ix.set_profiling(False)
         ev_s, ms_s = (ss["search_timed_evals"], ss["search_kernel_ms"]) if a.traversal == "device" else (ss["timed_evals"], ss["kernel_ms"])
-        small = {"queries_per_call": a.small_batch, "queries_per_sec": round(a.small_batch * 10 / dts, 1),
+        t0 = time.perf_counter()
+        for r_ in range(10):
+            ix.knn_query(q_sets[r_ % R][:a.small_batch], a.k)
+        dtb = time.perf_counter() - t0
+        small = {"queries_per_call": a.small_batch, "queries_per_sec": round(a.small_batch * 10 / dtb, 1),
+                 "resident_queries_per_sec": round(a.small_batch * 10 / dts, 1),
                  "roofline_frac": round(ev_s * ss["row_bytes"] / (ms_s / 1e3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_s > 0 else None}
-        ix.set_resident_queries(q_all[lo:hi])
     if world > 1:
-        t = torch.tensor([dt, dt_boundary], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([dt, dt_resident], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_boundary = float(t[0].item()), float(t[1].item())
+        dt, dt_resident = float(t[0].item()), float(t[1].item())
 
     if rank != 0:
         if world > 1:
@@ -287,10 +312,13 @@ def main():
 
     # ---------------- rank 0: quality, rooflines, CPU baseline, Add modes ----------------
     nrec = min(a.recall_queries, nq_total)
-    recall = recall_of(x, q_all[:nrec], a.k, a.metric, res_ids)
+    q_last = q_sets[last_set]              # the set the last timed step answered
+    recall = recall_of(x, q_last[:nrec], a.k, a.metric, res_ids)
 
     if a.traversal == "device":
-        kname, t_evals, t_launches, k_ms = "graph_search_kernel", st["search_timed_evals"], st["search_timed_launches"], st["search_kernel_ms"]
+        # native sharding: the contexts run side by side -- evaluations of all, launches and kernel time of the slowest one
+        kname, t_evals, t_launches, k_ms = ("graph_search_kernel", sum(c["search_timed_evals"] for c in st_all) / len(st_all),
+                                            st["search_timed_launches"], max(c["search_kernel_ms"] for c in st_all))
     else:
         kname, t_evals, t_launches, k_ms = "slot_distance_kernel", st["timed_evals"], st["timed_launches"], st["kernel_ms"]
     kernel_s = k_ms / 1e3
@@ -301,7 +329,7 @@ def main():
         pm = json.loads((ROOT / "profiles" / f"{PROFILE_ROUND}_pmc_traffic.json").read_text())
         w = pm["workload"]
         if a.traversal == "device" and (w["n"], w["dim"], w["nq"], w["ef_search"], w["k"], w["max_edges"]) == \
-                (a.n, a.dim, hi - lo, a.ef_search, a.k, a.max_edges) and a.metric == "sq_euclid":
+                (a.n, a.dim, per_gpu, a.ef_search, a.k, a.max_edges) and a.metric == "sq_euclid":
             traffic = round(pm["traffic_bytes_per_launch"])
     except Exception:
         pass
@@ -337,7 +365,8 @@ def main():
     extra = rng_x.random((max(extra_total, 1), a.dim), dtype=np.float32)
     if a.metric == "ucosine":
         extra = (extra / np.sqrt((extra * extra).sum(axis=1, dtype=np.float32, keepdims=True))).astype(np.float32)
-    e_seq, e_bnd, e_bat = extra[:a.seq_adds], extra[a.seq_adds:a.seq_adds + a.bounded_adds], extra[a.seq_adds + a.bounded_adds:extra_total]
+    o1 = a.seq_adds; o2 = o1 + a.window_adds; o3 = o2 + a.bounded_adds
+    e_seq, e_win, e_bnd, e_bat = extra[:o1], extra[o1:o2], extra[o2:o3], extra[o3:extra_total]
     B = cores  # bounded concurrency: what a Parallel.For over T = cores items holds in flight (HNSWIndex.cs:70-78)
 
     cpu = None
@@ -355,10 +384,10 @@ def main():
         ref.rng_skip(a.n)  # the product's level generator has drawn once per node
         same_graph = ref.graph_hash() == my_hash
         n1 = min(500, nq_total)
-        t0 = time.perf_counter(); c_ids1, c_d1 = ref.knn_query(q_all[:n1], a.k, threads=1); t1 = time.perf_counter() - t0
+        t0 = time.perf_counter(); c_ids1, c_d1 = ref.knn_query(q_last[:n1], a.k, threads=1); t1 = time.perf_counter() - t0
         nm = min(a.cpu_queries, nq_total)
         ref.reset_n_eval()
-        t0 = time.perf_counter(); c_ids, c_d = ref.knn_query(q_all[:nm], a.k, threads=cores); tm = time.perf_counter() - t0
+        t0 = time.perf_counter(); c_ids, c_d = ref.knn_query(q_last[:nm], a.k, threads=cores); tm = time.perf_counter() - t0
         cpu_evals_per_query = ref.n_eval / nm
         parity_ids = bool((c_ids == res_ids[:nm]).all())
         parity_d = bool(c_d.tobytes() == np.ascontiguousarray(res_d[:nm]).tobytes())
@@ -374,6 +403,8 @@ def main():
         if not a.no_add_modes:
             # the three Add schedules on the CPU, same vectors and same order as the GPU legs below
             t0 = time.perf_counter(); ref.add(e_seq); cpu_add["sequential"] = (a.seq_adds / (time.perf_counter() - t0), 1, ref.graph_hash())
+            if a.window_adds:  # the exact window builds the SEQUENTIAL graph: the CPU's same schedule is one item after the other
+                t0 = time.perf_counter(); ref.add(e_win); cpu_add["exact_window"] = (a.window_adds / (time.perf_counter() - t0), 1, ref.graph_hash())
             t0 = time.perf_counter()
             for i in range(0, a.bounded_adds, B):
                 ref.add_batched(e_bnd[i:i + B], B, threads=cores)
@@ -406,8 +437,26 @@ def main():
                 d["reference_evaluations"] = int(cpu_batched_evals)  # Distance() calls of the reference's loops for the same batch, same graph
                 d["reference_evaluations_per_row_fetched"] = round(cpu_batched_evals / max(1, fetched), 3)
             return d
+        def window_leg():
+            ix.set_insert_batch_live(-a.window)
+            w0 = ix.exact_window_stats()
+            d = leg("exact_window", e_win, max(1, a.window_adds),
+                    f"the graph of B=1 (HNSWIndex.Add(item) per item, HNSWIndex.cs:55-65) through speculative windows of {a.window} items: searches on "
+                    "one snapshot with read-set validation, valid prefix linked in order, the rest searched again (DESIGN.md 4.2)")
+            w1 = ix.exact_window_stats()
+            ix.set_insert_batch_live(a.insert_batch)
+            rounds, searches = w1["rounds"] - w0["rounds"], w1["searches"] - w0["searches"]
+            d.update({"window": a.window, "rounds": rounds, "items_per_round": round(a.window_adds / max(1, rounds), 2),
+                      "ms_per_round": round(1e3 * a.window_adds / d["adds_per_sec"] / max(1, rounds), 3),
+                      "searches_per_item": round(searches / max(1, a.window_adds), 3),
+                      "replay_rate": round(max(0, searches - a.window_adds) / max(1, a.window_adds), 3),
+                      "items_inserted_alone": w1["alone"] - w0["alone"]})
+            if "cpu_adds_per_sec" in d:
+                d["speedup_vs_one_cpu_core_same_graph"] = round(d["adds_per_sec"] / d["cpu_adds_per_sec"], 2)
+            return d
         add_modes = {
             "sequential": leg("sequential", e_seq, 1, "B=1: HNSWIndex.Add(item) one at a time (HNSWIndex.cs:55-65), the reference-exact mode"),
+            **({"exact_window": window_leg()} if a.window_adds and a.traversal == "device" else {}),
             "bounded": leg("bounded", e_bnd, B, f"B={B} (= host cores): batches a Parallel.For over {B} threads can hold in flight (HNSWIndex.cs:70-78)"),
             "batched": leg("batched", e_bat, max(1, a.batched_adds), f"one snapshot batch of {a.batched_adds} into the built index"),
         }
@@ -451,26 +500,59 @@ def main():
             "equivalent_GBps_at_one_row_per_evaluation": round(roofline_add["achieved"] * ratio, 1),
             "note": "the reference reads one candidate row per Distance() call; this path does the same evaluations on fewer reads (rows reused from LDS); `frac` counts reads, not evaluations"}
 
+    # How many queries a call needs before the GPU beats the host (a single traversal is a chain of dependent steps on one
+    # wavefront: tiny calls are latency-bound and lose to a CPU core)
+    crossover = None
+    if world == 1 and not native and cpu is not None:
+        sizes, rates = [1, 4, 16, 64, 256, 1024, 4096], []
+        for b in sizes:
+            reps = max(3, min(40, 2048 // b))
+            ix.knn_query(q_sets[0][:b], a.k)
+            t0 = time.perf_counter()
+            for r_ in range(reps):
+                off = (r_ * b) % max(1, nq_total - b)
+                ix.knn_query(q_sets[r_ % R][off:off + b], a.k)
+            rates.append(round(b * reps / (time.perf_counter() - t0), 1))
+
+        def first_above(level):
+            for i, (b, r_) in enumerate(zip(sizes, rates)):
+                if r_ > level:
+                    if i == 0:
+                        return b
+                    b0, r0 = sizes[i - 1], rates[i - 1]  # log-linear between the two measured call sizes
+                    f = (np.log(level) - np.log(r0)) / max(1e-9, np.log(r_) - np.log(r0))
+                    return int(round(float(np.exp(np.log(b0) + f * (np.log(b) - np.log(b0))))))
+            return None
+        crossover = {"queries_per_call": sizes, "gpu_queries_per_sec": rates,
+                     "cpu_one_thread_queries_per_sec": cpu["single_thread_queries_per_s"], f"cpu_{cores}_threads_queries_per_sec": cpu["value"],
+                     "crossover_vs_one_cpu_thread": first_above(cpu["single_thread_queries_per_s"]),
+                     f"crossover_vs_{cores}_cpu_threads": first_above(cpu["value"]),
+                     "note": "hnsw_knn_query calls of that many queries, fresh host buffers each; below the crossover a call is faster on the host"}
+
     qps = nq_total * a.steps / dt
     shape = (a.dim, a.metric, a.max_edges, a.ef_construction)
     cfg_name = {(128, "sq_euclid", 16, 200): "C2" if a.n <= 1_000_000 else "C4-size", (768, "ucosine", 32, 400): "C3",
                 (96, "sq_euclid_i8", 16, 200): "C5-size"}.get(shape, "custom")
-    per_gpu = hi - lo
+    n_gpus = world * ndev_native
     out = {
-        "metric": "knn_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
+        "metric": "knn_queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": n_gpus,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "i8 (int32 dot, f64 epilogue)" if a.metric == "sq_euclid_i8" else "f32", "data": "synthetic" if a.data == "uniform" else "synthetic (clustered)",
         "config": {
             "workload": f"{cfg_name}: {a.n}x{a.dim} {'int8+scale' if a.metric == 'sq_euclid_i8' else 'f32'} {a.metric}, M={a.max_edges} efConstruction={a.ef_construction} "
-                        f"efSearch={a.ef_search} k={a.k}; step = batched KnnQuery of {per_gpu} queries per GPU, query set resident in HBM "
-                        f"(query set sharded over ranks, one all-gather of top-k)",
+                        f"efSearch={a.ef_search} k={a.k}; step = one hnsw_knn_query call (the reference's export: host buffers in and out, a different "
+                        f"query set every step) of {per_gpu} queries per GPU, rows and graph resident in HBM "
+                        + ("(one process, the library shards the call over its device contexts)" if native else "(query set sharded over ranks, one all-gather of top-k)"),
             "n": a.n, "dim": a.dim, "queries_per_gpu_per_step": per_gpu, "queries_per_step": nq_total, "k": a.k, "max_edges": a.max_edges,
-            "ef_construction": a.ef_construction, "ef_search": a.ef_search,
-            "add_mode": f"snapshot-batched, cap {a.insert_batch}", "parallelism": f"query-shard x{world}, index replicated ({a.build if world > 1 else 'one build'})",
+            "ef_construction": a.ef_construction, "ef_search": a.ef_search, "query_sets": R,
+            "add_mode": f"snapshot-batched, cap {a.insert_batch}",
+            "parallelism": (f"native: one process, query-shard x{ndev_native} device contexts, replicas copied device to device" if native else
+                            f"query-shard x{world}, index replicated ({a.build if world > 1 else 'one build'})"),
         },
-        "boundary_call_queries_per_sec": round(nq_total / dt_boundary, 1),
-        "boundary_call_note": "the same step through the reference's export hnsw_knn_query (host buffers in and out every call: PCIe-inclusive); "
-                              "`value` is the contract's figure with the query set already resident in HBM",
+        "entry_point": "hnsw_knn_query",
+        "resident_queries_per_sec": round(nq_total / dt_resident, 1),
+        "resident_note": "the same step with the query set uploaded once before the timed region (hnsw_mi355x_knn_query_resident); "
+                         "`value` is the reference's export, PCIe-inclusive",
         "recall_at_10": round(recall, 4),
         "recall_note": "exact brute-force ground truth; i.i.d. uniform data (the reference's test distribution) has no "
                        "neighbourhood structure at this size -- the CPU path returns the same ids (see cpu_baseline); "
@@ -479,13 +561,13 @@ def main():
         "add_per_sec": round(a.n / build_s, 1), "build_seconds": round(build_s, 3),
         "add_note": "hnsw_add of the whole set in one call: the deterministic snapshot-batched schedule (DESIGN.md 4) -- one legal outcome "
                     "of the reference's Parallel.For Add(List), checked bit for bit against the CPU restatement of the same schedule; "
-                    "the reference-exact sequential mode and a bounded-concurrency mode are in add_modes",
+                    "the reference-exact graph (sequential, and through exact windows) and a bounded-concurrency mode are in add_modes",
         "build_evals": build_stats["evals"] + build_stats["search_evals"],
         "build_launches": build_stats["launches"] + build_stats["search_launches"],
         "replicas_identical": replicas_identical,
-        "evals_per_query": round((st["search_evals"] + st["evals"]) / max(1, per_gpu * a.steps), 1),
-        "traversal": a.traversal, "search_overflows": st["search_overflows"], "search_repeats": st["search_repeats"],
-        "small_batch": small,
+        "evals_per_query": round(sum(c["search_evals"] + c["evals"] for c in st_all) / max(1, per_gpu * ndev_native * a.steps), 1),
+        "traversal": a.traversal, "search_overflows": sum(c["search_overflows"] for c in st_all), "search_repeats": sum(c["search_repeats"] for c in st_all),
+        "small_batch": small, "crossover_batch_vs_cpu": crossover,
         "roofline": roofline, "roofline_add": roofline_add, "add_modes": add_modes, "cpu_baseline": cpu,
     }
     print(json.dumps(out))
