@@ -85,6 +85,12 @@ public:
     bool upload_rows_wait(long long upto);
     // Replaces the resident query set (nq x dim); norms for cosine computed on device.
     bool set_queries(const float *queries, int nq);
+    // The same, with only the first `head` rows uploaded now: the rest follows behind the traversal launch of the next
+    // search_batch (which must come next), the kernel waiting for rows that have not landed yet.  Falls back to
+    // set_queries where that does not apply (cosine / int8 rows, head >= nq).
+    bool set_queries_streamed(const float *queries, int nq, int head);
+    // Forgets a tail that no launch picked up (an error between the two calls): the resident set is then empty.
+    void cancel_streamed() { if (tail_.n > 0) { tail_.n = 0; n_queries_ = 0; } }
     // ---- replicas (query sharding over the GPUs of one node, one context per GPU in one process) ----
     // Makes this context a replica of `src`: stored rows (only those it does not hold yet when `rows_from` >= 0 says
     // where they start to differ), per-row norms and the whole graph mirror, copied device to device
@@ -289,6 +295,10 @@ private:
     size_t s_order_cap_ = 0;
     int *s_rlog_ = nullptr; // insert search: per-job read logs (exact-window Add)
     size_t s_rlog_cap_ = 0;
+    struct QueryTail { const float *src = nullptr; long long first = 0, n = 0; } tail_; // set_queries_streamed: rows still on the host
+    int *h_ready_ = nullptr, *d_ready_ = nullptr; // rows of the query set that have landed (host memory, read by the kernel)
+    void *copy_stream_ = nullptr;
+    bool upload_tail();
     int *s_dry_ = nullptr;  // link_dry_run: [jobs | flags]
     size_t s_dry_cap_ = 0;
     int *s_wdry_ = nullptr; // windowed insert search: [upper_owner | dry0 | dryU]

@@ -164,6 +164,8 @@ Device::~Device()
     if (hipSetDevice(device_) != hipSuccess) return;
     if (stream_) { (void)hipStreamSynchronize(S(stream_)); (void)hipStreamDestroy(S(stream_)); }
     for (int i = 0; i < 8; ++i) { if (up_pin_[i]) (void)hipHostFree(up_pin_[i]); if (up_ev_[i]) (void)hipEventDestroy((hipEvent_t)up_ev_[i]); }
+    if (h_ready_) (void)hipHostFree(h_ready_);
+    if (copy_stream_) (void)hipStreamDestroy(S(copy_stream_));
     if (bg_.th.joinable()) bg_.th.join();
     if (bg_.stream) (void)hipStreamDestroy(S(bg_.stream));
     for (int i = 0; i < 2; ++i) { if (bg_.pin[i]) (void)hipHostFree(bg_.pin[i]); if (bg_.ev[i]) (void)hipEventDestroy((hipEvent_t)bg_.ev[i]); }
@@ -475,6 +477,84 @@ StepBuffers *Device::alloc_step(int nslots, int stride)
         return nullptr;
     }
     return sb;
+}
+
+// hnsw_knn_query hands over host buffers every call, and a 65 536 x 128 query set is 33 MB: uploaded in front of
+// the traversal it was 4 % of the call.  Here only the first `head` rows are uploaded before the launch; the rest
+// follows on the copy stream WHILE the traversal kernel runs (search_batch -> upload_tail), chunk by chunk, and a word
+// in host memory tells the kernel how many rows have landed (graph_search_kernel's `ready`).  Chunks are whole 128-byte
+// lines of the query matrix, so no line of it is ever read half-arrived.  Plain float metrics only (nothing to
+// compute per query row on arrival).
+bool Device::set_queries_streamed(const float *queries, int nq, int head)
+{
+    if (metric_ == M_COS || metric_ == M_I8 || nq <= 0 || head <= 0 || head >= nq) return set_queries(queries, nq);
+    head = std::min(nq, (head + 31) & ~31);
+    if (head >= nq) return set_queries(queries, nq);
+    if (!bind()) return false;
+    if (!h_ready_) {
+        HIP_OK(hipHostMalloc((void **)&h_ready_, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_OK(hipHostGetDevicePointer((void **)&d_ready_, h_ready_, 0));
+        hipStream_t cs;
+        HIP_OK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        copy_stream_ = cs;
+    }
+    if (!set_queries(queries, head)) return false; // allocates for `head` rows at least ...
+    if (nq > q_capacity_) {                         // ... and for the whole set, keeping the head
+        float *nqbuf = nullptr;
+        const long long cap = std::max<long long>(nq, 1024);
+        HIP_OK(hipMalloc(&nqbuf, (size_t)cap * pitch_ * sizeof(float)));
+        HIP_OK(hipMemcpyAsync(nqbuf, d_queries_, (size_t)head * pitch_ * sizeof(float), hipMemcpyDeviceToDevice, S(stream_)));
+        HIP_OK(hipStreamSynchronize(S(stream_)));
+        HIP_OK(hipFree(d_queries_));
+        d_queries_ = nqbuf;
+        q_capacity_ = cap;
+    }
+    n_queries_ = nq;
+    __atomic_store_n(h_ready_, head, __ATOMIC_RELEASE);
+    tail_.src = queries;
+    tail_.first = head;
+    tail_.n = nq - head;
+    return true;
+}
+
+bool Device::upload_tail()
+{
+    const long long first = tail_.first, n = tail_.n;
+    const float *src = tail_.src;
+    tail_.n = 0;
+    if (n <= 0) return true;
+    constexpr size_t kChunk = 2u << 20;
+    for (int i = 0; i < 2; ++i) {
+        if (!up_pin_[i]) HIP_OK(hipHostMalloc(&up_pin_[i], kChunk, hipHostMallocDefault));
+        if (!up_ev_[i]) { hipEvent_t e; HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); up_ev_[i] = e; }
+    }
+    const size_t row_bytes = (size_t)dim_ * sizeof(float);
+    const long long rows_per_chunk = std::max<long long>(32, (long long)(kChunk / row_bytes) & ~31LL); // whole 128-B lines
+    hipStream_t cs = S(copy_stream_);
+    long long sent = 0, confirmed = 0;
+    int b = 0;
+    long long in_slot[2] = {0, 0};
+    while (confirmed < n) {
+        if (sent < n && in_slot[b] == 0) {
+            const long long r = std::min(rows_per_chunk, n - sent);
+            memcpy(up_pin_[b], src + (size_t)(first + sent) * dim_, (size_t)r * row_bytes);
+            HIP_OK(hipMemcpyAsync(d_queries_ + (size_t)(first + sent) * pitch_, up_pin_[b], (size_t)r * row_bytes, hipMemcpyHostToDevice, cs));
+            HIP_OK(hipEventRecord((hipEvent_t)up_ev_[b], cs));
+            in_slot[b] = r;
+            sent += r;
+            b ^= 1;
+            continue;
+        }
+        // the older of the two copies in flight
+        const int o = in_slot[b] != 0 ? b : b ^ 1;
+        HIP_OK(hipEventSynchronize((hipEvent_t)up_ev_[o]));
+        confirmed += in_slot[o];
+        in_slot[o] = 0;
+        b = o;
+        __atomic_store_n(h_ready_, (int)(first + confirmed), __ATOMIC_RELEASE);
+    }
+    up_busy_[0] = up_busy_[1] = false;
+    return true;
 }
 
 bool Device::clone_from(Device *src, long long pool_len)
@@ -1442,6 +1522,9 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     int *h_flag = reinterpret_cast<int *>(hs + 16 + b_jobs + 2 * b_res);
     int *d_ids = reinterpret_cast<int *>(s_hits_);
     float *d_d = reinterpret_cast<float *>(s_hits_) + (size_t)chunk * k_out;
+    // a query set whose tail is still on the host (set_queries_streamed): the launch is gated on the rows' arrival
+    const int *gate = tail_.n > 0 ? d_ready_ : nullptr;
+    struct TailGuard { Device *d; ~TailGuard() { d->tail_.n = 0; } } tail_guard{this}; // whatever happens below, nothing stays pending
     for (long long off = 0; off < njobs; off += chunk) {
         const int nj = (int)std::min<long long>(chunk, njobs - off);
         memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
@@ -1456,7 +1539,8 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0); \
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0, \
+                       gate); \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
     do {                                                                                                                   \
@@ -1482,6 +1566,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
 #undef LAUNCH3
 #undef LAUNCH2
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
+        if (tail_.n > 0 && !upload_tail()) return false; // the rest of the query set, while the launch above is running
         HIP_OK(hipMemcpyAsync(h_ids, d_ids, 4u * (size_t)nj * k_out, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(h_d, d_d, 4u * (size_t)nj * k_out, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(h_flag, s_flag_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));

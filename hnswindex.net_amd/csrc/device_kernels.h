@@ -1930,18 +1930,41 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
                     const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
                     int spill_cap, unsigned *__restrict__ visited, long long vis_words, int *__restrict__ vis_tab, int vis_tab_cap, int k_out,
                     int *__restrict__ out_ids, float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
-                    unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap)
+                    unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap,
+                    const int *__restrict__ ready)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
                  vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, (unsigned)(vis_tab_cap - 1), 0, vis_tab_cap / 4 * 3};
     ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
+    // `ready` (hnsw_knn_query on host buffers): the launch started when the first rows of the query set had landed; the
+    // rest is still arriving on the copy engine, and *ready (a word in host memory the uploading thread advances) says how
+    // many rows are there.  Jobs are taken in order, so a wave almost never has to wait; when it does it sleeps and
+    // polls, for a bounded time -- a job whose row has not arrived by then is handed back (flag 1), never waited for.
+    int known_ready = 0;
     for (;;) {
         int job = 0;
         if (lane == 0) job = atomicAdd(job_counter, 1);
         job = __builtin_amdgcn_readfirstlane(job);
         if (job >= njobs) break;
+        if (ready) {
+            const int need = __builtin_amdgcn_readfirstlane(jobs[job].qref);
+            if (need >= known_ready) {
+                for (int spin = 0; spin < (1 << 15); ++spin) { // at most ~0.1 s
+                    int r = 0;
+                    if (lane == 0) r = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    known_ready = __builtin_amdgcn_readfirstlane(r);
+                    if (need < known_ready) break;
+                    __builtin_amdgcn_s_sleep(127);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the rows read next were written by the copy engine
+                if (need >= known_ready) {
+                    if (lane == 0) { out_cnt[job] = 0; out_flag[job] = 1; }
+                    continue;
+                }
+            }
+        }
         search_job<METRIC, NS, HASHED>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
                                V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job, overlap != 0);
         V.clear(lane);
@@ -2798,7 +2821,8 @@ __global__ void sqrt_rn_kernel(const double *in, double *out, int n)
         const float *__restrict__, const double *__restrict__, const float *__restrict__, const double *__restrict__, int,      \
         const int *__restrict__, int, const int64_t *__restrict__, const int *__restrict__, int, const SearchJob *__restrict__,  \
         int, int, ND *__restrict__, int, unsigned *__restrict__, long long, int *__restrict__, int, int, int *__restrict__,      \
-        float *__restrict__, int *__restrict__, int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int);
+        float *__restrict__, int *__restrict__, int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int, \
+        const int *__restrict__);
 #define HNSW_INSERT_SIGNATURE(PREFIX, M, NS, H)                                                                                  \
     PREFIX template __global__ void graph_insert_search_kernel<M, NS, H>(                                                       \
         const float *__restrict__, const double *__restrict__, int, const int *__restrict__, int, const int64_t *__restrict__,   \

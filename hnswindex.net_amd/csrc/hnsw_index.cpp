@@ -1383,8 +1383,13 @@ int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *o
         for (long long j = 0; j < (long long)count * std::max(k, 0); ++j) { out_ids[j] = -1; out_dists[j] = std::numeric_limits<float>::quiet_NaN(); }
         return 0;
     }
-    if (set_resident_queries(queries, count, dim, err) < 0) return -1;
-    return knn_query_resident(k, out_ids, out_dists, err);
+    // the queries arrive as host buffers: where the traversal runs on the device, all but the first rows are uploaded
+    // BEHIND the launch (Device::set_queries_streamed), which starts as soon as those first rows are resident
+    const bool streamed = p_.device_traversal && dim == dim_ && dev_ && dev_->traversal_fits(std::max(p_.min_nn, k), false, p_.max_edges);
+    if (set_resident_queries(queries, count, dim, err, streamed) < 0) return -1;
+    const int rc = knn_query_resident(k, out_ids, out_dists, err);
+    for (int g = 0; g < (sharded_resident_ ? p_.devices : 1); ++g) context(g)->cancel_streamed(); // (only after an error: `queries` is borrowed for this call)
+    return rc;
 }
 
 // The device contexts 1 .. devices - 1 (created on first use; more contexts than GPUs share them round robin --
@@ -1420,8 +1425,9 @@ bool HnswIndex::ensure_replicas(bool clone, std::string &err)
     return true;
 }
 
-int HnswIndex::set_resident_queries(const float *queries, int count, int dim, std::string &err)
+int HnswIndex::set_resident_queries(const float *queries, int count, int dim, std::string &err, bool streamed)
 {
+    constexpr int kStreamMin = 8192, kStreamHead = 4096; // a call this large starts on its first rows; see Device::set_queries_streamed
     if (!ensure_dim(dim, err)) return -1;
     Tick t(g_pt.set_queries);
     sharded_resident_ = false;
@@ -1435,7 +1441,10 @@ int HnswIndex::set_resident_queries(const float *queries, int count, int dim, st
         for (int g = 0; g < n; ++g)
             th.emplace_back([&, g] {
                 const long long lo = shard_lo_[(size_t)g], hi = shard_lo_[(size_t)g + 1];
-                if (!context(g)->set_queries(queries + (size_t)lo * (size_t)dim, (int)(hi - lo))) errs[(size_t)g] = get_dev_error().empty() ? "set_queries failed" : get_dev_error();
+                const float *qs = queries + (size_t)lo * (size_t)dim;
+                const int cnt = (int)(hi - lo);
+                if (!(streamed && cnt >= kStreamMin ? context(g)->set_queries_streamed(qs, cnt, kStreamHead) : context(g)->set_queries(qs, cnt)))
+                    errs[(size_t)g] = get_dev_error().empty() ? "set_queries failed" : get_dev_error();
             });
         for (auto &t2 : th) t2.join();
         for (const std::string &e : errs) if (!e.empty()) { err = e; resident_queries_ = 0; return -1; }
@@ -1443,7 +1452,7 @@ int HnswIndex::set_resident_queries(const float *queries, int count, int dim, st
         resident_queries_ = count;
         return 0;
     }
-    if (!dev_->set_queries(queries, count)) { err = get_dev_error(); return -1; }
+    if (!(streamed && count >= kStreamMin ? dev_->set_queries_streamed(queries, count, kStreamHead) : dev_->set_queries(queries, count))) { err = get_dev_error(); return -1; }
     resident_queries_ = count;
     return 0;
 }

@@ -47,7 +47,7 @@ public:
 
     // Measurement aid: upload a query set once (resident in HBM), then run KnnQuery on it any
     // number of times without host->device traffic for the inputs.
-    int set_resident_queries(const float *queries, int count, int dim, std::string &err);
+    int set_resident_queries(const float *queries, int count, int dim, std::string &err, bool streamed = false);
     int knn_query_resident(int k, int *out_ids, float *out_dists, std::string &err);
 
     // hnsw_range_query (HNSWIndex.RangeQuery, src/HNSWIndex/HNSWIndex.cs:144-168): per query the
