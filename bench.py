@@ -299,6 +299,25 @@ def main():
         small = {"queries_per_call": a.small_batch, "queries_per_sec": round(a.small_batch * 10 / dtb, 1),
                  "resident_queries_per_sec": round(a.small_batch * 10 / dts, 1),
                  "roofline_frac": round(ev_s * ss["row_bytes"] / (ms_s / 1e3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_s > 0 else None}
+        # same-type calls on one handle overlap (README.md:64-65): T host threads, each issuing hnsw_knn_query calls of that
+        # size back to back on its own query sets -- every call has a query lane of its own, the launches run side by side
+        import threading
+        for T in (2, 4):
+            got = [None] * T
+
+            def worker(t):
+                for r_ in range(10):
+                    got[t] = ix.knn_query(q_sets[(t + r_) % R][t * a.small_batch:(t + 1) * a.small_batch] if (t + 1) * a.small_batch <= nq_total
+                                          else q_sets[(t + r_) % R][:a.small_batch], a.k)
+            th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+            t0 = time.perf_counter()
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            dtt = time.perf_counter() - t0
+            small[f"queries_per_sec_{T}_host_threads"] = round(T * a.small_batch * 10 / dtt, 1)
+            small[f"speedup_{T}_host_threads_vs_one"] = round(T * a.small_batch * 10 / dtt / small["queries_per_sec"], 3)
     if world > 1:
         t = torch.tensor([dt, dt_resident], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <atomic>
 #include <cstdint>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -68,6 +69,12 @@ struct SearchHit {
 class Device {
 public:
     static Device *create(int device, int dim, int metric, long long capacity);
+    // A second context on the same GPU that BORROWS the primary's stored rows and graph mirror and owns everything
+    // a query needs besides (stream, resident query set, per-wave scratch, staging): two hnsw_knn_query calls on one
+    // index then run side by side, the head of one launch filling the tail of the other.  rebind() refreshes the
+    // borrowed pointers (the primary may have grown); the caller guarantees the primary is not being written.
+    static Device *create_view(Device *primary);
+    void rebind(const Device *primary);
     ~Device();
 
     int dim() const { return dim_; }
@@ -295,6 +302,7 @@ private:
     size_t s_order_cap_ = 0;
     int *s_rlog_ = nullptr; // insert search: per-job read logs (exact-window Add)
     size_t s_rlog_cap_ = 0;
+    bool is_view_ = false;
     struct QueryTail { const float *src = nullptr; long long first = 0, n = 0; } tail_; // set_queries_streamed: rows still on the host
     int *h_ready_ = nullptr, *d_ready_ = nullptr; // rows of the query set that have landed (host memory, read by the kernel)
     void *copy_stream_ = nullptr;

@@ -159,9 +159,40 @@ Device *Device::create(int device, int dim, int metric, long long capacity)
     return d;
 }
 
+Device *Device::create_view(Device *primary)
+{
+    if (!primary) return nullptr;
+    Device *d = new Device();
+    d->is_view_ = true;
+    d->device_ = primary->device_;
+    d->dim_ = primary->dim_;
+    d->pitch_ = primary->pitch_;
+    d->metric_ = primary->metric_;
+    d->stats_.row_bytes = primary->stats_.row_bytes;
+    d->num_cu_ = primary->num_cu_;
+    if (hipSetDevice(d->device_) != hipSuccess) { set_dev_error("hipSetDevice failed"); delete d; return nullptr; }
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { set_dev_error("hipStreamCreate failed"); delete d; return nullptr; }
+    d->stream_ = st;
+    d->rebind(primary);
+    return d;
+}
+
+void Device::rebind(const Device *p)
+{
+    d_rows_ = p->d_rows_; d_row_sn_ = p->d_row_sn_; capacity_ = p->capacity_; n_rows_hw_ = p->n_rows_hw_;
+    g_adj0_ = p->g_adj0_; g_level_ = p->g_level_; g_upper_ = p->g_upper_; g_pool_ = p->g_pool_;
+    g_tested0_ = p->g_tested0_; g_testedU_ = p->g_testedU_;
+    g_n_ = p->g_n_; g_cap_n_ = p->g_cap_n_; g_pool_cap_ = p->g_pool_cap_; g_stride0_ = p->g_stride0_; g_strideU_ = p->g_strideU_;
+}
+
 Device::~Device()
 {
     if (hipSetDevice(device_) != hipSuccess) return;
+    if (is_view_) { // borrowed: the primary frees them
+        d_rows_ = nullptr; d_row_sn_ = nullptr;
+        g_adj0_ = nullptr; g_level_ = nullptr; g_upper_ = nullptr; g_pool_ = nullptr; g_tested0_ = nullptr; g_testedU_ = nullptr;
+    }
     if (stream_) { (void)hipStreamSynchronize(S(stream_)); (void)hipStreamDestroy(S(stream_)); }
     for (int i = 0; i < 8; ++i) { if (up_pin_[i]) (void)hipHostFree(up_pin_[i]); if (up_ev_[i]) (void)hipEventDestroy((hipEvent_t)up_ev_[i]); }
     if (h_ready_) (void)hipHostFree(h_ready_);
@@ -494,8 +525,14 @@ bool Device::set_queries_streamed(const float *queries, int nq, int head)
     if (!h_ready_) {
         HIP_OK(hipHostMalloc((void **)&h_ready_, 64, hipHostMallocMapped | hipHostMallocCoherent));
         HIP_OK(hipHostGetDevicePointer((void **)&d_ready_, h_ready_, 0));
+        // The copies a gated kernel waits for must never queue behind that kernel.  HIP multiplexes streams onto a few
+        // hardware queues, and a copy stream that lands on the queue of a compute stream does exactly that (measured: two
+        // lanes, every wave slept its full bound).  High-priority streams have hardware queues of their own, and only
+        // copy streams are created with that priority here.
+        int lo = 0, hi = 0;
+        HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         hipStream_t cs;
-        HIP_OK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        HIP_OK(hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, hi));
         copy_stream_ = cs;
     }
     if (!set_queries(queries, head)) return false; // allocates for `head` rows at least ...

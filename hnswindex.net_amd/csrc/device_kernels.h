@@ -1951,12 +1951,14 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
         if (ready) {
             const int need = __builtin_amdgcn_readfirstlane(jobs[job].qref);
             if (need >= known_ready) {
-                for (int spin = 0; spin < (1 << 15); ++spin) { // at most ~0.1 s
+                // a read of host memory per poll: few polls, far apart (thousands of waves polling back to back were
+                // measured to starve the very copy they wait for) -- 512 x ~0.2 ms at most, then the job is handed back
+                for (int spin = 0; spin < 512; ++spin) {
                     int r = 0;
                     if (lane == 0) r = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     known_ready = __builtin_amdgcn_readfirstlane(r);
                     if (need < known_ready) break;
-                    __builtin_amdgcn_s_sleep(127);
+                    for (int z = 0; z < 48; ++z) __builtin_amdgcn_s_sleep(127);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the rows read next were written by the copy engine
                 if (need >= known_ready) {

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -32,8 +33,8 @@ void set_error(const std::string &s)
 } // namespace
 
 #define API extern "C" __attribute__((visibility("default")))
-// serialises the calls on one handle (HnswIndex::mutex)
-#define LOCK_INDEX(h) std::lock_guard<std::mutex> index_lock_(static_cast<HnswIndex *>(h)->mutex())
+// exclusive use of one handle (HnswIndex::mutex; hnsw_knn_query calls share it, see hnsw_index.h)
+#define LOCK_INDEX(h) std::unique_lock<std::shared_mutex> index_lock_(static_cast<HnswIndex *>(h)->mutex())
 
 API int hnsw_get_last_error_utf8(void *buf, int buf_len) // :27-39
 {
@@ -112,9 +113,18 @@ API int hnsw_knn_query(void *handle, const float *vectors, int count, int dim, i
     if (!handle) return 0;
     if (count <= 0) return 0;
     if (!vectors || !out_ids || !out_dists || dim <= 0) { set_error("System.ArgumentNullException: hnsw_knn_query"); return -1; }
-    LOCK_INDEX(handle);
     std::string err;
-    int rc = static_cast<HnswIndex *>(handle)->knn_query(vectors, count, dim, k, out_ids, out_dists, err);
+    HnswIndex *ix = static_cast<HnswIndex *>(handle);
+    {   // same-type calls overlap (README.md:64-65): shared lock, a query lane per call
+        std::shared_lock<std::shared_mutex> rd(ix->mutex());
+        int rc = 0;
+        if (ix->knn_query_concurrent(vectors, count, dim, k, out_ids, out_dists, rc, err)) {
+            if (rc < 0) { set_error(err); return -1; }
+            return 0;
+        }
+    }
+    LOCK_INDEX(handle);
+    int rc = ix->knn_query(vectors, count, dim, k, out_ids, out_dists, err);
     if (rc < 0) { set_error(err); return -1; }
     return 0;
 }
@@ -364,9 +374,7 @@ API int hnsw_mi355x_get_stats(void *h, hnswdev_stats *out)
 {
     if (!h || !out) return -1;
     LOCK_INDEX(h);
-    hnsw::Device *d = static_cast<HnswIndex *>(h)->device();
-    if (!d) { std::memset(out, 0, sizeof *out); return 0; }
-    d->get_stats(out);
+    static_cast<HnswIndex *>(h)->collect_stats(out); // the primary context plus the query lanes
     return 0;
 }
 API int hnsw_mi355x_device_count(void *h)
@@ -388,9 +396,7 @@ API int hnsw_mi355x_reset_stats(void *h)
 {
     if (!h) return -1;
     LOCK_INDEX(h);
-    HnswIndex *ix = static_cast<HnswIndex *>(h);
-    for (int g = 0; g < ix->device_count(); ++g)
-        if (hnsw::Device *d = ix->device_at(g)) d->reset_stats();
+    static_cast<HnswIndex *>(h)->reset_all_stats();
     return 0;
 }
 API int hnsw_mi355x_set_profiling(void *h, int enabled)

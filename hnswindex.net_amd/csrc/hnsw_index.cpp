@@ -663,6 +663,7 @@ HnswIndex::~HnswIndex()
         fprintf(stderr, "[hnsw trace] batches=%ld sync_graph=%.3fs search_half=%.3fs collect=%.3fs link_host=%.3fs link_dev=%.3fs (rounds=%ld prune_jobs=%ld) | query: set_queries=%.3fs dev=%.3fs post=%.3fs\n",
                 g_pt.batches, g_pt.sync_graph, g_pt.search_half, g_pt.collect, g_pt.link_host, g_pt.link_dev, g_pt.rounds, g_pt.prune_jobs, g_pt.set_queries, g_pt.query_dev, g_pt.post);
     engine_.reset(); // before the device it allocates from
+    for (auto &l : lanes_) l.reset();
     replicas_.clear();
     dev_.reset();
 }
@@ -1425,9 +1426,78 @@ bool HnswIndex::ensure_replicas(bool clone, std::string &err)
     return true;
 }
 
+// a call of at least kStreamMin queries starts on its first kStreamHead rows; see Device::set_queries_streamed
+static constexpr int kStreamMin = 32768, kStreamHead = 4096;
+
+// hnsw_knn_query from several host threads at once (lock held shared): one query lane per call.
+int HnswIndex::knn_query_concurrent(const float *queries, int count, int dim, int k, int *out_ids, float *out_dists, int &rc, std::string &err)
+{
+    static const bool enabled = [] { const char *e = std::getenv("HNSW_MI355X_CONCURRENT_QUERIES"); return !e || std::atoi(e) != 0; }();
+    if (!enabled || !failed_msg_.empty() || p_.devices > 1 || !p_.device_traversal || !dev_ || dim != dim_ || count <= 0 || k < 1 ||
+        graph_.entry < 0 || graph_.count <= 0 || graph_dirty_ || dev_->graph_nodes() != graph_.length)
+        return 0;
+    const int ef = std::max(p_.min_nn, k);
+    if (!dev_->traversal_fits(ef, false, p_.max_edges)) return 0;
+    // A call large enough to fill the chip on its own takes the exclusive path, where its query rows are uploaded BEHIND the
+    // launch (Device::set_queries_streamed): a kernel that sleeps on rows still arriving must have the GPU's queues to
+    // itself -- two such launches on two lanes were measured to starve each other's copies -- and overlapping it with
+    // another call would gain little.  The lanes serve the smaller calls, which leave the chip part-idle.
+    if (count >= kStreamMin) return 0;
+    int lane = -1;
+    {
+        std::unique_lock<std::mutex> lk(lane_mu_);
+        lane_cv_.wait(lk, [&] { return !lane_busy_[0] || !lane_busy_[1]; });
+        lane = lane_busy_[0] ? 1 : 0;
+        lane_busy_[lane] = true;
+        if (!lanes_[lane]) {
+            lanes_[lane].reset(Device::create_view(dev_.get()));
+            if (lanes_[lane]) lanes_[lane]->set_profiling(profiling_);
+        }
+    }
+    struct Release { HnswIndex *ix; int lane; ~Release() { { std::lock_guard<std::mutex> lk(ix->lane_mu_); ix->lane_busy_[lane] = false; } ix->lane_cv_.notify_one(); } } release{this, lane};
+    Device *d = lanes_[lane].get();
+    if (!d) return 0;
+    d->rebind(dev_.get()); // no writer is active: the primary's arrays are stable while this call runs
+    rc = -1;
+    if (!d->set_queries(queries, count)) { err = get_dev_error(); return 1; }
+    std::vector<SearchJob> jobs((size_t)count);
+    const int ep = graph_.entry, top = graph_.top_layer();
+    for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0, -1, 0};
+    std::vector<int> flag((size_t)count);
+    const bool ok = d->search_batch(jobs.data(), count, ef, k, out_ids, out_dists, flag.data());
+    if (!ok) { err = get_dev_error(); return 1; }
+    for (int i = 0; i < count; ++i) if (flag[(size_t)i]) return 0; // something was handed back: the exclusive path answers the whole call
+    rc = 0;
+    return 1;
+}
+
+void HnswIndex::collect_stats(hnswdev_stats *out)
+{
+    std::memset(out, 0, sizeof(*out));
+    if (!dev_) return;
+    dev_->get_stats(out);
+    for (auto &l : lanes_) {
+        if (!l) continue;
+        hnswdev_stats s;
+        l->get_stats(&s);
+        out->launches += s.launches; out->evals += s.evals; out->timed_launches += s.timed_launches; out->timed_evals += s.timed_evals; out->kernel_ms += s.kernel_ms;
+        out->search_launches += s.search_launches; out->search_evals += s.search_evals; out->search_timed_launches += s.search_timed_launches;
+        out->search_timed_evals += s.search_timed_evals; out->search_kernel_ms += s.search_kernel_ms; out->search_overflows += s.search_overflows;
+        out->search_repeats += s.search_repeats; out->visited_hash_launches += s.visited_hash_launches;
+    }
+}
+
+void HnswIndex::reset_all_stats()
+{
+    if (dev_) dev_->reset_stats();
+    for (auto &r : replicas_) r->reset_stats();
+    for (auto &l : lanes_) if (l) l->reset_stats();
+}
+
 int HnswIndex::set_resident_queries(const float *queries, int count, int dim, std::string &err, bool streamed)
 {
-    constexpr int kStreamMin = 8192, kStreamHead = 4096; // a call this large starts on its first rows; see Device::set_queries_streamed
+    static const bool stream_on = [] { const char *e = std::getenv("HNSW_MI355X_STREAM_QUERIES"); return !e || std::atoi(e) != 0; }();
+    streamed = streamed && stream_on;
     if (!ensure_dim(dim, err)) return -1;
     Tick t(g_pt.set_queries);
     sharded_resident_ = false;

@@ -3,7 +3,10 @@
 // gfx950 backend through the lock-step engine.
 #pragma once
 #include <memory>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -79,18 +82,37 @@ public:
     uint64_t graph_hash();
     void set_insert_batch(int v) { p_.insert_batch = v; }
     void exact_window_stats(uint64_t out[4]) const { out[0] = xw_rounds_; out[1] = xw_searches_; out[2] = xw_alone_; out[3] = xw_linked_; }
-    void set_profiling(bool on) { profiling_ = on; if (dev_) dev_->set_profiling(on); for (auto &r : replicas_) r->set_profiling(on); }
+    void set_profiling(bool on)
+    {
+        profiling_ = on;
+        if (dev_) dev_->set_profiling(on);
+        for (auto &r : replicas_) r->set_profiling(on);
+        for (auto &l : lanes_) if (l) l->set_profiling(on);
+    }
 
-    // One caller at a time per index: the reference promises that operations of one type may
-    // overlap on an index (/root/reference/README.md:64-65; BatchKnnQuery / Add(List) are
-    // Parallel.For, HNSWIndex.cs:70-78,129-137).  Here every call already fans out over the whole
-    // GPU, and the resident query set, the per-wave scratch and the staging buffers belong to the
-    // index, so overlapping calls on one handle are serialised: every handle-taking export holds
-    // this mutex for the duration of the call.  Calls on different handles run concurrently.
-    std::mutex &mutex() { return mu_; }
+    // Calls on one handle.  The reference promises that operations of one type may overlap on an index
+    // (/root/reference/README.md:64-65; BatchKnnQuery / Add(List) are Parallel.For, HNSWIndex.cs:70-78,129-137).  Here:
+    //   * hnsw_knn_query calls DO overlap: each takes the index lock shared and a query lane of its own -- a Device view
+    //     (stream, resident query set, per-wave scratch) that borrows the rows and the graph mirror -- so two host
+    //     threads' launches run side by side on the GPU, the head of one filling the tail of the other
+    //     (knn_query_concurrent; whatever it cannot serve -- sharded indices, host traversal, a graph mirror that is
+    //     not current, hand-backs -- goes through the exclusive path);
+    //   * everything else (Add, Remove, RangeQuery, ...) takes the lock exclusively: those calls already fan out over
+    //     the whole GPU and own the index's staging buffers.
+    // Calls on different handles run concurrently.
+    std::shared_mutex &mutex() { return mu_; }
+    // 1: answered (rc = the call's return value); 0: not eligible, take the exclusive path.  Call with the lock held SHARED.
+    int knn_query_concurrent(const float *queries, int count, int dim, int k, int *out_ids, float *out_dists, int &rc, std::string &err);
+    void collect_stats(hnswdev_stats *out);
+    void reset_all_stats();
 
 private:
-    std::mutex mu_;
+    std::shared_mutex mu_;
+    static constexpr int kLanes = 2;
+    std::unique_ptr<Device> lanes_[kLanes];
+    bool lane_busy_[kLanes] = {false, false};
+    std::mutex lane_mu_;
+    std::condition_variable lane_cv_;
     HnswIndex() = default;
     // A device failure in the middle of an Add leaves appended nodes without rows / links: the
     // index then refuses every further call with the original message.
