@@ -342,14 +342,23 @@ def main():
         kname, t_evals, t_launches, k_ms = "slot_distance_kernel", st["timed_evals"], st["timed_launches"], st["kernel_ms"]
     kernel_s = k_ms / 1e3
     achieved = t_evals * st["row_bytes"] / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    traffic = None
-    try:  # PMC traffic is collected in separate rocprofv3 passes (tools/run_profiles.sh); quote it only
-        # for the very workload it was measured on
+    # PMC traffic and the measured random-gather ceilings are collected in separate passes (tools/run_profiles_r3.sh; --pmc runs
+    # cannot be combined with tracing) and committed under profiles/: quoted only for the very workload they were measured on
+    traffic, traffic_add, gather = None, {}, None
+    fetched_row_bytes = 128 if a.metric == "sq_euclid_i8" and a.dim <= 120 else st["row_bytes"]
+    try:
         pm = json.loads((ROOT / "profiles" / f"{PROFILE_ROUND}_pmc_traffic.json").read_text())
-        w = pm["workload"]
-        if a.traversal == "device" and (w["n"], w["dim"], w["nq"], w["ef_search"], w["k"], w["max_edges"]) == \
-                (a.n, a.dim, per_gpu, a.ef_search, a.k, a.max_edges) and a.metric == "sq_euclid":
-            traffic = round(pm["traffic_bytes_per_launch"])
+        for c in pm["configs"].values():
+            w = c["workload"]
+            if a.traversal == "device" and (w["n"], w["dim"], w["queries_per_gpu_per_step"], w["ef_search"], w["k"], w["max_edges"]) == \
+                    (a.n, a.dim, per_gpu, a.ef_search, a.k, a.max_edges) and c["row_bytes_fetched"] == fetched_row_bytes:
+                traffic = round(c["graph_search_kernel"]["traffic_bytes_per_launch"])
+                traffic_add = {k: c[k] for k in ("insert_search", "link_half") if k in c}
+    except Exception:
+        pass
+    try:
+        gc = json.loads((ROOT / "profiles" / f"{PROFILE_ROUND}_gather_ceilings.json").read_text())["rows"]
+        gather = gc.get(str(fetched_row_bytes))
     except Exception:
         pass
     roofline = {
@@ -360,6 +369,11 @@ def main():
         "launches": t_launches, "avg_launch_us": round(1e3 * k_ms / max(1, t_launches), 2),
         "kernel_time_share_of_step": round(kernel_s / dt, 4),
     }
+    if gather:  # what RANDOM gathers of rows this size reach on this chip (tools/gather_bench, table >> Infinity Cache), in rows fetched
+        rows_per_s = t_evals / kernel_s if kernel_s > 0 else 0.0
+        roofline["measured_gather_ceiling"] = {"row_bytes_fetched": fetched_row_bytes, "GBps": gather["best_GBps"], "rows_per_s": round(gather["rows_per_s"]),
+                                               "source": f"profiles/{PROFILE_ROUND}_gather_ceilings.json"}
+        roofline["frac_of_measured_gather"] = round(rows_per_s / gather["rows_per_s"], 4)
     # the Add half: graph_insert_search_kernel (search half + heuristic) and the link half, HIP events during the build
     bs = build_stats
     rb = bs["row_bytes"]
@@ -371,7 +385,9 @@ def main():
         roofline_add = {
             "bound": "hbm", "kernels": "graph_insert_search_kernel + link half (link_plan/offsets/order + graph_link_kernel)",
             "achieved": round(in_kernel, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(in_kernel / HBM_PEAK_GBPS, 4),
-            "traffic": None, "bytes_per_eval": rb, "evals": add_evals,
+            "traffic": (round(sum(v["traffic_bytes_total"] for v in traffic_add.values())) if len(traffic_add) == 2 else None),
+            "traffic_over_algorithmic": ({k: round(v["traffic_over_algorithmic"], 3) for k, v in traffic_add.items()} or None),
+            "bytes_per_eval": rb, "evals": add_evals,
             "insert_search": {"launches": bs["insert_timed_launches"], "seconds": round(ins_s, 4), "evals": bs["insert_timed_evals"],
                               "frac": round(bs["insert_timed_evals"] * rb / ins_s / 1e9 / HBM_PEAK_GBPS, 4)},
             "link_half": {"launches": bs["link_timed_launches"], "seconds": round(lnk_s, 4), "evals": bs["link_timed_evals"],
