@@ -913,14 +913,6 @@ static int overlap_mode()
     return e ? std::atoi(e) : 1;
 }
 
-// int8 records: the overlapped traversal touches the records of the candidate it expects to pop next, so that they are in L2
-// when it does (device_kernels.h, traverse_sorted); HNSW_MI355X_I8_WARM=0 turns that off (A/B runs).
-static bool i8_warm()
-{
-    static const bool v = [] { const char *e = std::getenv("HNSW_MI355X_I8_WARM"); return !e || std::atoi(e) != 0; }();
-    return v;
-}
-
 // The MFMA Gram-block prefilter of RelativeNeighborPruning (device_kernels.h): on by default where it applies
 // (cosine family, dim % 8 == 0); HNSW_MI355X_MFMA=0 keeps the exact-only forms (the tests run both).
 static bool mfma_heuristic()
@@ -1088,7 +1080,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
                        dim3(64), LDS, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
-                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0) | (i8_warm() ? 4 : 0), d_order, \
+                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
                        windowed ? s_rlog_ : (int *)nullptr, read_log_cap); \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
@@ -1584,7 +1576,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (i8_warm() ? 4 : 0), \
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0), \
                        gate); \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \

@@ -1025,7 +1025,6 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     V.seen += 1;
     unsigned far_key = f2key(cur);                                   // farthestResultDist :135
     int pre_id = -1, pre_a = 0, pre_b = 0; // speculative prefetch of the next expansion's list (see traverse)
-    int warm = 0;                          // int8: words touched to warm L2 (see the overlapped form below)
     const int lstride = layer == 0 ? G.stride0 : G.strideU;
     PH(0);
     constexpr int kDoubt = 0x40000000, kIdMask = 0x3fffffff;
@@ -1059,7 +1058,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         bool have = false;     // this lane holds an unvisited neighbour
         float lane_d = 0.0f;
         int lane_id = 0;
-        const bool overlapped = (oflags & 1) != 0 && n <= 64; // oflags bit 0: rows requested with the visited atomics; bit 2: int8 L2 warming
+        const bool overlapped = (oflags & 1) != 0 && n <= 64; // oflags bit 0: rows requested with the visited atomics
         if (overlapped) {
             // Latency-bound launch (fewer jobs than resident waves): the rows of ALL listed neighbours
             // are fetched together with the visited atomics instead of after them -- one dependent
@@ -1088,19 +1087,6 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 }
             }
             if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
-            if constexpr (METRIC == M_I8) {
-                // int8 records are one 128-byte line each, and a traversal over them is bound by the dependent round trips
-                // of an expansion, not by bytes (0.19 of what random 128-B gathers reach on this chip, tools/gather_bench):
-                // bandwidth is there to spend.  The list of the candidate most likely to be popped next has arrived by now
-                // (pre_a: word l of its list in lane l); touching one word of each record it names brings those lines into
-                // L2 while the insertions below run.  Nothing is marked visited and nothing is decided on these loads: when
-                // the guess is right (half the time) the next expansion's records come from L2, otherwise the lines are
-                // simply not used.  The word lands in `warm`, which is consumed once, at the end of the traversal.
-                if (pre_id >= 0 && (oflags & 4) != 0) {
-                    const int pn = __builtin_amdgcn_readlane(pre_a, 0);
-                    if (lane >= 1 && lane <= pn && lane < lstride) warm ^= __float_as_int(rows[(size_t)pre_a * dim]);
-                }
-            }
             __syncthreads();
             if constexpr (HASHED) {
                 have = in && (int)old == -1;
@@ -1206,7 +1192,6 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     }
     __syncthreads();
     top_n_out = top_n;
-    if (METRIC == M_I8 && __ballot(warm == 0x5a5a5a5a) == ~0ull) tie = true; // (keeps the warming loads; never true in practice, and harmless if it were)
     if (T.any_flagged(top_n, lane, kDoubt)) tie = true;                  // (i) left unresolved
     // (iii): the SET is the reference's, only its order among equal distances is open.  A caller that can tell
     // whether that order shows in what it makes of the list asks for this case separately (insert_job).
@@ -2158,7 +2143,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
 {
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
-    const int overlap = overlap_and_flags & 5; // bit 0: overlapped form, bit 2: int8 L2 warming (bit 1: the MFMA-prefiltered heuristic is allowed)
+    const int overlap = overlap_and_flags & 1; // bit 0: overlapped form (bit 1: the MFMA-prefiltered heuristic is allowed)
     SearchJob jb = jobs[job];
     const GraphView G{adj0, stride0, upper, pool, strideU};
     const int item = ~jb.qref;
