@@ -169,6 +169,8 @@ public:
         int read_log_cap;       // in
         const int *upper_owner; // in: job index per upper-layer output slot (n_upper)
         const int *read_log, *dry0, *dryU; // out: pinned, valid until the next call
+        const int *drop0;    // out: per layer-0 selection entry, up to three ids the neighbour's list would lose (dry0's code says how many)
+        const int *repeated; // out: per job, 1 = a layer was answered by the exact two-heap traversal (equal distances)
     };
     bool insert_search_batch(const SearchJob *jobs, int njobs, int k, int max_edges0, int n_upper, InsertResults *res, WindowExtras *win = nullptr);
     // insert_search_batch brings back the flags only; this fetches the selected ids into the arrays `res`

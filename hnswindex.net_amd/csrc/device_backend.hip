@@ -1033,8 +1033,10 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     const size_t b_sel0 = 4u * (size_t)njobs * sel_stride, b_cnt0 = 4u * (size_t)njobs, b_selU = 4u * nU * sel_stride, b_cntU = 4u * nU, b_flag = 4u * (size_t)njobs;
     const size_t b_log = windowed ? 4u * (size_t)njobs * (size_t)read_log_cap : 0;
     const size_t b_dry = windowed ? b_sel0 + b_selU : 0;
-    if (windowed && !grow_dev(&s_wdry_, &s_wdry_cap_, nU + (b_sel0 + b_selU) / 4u)) return false;
-    const size_t need = b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 16 + b_log + b_dry;
+    const size_t b_drop = windowed ? 3u * b_sel0 : 0;          // three ids per layer-0 selection entry
+    const size_t b_rep = windowed ? b_flag : 0;                // the jobs' "repeated" flags (the job flags themselves are folded to 0 / 1 below)
+    if (windowed && !grow_dev(&s_wdry_, &s_wdry_cap_, nU + (b_sel0 + b_selU + b_drop) / 4u)) return false;
+    const size_t need = b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 16 + b_log + b_dry + b_drop + b_rep;
     if (need > h_res_cap_) {
         if (h_res_) (void)hipHostFree(h_res_);
         h_res_ = nullptr; h_res_cap_ = 0;
@@ -1109,19 +1111,19 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         if (windowed) { // one launch (njobs <= chunk): everything the host validates with rides on the same wait
-            int *d_owner = s_wdry_, *d_dry0 = s_wdry_ + nU, *d_dryU = d_dry0 + (size_t)njobs * sel_stride;
+            int *d_owner = s_wdry_, *d_dry0 = s_wdry_ + nU, *d_dryU = d_dry0 + (size_t)njobs * sel_stride, *d_drop0 = d_dry0 + b_dry / 4u;
             if (n_upper > 0) {
                 memcpy(h_log + b_log / 4u, win->upper_owner, 4u * (size_t)n_upper); // staged behind the logs (the dry flags land there afterwards)
                 HIP_OK(hipMemcpyAsync(d_owner, h_log + b_log / 4u, 4u * (size_t)n_upper, hipMemcpyHostToDevice, st));
             }
-            HIP_OK(hipMemsetAsync(d_dry0, 0x01, b_dry, st)); // every flag non-zero ("changed") unless the kernel says otherwise
+            HIP_OK(hipMemsetAsync(d_dry0, 0xff, b_dry, st)); // every code "changed, set of lost ids unknown" unless the kernel says otherwise
             const int k_cap = nbcap();
             const size_t lds_link = ((search_lds_bytes(k_cap, 0, pitch_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
             const int grid = (njobs + n_upper) * sel_stride;
 #define LAUNCH_DRY(M)                                                                                                          \
     hipLaunchKernelGGL(graph_link_dry_sel_kernel<M>, dim3(grid), dim3(64), lds_link, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, s_iflag_, s_sel_, s_lcnt_, s_selU_, s_cntU_, sel_stride, d_owner, njobs, max_edges0, \
-                       k_cap, d_dry0, d_dryU, s_evals_, nbcap(), g_tested0_, g_testedU_, g_n_)
+                       k_cap, d_dry0, d_dryU, s_evals_, nbcap(), g_tested0_, g_testedU_, g_n_, d_drop0)
             if (metric_ == M_SQ) LAUNCH_DRY(M_SQ);
             else if (metric_ == M_COS) LAUNCH_DRY(M_COS);
             else if (metric_ == M_I8) LAUNCH_DRY(M_I8);
@@ -1129,7 +1131,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
 #undef LAUNCH_DRY
             HIP_OK(hipGetLastError());
             HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            HIP_OK(hipMemcpyAsync(h_log + b_log / 4u, d_dry0, b_dry, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(h_log + b_log / 4u, d_dry0, b_dry + b_drop, hipMemcpyDeviceToHost, st)); // flags and dropped ids are adjacent
             HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
             HIP_OK(hipMemcpyAsync(h_sel0, s_sel_, b_sel0, hipMemcpyDeviceToHost, st));
             HIP_OK(hipMemcpyAsync(h_cnt0, s_lcnt_, b_cnt0, hipMemcpyDeviceToHost, st));
@@ -1162,7 +1164,9 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
     }
+    int *h_rep = windowed ? h_log + (b_log + b_dry + b_drop) / 4u : nullptr;
     for (int i = 0; i < njobs; ++i) {
+        if (h_rep) h_rep[i] = h_flag[i] == 2;
         if (h_flag[i] == 2) { stats_.search_repeats++; h_flag[i] = 0; }
         stats_.search_overflows += (uint64_t)(h_flag[i] != 0);
     }
@@ -1172,7 +1176,10 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     fetch_njobs_ = windowed ? 0 : njobs;
     fetch_nupper_ = n_upper;
     *res = InsertResults{h_sel0, h_cnt0, h_selU, h_cntU, h_flag, sel_stride};
-    if (windowed) { win->read_log = h_log; win->dry0 = h_log + b_log / 4u; win->dryU = win->dry0 + (size_t)njobs * sel_stride; }
+    if (windowed) {
+        win->read_log = h_log; win->dry0 = h_log + b_log / 4u; win->dryU = win->dry0 + (size_t)njobs * sel_stride;
+        win->drop0 = win->dry0 + b_dry / 4u; win->repeated = h_rep;
+    }
     return true;
 }
 

@@ -764,13 +764,17 @@ __device__ unsigned long long g_phase_link[12];
 // snapshot of the graph is still the sequential one while none of them has been written since.  p == nullptr
 // (every other caller): nothing is recorded and the code folds away.  n keeps counting beyond cap: the host
 // sees the overflow.
+// Every entry is a pair: the node (or marker) and, for a beam-search expansion, the key of the farthest result at that
+// moment if the result list was full (0xffffffff otherwise, and for descent passes and markers): a neighbour whose distance
+// key is not below it would not have been pushed by that expansion -- which lets the host tell that a list which did change
+// since the snapshot changed in a way this reader would not have noticed (hnsw_index.cpp, "a change the reader does not see").
 struct ReadLog {
     int *p;
-    int n, cap;
-    __device__ __forceinline__ void put(int v, int lane)
+    int n, cap; // in entries (pairs)
+    __device__ __forceinline__ void put(int v, int lane, unsigned far = 0xffffffffu)
     {
         if (p) {
-            if (lane == 0 && n < cap) p[n] = v;
+            if (lane == 0 && n < cap) { p[2 * n] = v; p[2 * n + 1] = (int)far; }
             n++;
         }
     }
@@ -1034,7 +1038,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         const HEnt c = T.at(pos);
         if (c.id & kDoubt) { tie = true; break; } // the reference may be expanding its twin instead
         T.mark(pos, lane);
-        RL.put(c.id & kIdMask, lane);
+        RL.put(c.id & kIdMask, lane, top_n >= k ? far_key : 0xffffffffu);
         PH(1);
         int n, nb_a = 0, nb_b = 0;
         if (c.id == pre_id) {
@@ -2154,7 +2158,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     unsigned long long evals = 0;
     bool ok = true, repeat = false;
     // exact-window Add: record [n, entries...] of this job's read log (n beyond the capacity = overflow)
-    ReadLog RL{read_log ? read_log + (size_t)job * read_log_cap + 1 : nullptr, 0, read_log_cap - 1};
+    ReadLog RL{read_log ? read_log + (size_t)job * read_log_cap + 2 : nullptr, 0, (read_log_cap - 2) / 2};
 #ifdef EXP_PHASE_CLOCKS
     const long long ph_j0 = __builtin_readcyclecounter();
 #endif
@@ -2393,7 +2397,7 @@ __device__ __forceinline__ void link_group(const float *__restrict__ rows, const
                   int stride0, const int64_t *__restrict__ upper, int *__restrict__ pool, int strideU,
                   int node, int layer, NextItem next_item, int max_edges0, int k_cap, int *__restrict__ out_list,
                   unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU,
-                  unsigned char *smem, int *__restrict__ dry_changed = nullptr)
+                  unsigned char *smem, int *__restrict__ dry_changed = nullptr, int *__restrict__ dry_drop = nullptr, int dry_item = -1)
 {
     const SearchLds L = carve_lds(smem, k_cap, 0, dim, nbcap);
     // shortcut scratch behind the common carve-up: distances of up to kNewMax new entries to every
@@ -2505,10 +2509,38 @@ __device__ __forceinline__ void link_group(const float *__restrict__ rows, const
         }
     }
     if (dry_changed) { // dry run (exact-window Add): nothing is written; would the list read differently afterwards?
-        bool diff = cnt != l[0];
+        // code 0: the same sequence of ids.  Otherwise bit 0 set, bit 1 = the appended item stays in the list, bits 8.. = how
+        // many ids the list loses (their ids to dry_drop[0..3), at most three; 255 = more than that).
+        const int oc = l[0];
+        bool diff = cnt != oc;
         for (int i = lane; i < cnt && !diff; i += 64) diff = L.nbuf[i] != l[1 + i];
-        const bool any_diff = __ballot(diff) != 0ull;
-        if (lane == 0) { *dry_changed = any_diff ? 1 : 0; atomicAdd(eval_counter, evals); }
+        int code = 0;
+        if (__ballot(diff) != 0ull) {
+            bool has = false;
+            for (int i = lane; i < cnt; i += 64) has = has || L.nbuf[i] == dry_item;
+            code = 1 | (__ballot(has) != 0ull ? 2 : 0);
+            int nd = 0;
+            for (int base = 0; base < oc; base += 64) {
+                const int i = base + lane;
+                bool gone = false;
+                int x = 0;
+                if (i < oc) {
+                    x = l[1 + i];
+                    gone = true;
+                    for (int u = 0; u < cnt; ++u) gone = gone && L.nbuf[u] != x;
+                }
+                unsigned long long m = __ballot(gone);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int gid = __builtin_amdgcn_readlane(x, src);
+                    if (nd < 3 && dry_drop && lane == 0) dry_drop[nd] = gid;
+                    nd++;
+                }
+            }
+            code |= (nd > 3 ? 255 : nd) << 8;
+        }
+        if (lane == 0) { *dry_changed = code; atomicAdd(eval_counter, evals); }
         __syncthreads();
         return;
     }
@@ -2552,9 +2584,10 @@ graph_link_dry_kernel(const float *__restrict__ rows, const double *__restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int g = blockIdx.x;
     int item = jobs3[3 * g + 2];
+    const int the_item = item;
     link_group<METRIC>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs3[3 * g], jobs3[3 * g + 1],
                        [&]() { const int r = item; item = -1; return r; }, max_edges0, k_cap, (int *)nullptr, eval_counter, nbcap,
-                       tested0, testedU, smem, out_changed + g);
+                       tested0, testedU, smem, out_changed + g, (int *)nullptr, the_item);
 }
 
 // The same for the selections an insert search just left on the device (no host step in between): block b stands
@@ -2570,17 +2603,18 @@ graph_link_dry_sel_kernel(const float *__restrict__ rows, const double *__restri
                           const int *__restrict__ cnt0, const int *__restrict__ selU, const int *__restrict__ cntU, int sel_stride,
                           const int *__restrict__ upper_owner, int njobs, int max_edges0, int k_cap, int *__restrict__ out0,
                           int *__restrict__ outU, unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0,
-                          int *__restrict__ testedU, long long n_nodes)
+                          int *__restrict__ testedU, long long n_nodes, int *__restrict__ drop0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int r = blockIdx.x / sel_stride, e = blockIdx.x % sel_stride;
     int job, layer, cnt;
     const int *sel;
-    int *out;
+    int *out, *drop = nullptr; // the ids a list would lose are reported for layer 0 (three per entry)
     if (r < njobs) {
         job = r; layer = 0;
         if (jobs[job].stop_layer > 0) return;
         cnt = cnt0[r]; sel = sel0 + (size_t)r * sel_stride; out = out0 + (size_t)r * sel_stride;
+        drop = drop0 + ((size_t)r * sel_stride + e) * 3;
     } else {
         const int u = r - njobs;
         job = upper_owner[u];
@@ -2593,9 +2627,10 @@ graph_link_dry_sel_kernel(const float *__restrict__ rows, const double *__restri
     const int nb = sel[e];
     int item = ~jobs[job].qref;
     if (nb < 0 || nb >= n_nodes || item < 0 || item >= n_nodes) return;
+    const int the_item = item;
     link_group<METRIC>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, nb, layer,
                        [&]() { const int x = item; item = -1; return x; }, max_edges0, k_cap, (int *)nullptr, eval_counter, nbcap,
-                       tested0, testedU, smem, out + e);
+                       tested0, testedU, smem, out + e, drop, the_item);
 }
 
 // ---- the same with the grouping done on the device (no host work between the insert search and

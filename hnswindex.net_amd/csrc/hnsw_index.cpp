@@ -973,7 +973,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
 {
     const int m = (int)fresh.size();
     const int M2 = 2 * p_.max_edges;
-    const int log_cap = std::max(1024, 8 * p_.max_candidates);
+    const int log_cap = std::max(2048, 16 * p_.max_candidates); // ints per job: [count, -, (node, far key) pairs...]
     W = std::max(2, W);
     constexpr int kAhead = 4; // upper layers are searched up to kAhead windows ahead of the frontier
     const int ring = W * (1 + kAhead);
@@ -987,9 +987,14 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         bool handback = false;
         Part up, lo;     // for a single-layer item `up` is the descent alone, searched together with `lo`
         std::vector<std::vector<int>> sel;   // per layer
-        std::vector<std::vector<char>> same; // per layer and entry: the dry run says the append leaves that list as it reads
-        std::vector<int> r0;      // layer-0 lists read
+        std::vector<std::vector<int>> code;  // per layer and entry, the dry run's verdict on the back-edge append: 0 = the neighbour's
+                                             // list reads as before; else bit 0, bit 1 = the item stays in it, bits 8.. = ids it loses (255: unknown)
+        std::vector<int> drop;    // layer 0: up to three lost ids per entry
+        std::vector<int> r0;      // layer-0 lists read ...
+        std::vector<uint32_t> f0; // ... and the key of the farthest result when each was expanded (0xffffffff: result list not full yet)
         std::vector<uint64_t> rU; // upper-layer lists read: layer << 32 | node
+        bool repeated = false;    // a layer was answered by the exact two-heap traversal (equal distances): order-sensitive
+        int blocker = -1;         // this round: the first item of the window whose linking invalidates this result (-1: none)
     };
     std::vector<Spec> spec((size_t)ring);
     if (mod0_.size() < (size_t)graph_.length) mod0_.resize((size_t)graph_.length, 0u);
@@ -1089,7 +1094,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
                 const int kind = todo[(size_t)i].kind;
                 if (res.flag[i] != 0) { s.handback = true; continue; }
                 s.sel.resize((size_t)s.l0 + 1);
-                s.same.resize((size_t)s.l0 + 1);
+                s.code.resize((size_t)s.l0 + 1);
                 const int lfrom = kind == kLower ? 0 : s.l0, lto = kind == kUpper ? 1 : 0;
                 bool bad = false;
                 for (int layer = lfrom; layer >= lto; --layer) {
@@ -1098,22 +1103,95 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
                     else { const size_t u = (size_t)(upper_base[(size_t)i] + layer - 1); ids = res.selU + u * res.sel_stride; dry = win.dryU + u * res.sel_stride; cnt = res.cntU[u]; }
                     if (cnt < 1 || cnt > (layer == 0 ? M2 : M2 / 2)) { bad = true; break; }
                     s.sel[(size_t)layer].assign(ids, ids + cnt);
-                    s.same[(size_t)layer].resize((size_t)cnt);
-                    for (int e = 0; e < cnt; ++e) s.same[(size_t)layer][(size_t)e] = dry_on && dry[e] == 0;
+                    s.code[(size_t)layer].resize((size_t)cnt);
+                    for (int e = 0; e < cnt; ++e) s.code[(size_t)layer][(size_t)e] = dry_on ? dry[e] : -1; // -1: changed, lost ids unknown
+                    if (layer == 0) s.drop.assign(win.drop0 + (size_t)i * res.sel_stride * 3, win.drop0 + ((size_t)i * res.sel_stride + (size_t)cnt) * 3);
                 }
+                if (kind != kUpper) s.repeated = win.repeated[i] != 0;
+                else if (win.repeated[i]) s.repeated = true;
                 if (bad) { err = "exact window: the device returned an impossible selection count"; return false; }
                 // the read log: upper-layer entries belong to the upper part, layer-0 entries to the lower part
                 const int *lg = win.read_log + (size_t)i * log_cap;
-                const bool overflow = lg[0] < 0 || lg[0] > log_cap - 1;
+                const bool overflow = lg[0] < 0 || lg[0] > (log_cap - 2) / 2;
                 if (kind != kLower) { s.rU.clear(); s.up = Part{true, overflow, R}; }
-                if (kind != kUpper) { s.r0.clear(); s.lo = Part{true, overflow, R}; }
+                if (kind != kUpper) { s.r0.clear(); s.f0.clear(); s.lo = Part{true, overflow, R}; }
                 if (!overflow) {
                     int layer = 0;
-                    for (int e = 1; e <= lg[0]; ++e) {
-                        const int v = lg[e];
+                    for (int e = 0; e < lg[0]; ++e) {
+                        const int v = lg[2 + 2 * e];
                         if (v < 0) layer = -v - 1;
-                        else if (layer == 0) s.r0.push_back(v);
+                        else if (layer == 0) { s.r0.push_back(v); s.f0.push_back((uint32_t)lg[3 + 2 * e]); }
                         else s.rU.push_back(((uint64_t)(uint32_t)layer << 32) | (uint32_t)v);
+                    }
+                }
+            }
+        }
+        // ---- a change the reader does not see ----
+        // Within this round the items are linked in order, and an item's result stays the sequential one as long as no earlier
+        // item of the window changes a list it read IN A WAY IT WOULD HAVE NOTICED.  The dry run says what each back-edge append
+        // does to its list: nothing (code 0), or the list gains the item and / or loses up to three ids.  A search that expanded
+        // node v when its result list was full with farthest key f pushes a neighbour only if the neighbour's key is below f
+        // (GraphNavigator.cs:165), and f never grows: an id v's list GAINS whose key is not below f would have been measured and
+        // turned away; an id it LOSES whose key is not below f was turned away when it was measured (or had been seen before), and
+        // is turned away again wherever the search meets it later.  Either way every push and every pop is the same (the evaluation
+        // count is not) -- provided the search does not depend on the ORDER of a list, which the sorted-list traversal does not
+        // (a job answered by the exact two-heap traversal does, and is not given this benefit).  The distances that decides it,
+        // reader row against gained / lost row, are one batch of id<->id distances on the device (the kernels' own arithmetic, so
+        // the keys compare exactly as they would have inside the search).  Per layer-0 list only the FIRST change of a round is
+        // known this way (the dry run saw the list as it was); a second one, or a change whose lost ids are unknown, blocks.
+        int hi_link = p;
+        for (; hi_link < hi; ++hi_link) {
+            const Spec &s = spec[(size_t)(hi_link % ring)];
+            if (s.t != hi_link || !up_valid(s, R) || !lo_valid(s, R)) break;
+        }
+        struct Change { int t, e; bool known; };
+        xw_first_.clear(); xw_second_.clear();
+        for (int t = p; t < hi_link; ++t) {
+            Spec &s = spec[(size_t)(t % ring)];
+            s.blocker = -1;
+            const std::vector<int> &sel0 = s.sel[0];
+            for (size_t e = 0; e < sel0.size(); ++e) {
+                const int v = sel0[e], c = s.code[0][e];
+                const bool fresh_list = mod0_[(size_t)v] <= s.lo.snap; // unchanged since the dry run saw it
+                auto it = xw_first_.find(v);
+                if (it == xw_first_.end()) {
+                    if (fresh_list && c == 0) continue; // the append leaves it as it reads
+                    xw_first_.emplace(v, XwChange{t, (int)e, fresh_list && c > 0 && ((c >> 8) & 0xff) <= 3});
+                } else if (!xw_second_.count(v)) xw_second_.emplace(v, t); // whatever it does, its list is no longer the one the dry run saw
+            }
+        }
+        if (!xw_first_.empty()) {
+            pa_.clear(); pb_.clear(); pfar_.clear(); powner_.clear();
+            for (int t = p + 1; t < hi_link; ++t) {
+                Spec &s = spec[(size_t)(t % ring)];
+                auto block = [&](int by) { if (by < t && (s.blocker < 0 || by < s.blocker)) s.blocker = by; };
+                const int jid = fresh[(size_t)t];
+                for (size_t r = 0; r < s.r0.size(); ++r) {
+                    auto it = xw_first_.find(s.r0[r]);
+                    if (it == xw_first_.end() || it->second.t >= t) continue;
+                    const XwChange &c1 = it->second;
+                    auto i2 = xw_second_.find(s.r0[r]);
+                    if (i2 != xw_second_.end()) block(i2->second);
+                    const uint32_t far = s.f0[r];
+                    if (!c1.known || s.repeated || far == 0xffffffffu) { block(c1.t); continue; }
+                    const Spec &w = spec[(size_t)(c1.t % ring)];
+                    const int code = w.code[0][(size_t)c1.e], nd = (code >> 8) & 0xff;
+                    if (code & 2) { pa_.push_back(jid); pb_.push_back(fresh[(size_t)c1.t]); pfar_.push_back(far); powner_.push_back(std::make_pair(t, c1.t)); }
+                    for (int d = 0; d < nd; ++d) { pa_.push_back(jid); pb_.push_back(w.drop[(size_t)c1.e * 3 + (size_t)d]); pfar_.push_back(far); powner_.push_back(std::make_pair(t, c1.t)); }
+                }
+            }
+            if (!pa_.empty()) {
+                pd_.resize(pa_.size());
+                if (!dev_->dist_pair_batch(pa_.data(), pb_.data(), (int)pa_.size(), pd_.data())) { err = get_dev_error(); return false; }
+                xw_pairs_ += (uint64_t)pa_.size();
+                for (size_t q = 0; q < pa_.size(); ++q) {
+                    uint32_t u;
+                    std::memcpy(&u, &pd_[q], 4);
+                    const bool odd = pd_[q] != pd_[q] || u == 0x80000000u;         // NaN / -0: no key
+                    const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u); // the kernels' f2key
+                    if (odd || key < pfar_[q]) {                                     // it would have been pushed: the change shows
+                        Spec &s = spec[(size_t)(powner_[q].first % ring)];
+                        if (s.blocker < 0 || powner_[q].second < s.blocker) s.blocker = powner_[q].second;
                     }
                 }
             }
@@ -1123,20 +1201,22 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         uint32_t cur = R;
         int t = p;
         Selection sel;
-        for (; t < hi; ++t) {
+        for (; t < hi_link; ++t) {
             Spec &s = spec[(size_t)(t % ring)];
-            if (s.t != t || !up_valid(s, cur) || !lo_valid(s, cur)) break;
+            if (s.blocker >= 0 || !up_valid(s, cur)) break;                       // (upper layers: any write since the snapshot counts)
+            if (s.lo.overflow && !(s.lo.snap == cur)) break;                      // no read log: only good on the very graph it searched
             ++cur;
             for (size_t layer = 0; layer < s.sel.size(); ++layer) {
                 const uint32_t snap = layer == 0 ? s.lo.snap : s.up.snap; // the dry run saw the graph of that snapshot
                 for (size_t e = 0; e < s.sel[layer].size(); ++e) {
                     const int nb = s.sel[layer][e];
+                    const bool same = s.code[layer][e] == 0;
                     if (layer == 0) {
-                        if (s.same[layer][e] && mod0_[(size_t)nb] <= snap) continue; // unchanged since, and the append leaves it as it reads
+                        if (same && mod0_[(size_t)nb] <= snap) continue; // unchanged since, and the append leaves it as it reads
                         mod0_[(size_t)nb] = cur;
                     } else {
                         const uint64_t key = ((uint64_t)layer << 32) | (uint32_t)nb;
-                        if (s.same[layer][e] && modU_at(key) <= snap) continue;
+                        if (same && modU_at(key) <= snap) continue;
                         modU_[key] = cur;
                     }
                 }

@@ -196,7 +196,14 @@ private:
     std::vector<uint32_t> mod0_;
     std::unordered_map<uint64_t, uint32_t> modU_;
     uint32_t seq_ = 0;
-    uint64_t xw_rounds_ = 0, xw_searches_ = 0, xw_alone_ = 0, xw_linked_ = 0; // exact-window statistics (hnsw_mi355x_exact_window_stats)
+    uint64_t xw_rounds_ = 0, xw_searches_ = 0, xw_alone_ = 0, xw_linked_ = 0, xw_pairs_ = 0;
+    struct XwChange { int t, e; bool known; };             // first change of a layer-0 list in the current round: window item, selection entry
+    std::unordered_map<int, XwChange> xw_first_;
+    std::unordered_map<int, int> xw_second_;               // ... and the item that touches it next
+    std::vector<int> pa_, pb_;                             // id<->id distances asked for (reader row, gained / lost row)
+    std::vector<uint32_t> pfar_;
+    std::vector<std::pair<int, int>> powner_;              // (reader item, writer item)
+    std::vector<float> pd_; // exact-window statistics (hnsw_mi355x_exact_window_stats)
     bool host_lists_stale_ = false; // the HBM mirror holds newer neighbour lists than graph_ (device-linked Add)
     long long dev_pool_len_ = 0;    // pool ints already mirrored
     std::vector<int> grp_of_node0_; // link half: group index per layer-0 neighbour (-1 = none)

@@ -711,6 +711,7 @@ static int search_layer_f(sctx_t *c, int entry_id, int layer, int k, const float
         if (closest.dist > farthest && top.count >= k) break;   /* :147 */
         const edges_t *e = &ix->nodes[closest.id].out[layer];
         alog_put(ix, 0, layer, closest.id);
+        if (ix->alog) { union { float f; uint32_t u; } fu; fu.f = farthest; alog_put(ix, 4, layer, (int)(top.count >= k ? fu.u : 0xFFFFFFFFu)); }
         for (int i = 0; i < e->count; ++i) {
             int nb = e->buf[i];
             if (visited_has(c->vis, nb)) continue;              /* :161 */
@@ -843,14 +844,25 @@ static int connect_at_layer(sctx_t *c, int cur_id, int best_peer, int layer)
         if (ix->allow_removals) edges_add(&nb->in[layer], cur_id); /* :204 */
         edges_add(&nb->out[layer], cur_id);                        /* :207 */
         if (nb->out[layer].count > max_edges_at(ix, layer)) {      /* :209-212 */
+            int alog_old[160], alog_old_n = 0;
+            if (ix->alog) for (int t = 0; t + 1 < nb->out[layer].count && t < 160; t++) alog_old[alog_old_n++] = nb->out[layer].buf[t]; /* the list before the append */
             prune_overflow(c, nb_id, layer);
             if (ix->alog) { /* kind 3: the prune turned the new item away and kept everything else (the list is the same set) */
                 const edges_t *e = &ix->nodes[nb_id].out[layer];
                 int has = 0;
                 for (int t = 0; t < e->count; t++) has |= e->buf[t] == cur_id;
-                alog_put(ix, (!has && e->count == max_edges_at(ix, layer)) ? 3 : 1, layer, nb_id);
+                const int same = !has && e->count == max_edges_at(ix, layer);
+                alog_put(ix, same ? 3 : 1, layer, nb_id);
+                if (!same) { /* kind 5: an id the list gained, kind 6: an id it lost (old = saved copy below) */
+                    if (has) alog_put(ix, 5, layer, cur_id);
+                    for (int t = 0; t < alog_old_n; t++) {
+                        int keep = 0;
+                        for (int u = 0; u < e->count; u++) keep |= e->buf[u] == alog_old[t];
+                        if (!keep) alog_put(ix, 6, layer, alog_old[t]);
+                    }
+                }
             }
-        } else alog_put(ix, 1, layer, nb_id);
+        } else { alog_put(ix, 1, layer, nb_id); alog_put(ix, 5, layer, cur_id); }
     }
     return first; /* :216 */
 }
