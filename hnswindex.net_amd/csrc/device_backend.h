@@ -311,8 +311,10 @@ private:
     bool upload_tail();
     int *s_dry_ = nullptr;  // link_dry_run: [jobs | flags]
     size_t s_dry_cap_ = 0;
-    int *s_wdry_ = nullptr; // windowed insert search: [upper_owner | dry0 | dryU]
+    int *s_wdry_ = nullptr; // windowed insert search: upper_owner
     size_t s_wdry_cap_ = 0;
+    int *s_win_ = nullptr;  // windowed insert search: every output of the launch, laid out like the pinned result block
+    size_t s_win_cap_ = 0;
     SearchHit *s_spill_ = nullptr;
     size_t s_spill_cap_ = 0;
     SearchHit *s_arena_ = nullptr; // range search: the launch's results, packed

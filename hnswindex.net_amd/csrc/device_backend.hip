@@ -228,7 +228,7 @@ Device::~Device()
     }
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_rlog_, (void *)s_dry_, (void *)s_wdry_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_rlog_, (void *)s_dry_, (void *)s_wdry_, (void *)s_win_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
@@ -1035,8 +1035,11 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     const size_t b_dry = windowed ? b_sel0 + b_selU : 0;
     const size_t b_drop = windowed ? 3u * b_sel0 : 0;          // three ids per layer-0 selection entry
     const size_t b_rep = windowed ? b_flag : 0;                // the jobs' "repeated" flags (the job flags themselves are folded to 0 / 1 below)
-    if (windowed && !grow_dev(&s_wdry_, &s_wdry_cap_, nU + (b_sel0 + b_selU + b_drop) / 4u)) return false;
+    if (windowed && !grow_dev(&s_wdry_, &s_wdry_cap_, nU)) return false; // (upper_owner)
     const size_t need = b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 16 + b_log + b_dry + b_drop + b_rep;
+    // windowed: everything the kernels write lives in ONE device block laid out like the pinned results below, so that it comes
+    // back in one copy (a round of the exact window is ~2 ms: a dozen 4-microsecond copies and their launch overhead showed)
+    if (windowed && !grow_dev(&s_win_, &s_win_cap_, (need - b_rep + 3) / 4u + 64)) return false;
     if (need > h_res_cap_) {
         if (h_res_) (void)hipHostFree(h_res_);
         h_res_ = nullptr; h_res_cap_ = 0;
@@ -1049,6 +1052,14 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     int *h_flag = reinterpret_cast<int *>(hb + b_sel0 + b_cnt0 + b_selU + b_cntU);
     unsigned long long *h_ev = reinterpret_cast<unsigned long long *>(hb + ((b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 7) & ~(size_t)7));
     int *h_log = reinterpret_cast<int *>(reinterpret_cast<char *>(h_ev) + 8);
+    // where the kernels write: the members, or (windowed) the same offsets inside s_win_
+    char *db = reinterpret_cast<char *>(s_win_);
+    int *p_sel0 = windowed ? reinterpret_cast<int *>(db) : s_sel_, *p_cnt0 = windowed ? reinterpret_cast<int *>(db + b_sel0) : s_lcnt_;
+    int *p_selU = windowed ? reinterpret_cast<int *>(db + b_sel0 + b_cnt0) : s_selU_, *p_cntU = windowed ? reinterpret_cast<int *>(db + b_sel0 + b_cnt0 + b_selU) : s_cntU_;
+    int *p_flag = windowed ? reinterpret_cast<int *>(db + b_sel0 + b_cnt0 + b_selU + b_cntU) : s_iflag_;
+    const size_t off_ev = (b_sel0 + b_cnt0 + b_selU + b_cntU + b_flag + 7) & ~(size_t)7;
+    unsigned long long *p_evals = windowed ? reinterpret_cast<unsigned long long *>(db + off_ev) : s_evals_;
+    int *p_log = windowed ? reinterpret_cast<int *>(db + off_ev + 8) : s_rlog_;
     // staging: [jobs | processing order]
     SearchJob *h_jobs = static_cast<SearchJob *>(pinned_stage((sizeof(SearchJob) + sizeof(int)) * (size_t)chunk));
     if (!h_jobs) return false;
@@ -1072,7 +1083,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
             }
         }
         HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int), st));
-        HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
+        HIP_OK(hipMemsetAsync(p_evals, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
@@ -1081,9 +1092,9 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
-                       max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, s_sel_ + (size_t)off * sel_stride, s_lcnt_ + off, s_selU_, s_cntU_,        \
-                       sel_stride, s_iflag_ + off, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
-                       windowed ? s_rlog_ : (int *)nullptr, read_log_cap); \
+                       max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, p_sel0 + (size_t)off * sel_stride, p_cnt0 + off, p_selU, p_cntU,        \
+                       sel_stride, p_flag + off, p_evals, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
+                       windowed ? p_log : (int *)nullptr, read_log_cap); \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
     do {                                                                                                                   \
@@ -1109,9 +1120,9 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
 #undef LAUNCH3
 #undef LAUNCH2
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
-        HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        if (!windowed) HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         if (windowed) { // one launch (njobs <= chunk): everything the host validates with rides on the same wait
-            int *d_owner = s_wdry_, *d_dry0 = s_wdry_ + nU, *d_dryU = d_dry0 + (size_t)njobs * sel_stride, *d_drop0 = d_dry0 + b_dry / 4u;
+            int *d_owner = s_wdry_, *d_dry0 = p_log + b_log / 4u, *d_dryU = d_dry0 + (size_t)njobs * sel_stride, *d_drop0 = d_dry0 + b_dry / 4u;
             if (n_upper > 0) {
                 memcpy(h_log + b_log / 4u, win->upper_owner, 4u * (size_t)n_upper); // staged behind the logs (the dry flags land there afterwards)
                 HIP_OK(hipMemcpyAsync(d_owner, h_log + b_log / 4u, 4u * (size_t)n_upper, hipMemcpyHostToDevice, st));
@@ -1122,24 +1133,15 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
             const int grid = (njobs + n_upper) * sel_stride;
 #define LAUNCH_DRY(M)                                                                                                          \
     hipLaunchKernelGGL(graph_link_dry_sel_kernel<M>, dim3(grid), dim3(64), lds_link, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
-                       g_upper_, g_pool_, g_strideU_, s_jobs_, s_iflag_, s_sel_, s_lcnt_, s_selU_, s_cntU_, sel_stride, d_owner, njobs, max_edges0, \
-                       k_cap, d_dry0, d_dryU, s_evals_, nbcap(), g_tested0_, g_testedU_, g_n_, d_drop0)
+                       g_upper_, g_pool_, g_strideU_, s_jobs_, p_flag, p_sel0, p_cnt0, p_selU, p_cntU, sel_stride, d_owner, njobs, max_edges0, \
+                       k_cap, d_dry0, d_dryU, p_evals, nbcap(), g_tested0_, g_testedU_, g_n_, d_drop0)
             if (metric_ == M_SQ) LAUNCH_DRY(M_SQ);
             else if (metric_ == M_COS) LAUNCH_DRY(M_COS);
             else if (metric_ == M_I8) LAUNCH_DRY(M_I8);
             else LAUNCH_DRY(M_UCOS);
 #undef LAUNCH_DRY
             HIP_OK(hipGetLastError());
-            HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            HIP_OK(hipMemcpyAsync(h_log + b_log / 4u, d_dry0, b_dry + b_drop, hipMemcpyDeviceToHost, st)); // flags and dropped ids are adjacent
-            HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
-            HIP_OK(hipMemcpyAsync(h_sel0, s_sel_, b_sel0, hipMemcpyDeviceToHost, st));
-            HIP_OK(hipMemcpyAsync(h_cnt0, s_lcnt_, b_cnt0, hipMemcpyDeviceToHost, st));
-            if (n_upper > 0) {
-                HIP_OK(hipMemcpyAsync(h_selU, s_selU_, 4u * (size_t)n_upper * sel_stride, hipMemcpyDeviceToHost, st));
-                HIP_OK(hipMemcpyAsync(h_cntU, s_cntU_, 4u * (size_t)n_upper, hipMemcpyDeviceToHost, st));
-            }
-            HIP_OK(hipMemcpyAsync(h_log, s_rlog_, b_log, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(hb, db, need - b_rep, hipMemcpyDeviceToHost, st)); // selections, counts, flags, evaluations, read logs, dry-run codes, lost ids
         }
         HIP_OK(hipStreamSynchronize(st)); // the job staging buffer is reused by the next chunk
         stats_.search_launches++;
@@ -1170,7 +1172,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         if (h_flag[i] == 2) { stats_.search_repeats++; h_flag[i] = 0; }
         stats_.search_overflows += (uint64_t)(h_flag[i] != 0);
     }
-    last_insert_jobs_ = njobs <= chunk ? njobs : 0; // a single launch left everything in place
+    last_insert_jobs_ = (njobs <= chunk && !windowed) ? njobs : 0; // a single launch left everything in place (windowed: in its own block)
     last_insert_upper_ = n_upper;
     last_insert_stride_ = sel_stride;
     fetch_njobs_ = windowed ? 0 : njobs;

@@ -1527,19 +1527,21 @@ int HnswIndex::knn_query_concurrent(const float *queries, int count, int dim, in
     {
         std::unique_lock<std::mutex> lk(lane_mu_);
         lane_cv_.wait(lk, [&] { return !lane_busy_[0] || !lane_busy_[1]; });
-        lane = lane_busy_[0] ? 1 : 0;
+        lane = lane_busy_[0] ? 1 : 0; // lane 0 is the primary context itself (a lone caller runs exactly where the exclusive path would)
         lane_busy_[lane] = true;
-        if (!lanes_[lane]) {
+        if (lane > 0 && !lanes_[lane]) {
             lanes_[lane].reset(Device::create_view(dev_.get()));
             if (lanes_[lane]) lanes_[lane]->set_profiling(profiling_);
         }
     }
     struct Release { HnswIndex *ix; int lane; ~Release() { { std::lock_guard<std::mutex> lk(ix->lane_mu_); ix->lane_busy_[lane] = false; } ix->lane_cv_.notify_one(); } } release{this, lane};
-    Device *d = lanes_[lane].get();
+    Device *d = lane == 0 ? dev_.get() : lanes_[lane].get();
     if (!d) return 0;
-    d->rebind(dev_.get()); // no writer is active: the primary's arrays are stable while this call runs
+    if (lane > 0) d->rebind(dev_.get()); // no writer is active: the primary's arrays are stable while this call runs
     rc = -1;
+    if (lane == 0) { resident_queries_ = 0; sharded_resident_ = false; } // hnsw_knn_query leaves its own queries resident on the primary
     if (!d->set_queries(queries, count)) { err = get_dev_error(); return 1; }
+    if (lane == 0) resident_queries_ = count;
     std::vector<SearchJob> jobs((size_t)count);
     const int ep = graph_.entry, top = graph_.top_layer();
     for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0, -1, 0};

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3 profile set, run on the GPU box (via gpurun).  Summaries land in gpurun_out/profiles3/; tools/install_profiles_r3.py
 # copies them into profiles/ and derives r3_pmc_traffic.json (per configuration) and r3_mfma_utilisation.json.
-#   usage: tools/run_profiles_r3.sh [c2|calib|c3|c4|c5|misc|all]
+#   usage: tools/run_profiles_r3.sh [c2|calib|c3|c4|c5|misc|plain|all]
 set -o pipefail
 WHAT=${1:-all}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profiles3; mkdir -p $O
@@ -17,6 +17,13 @@ pmc() { # name, counters, bench args...
   python3 $R/tools/prof_summary.py /tmp/p_$name $O/$name.json graph_search_kernel graph_insert_search_kernel graph_link_kernel > /dev/null
   echo "$name done"; rm -rf /tmp/p_$name
 }
+if [ $WHAT = plain ]; then # only the plain bench lines of every configuration (no profiler attached)
+python3 $R/bench.py > $O/bench_plain.log 2>&1; echo c2 plain done
+python3 $R/bench.py $C4 --small-batch 0 --steps 10 --recall-study-n 0 --no-clustered-check > $O/bench_c4_size.log 2>&1; echo c4 plain done
+python3 $R/bench.py $C5 --small-batch 0 --steps 10 --recall-study-n 0 --no-clustered-check > $O/bench_c5_size.log 2>&1; echo c5 plain done
+python3 $R/bench.py $C3 --small-batch 0 --steps 10 --recall-study-n 0 --seq-adds 500 --window-adds 2000 --bounded-adds 1024 --batched-adds 8192 --no-clustered-check > $O/bench_c3.log 2>&1; echo c3 plain done
+python3 $R/bench.py --data clustered > $O/bench_clustered.log 2>&1; echo clustered done
+fi
 if [ $WHAT = c2 ] || [ $WHAT = all ]; then
 python3 $R/bench.py > $O/bench_plain.log 2>&1; echo plain done
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- python3 $R/bench.py $Q > $O/bench_under_rocprof.log 2>&1
