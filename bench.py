@@ -350,7 +350,7 @@ def main():
         pm = json.loads((ROOT / "profiles" / f"{PROFILE_ROUND}_pmc_traffic.json").read_text())
         for c in pm["configs"].values():
             w = c["workload"]
-            if a.traversal == "device" and (w["n"], w["dim"], w["queries_per_gpu_per_step"], w["ef_search"], w["k"], w["max_edges"]) == \
+            if a.traversal == "device" and a.data == "uniform" and (w["n"], w["dim"], w["queries_per_gpu_per_step"], w["ef_search"], w["k"], w["max_edges"]) == \
                     (a.n, a.dim, per_gpu, a.ef_search, a.k, a.max_edges) and c["row_bytes_fetched"] == fetched_row_bytes:
                 traffic = round(c["graph_search_kernel"]["traffic_bytes_per_launch"])
                 traffic_add = {k: c[k] for k in ("insert_search", "link_half") if k in c}
