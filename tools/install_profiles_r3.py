@@ -28,7 +28,8 @@ def bench(path):
 
 for f, name in (("bench_plain", "bench_1m_plain"), ("bench_under_rocprof", "bench_under_rocprof"), ("bench_c3", "bench_c3_1m_768_ucosine"),
                 ("bench_c4_size", "bench_c4_10m_1gpu"), ("bench_c5_size", "bench_c5_10m_96_int8_1gpu"), ("bench_clustered", "bench_1m_clustered"),
-                ("bench_host_cabi", "bench_host_cabi_200k")):
+                ("bench_host_cabi", "bench_host_cabi_200k"), ("bench_2rank_gloo", "bench_2rank_gloo_rehearsal_200k"),
+                ("bench_native2", "bench_native_2contexts_rehearsal_200k")):
     if (src / f"{f}.log").exists() and json_line(src / f"{f}.log"):
         (dst / f"{r}_{name}.json").write_text(json_line(src / f"{f}.log"))
 for f, name in (("kernel_stats.json", "bench_1m_kernel_stats.json"), ("s_kernel_stats.csv", "bench_1m_kernel_stats.csv"),
