@@ -806,6 +806,9 @@ void Device::reset_stats()
         for (int i = 0; i < 6; ++i) tot += (double)h[i];
         fprintf(stderr, "[phase clocks, insert] RelativeNeighborPruning %.1f%% of the insert jobs' cycles; descent %.1f%% of their traversal cycles\n",
                 100.0 * (double)h[8] / (double)h[9], 100.0 * (double)h[0] / tot);
+        fprintf(stderr, "[phase clocks] descent %.1f%% pop %.1f%% list %.1f%% visited %.1f%% rows %.1f%% push %.1f%% | expansions %llu, prefetch hits %llu, cycles/expansion %.0f, heuristic cycles/job %.0f, job cycles %.0f\n",
+                100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, h[7], h[6],
+                tot / (double)std::max(1ull, h[7]), (double)h[8], (double)h[9]);
     }
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z);
 #endif
