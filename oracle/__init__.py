@@ -86,6 +86,15 @@ def lib():
         L.orc_heap_script.argtypes = [ct.c_int, _I, _F, ct.c_int, _I, _F, _I, _I]
         L.orc_search_layer.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, _F, _I, _F]
         L.orc_find_entry_point.argtypes = [ct.c_void_p, ct.c_int, _F]
+        L.orc_alloc_only.argtypes = [ct.c_void_p, _F, ct.c_int, _I]
+        L.orc_connect_allocated.argtypes = [ct.c_void_p, ct.c_int]
+        L.orc_connect_allocated.restype = None
+        L.orc_window_search.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int]
+        L.orc_window_dry.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, _I, _I]
+        L.orc_window_link.argtypes = [ct.c_void_p, ct.c_int, _I, _I, ct.c_int]
+        L.orc_window_link.restype = None
+        L.orc_dist_ids.argtypes = [ct.c_void_p, ct.c_int, ct.c_int]
+        L.orc_dist_ids.restype = ct.c_float
         L.orc_access_log.argtypes = [ct.c_void_p, ct.c_longlong]
         L.orc_access_log.restype = None
         L.orc_access_log_fetch.argtypes = [ct.c_void_p, ct.POINTER(ct.c_int64), ct.c_longlong]
@@ -227,6 +236,40 @@ class OracleIndex:
         ids = np.empty(a.shape[0], dtype=np.int32)
         lib().orc_add_batched_mt(self._h, _pf(a), a.shape[0], _pi(ids), int(max_batch), int(threads))
         return ids
+
+    # ---- the exact-window schedule taken apart (tests/test_window_model.py) ----
+    def alloc_only(self, vecs):
+        a = _f32(vecs).reshape(-1, self.dim)
+        ids = np.empty(a.shape[0], dtype=np.int32)
+        lib().orc_alloc_only(self._h, _pf(a), a.shape[0], _pi(ids))
+        return ids
+
+    def connect_allocated(self, i):
+        lib().orc_connect_allocated(self._h, int(i))
+
+    def window_search(self, i, stride=130):
+        """Selections per layer of item i on the graph as it stands (nothing written): list of id arrays, layer 0 first."""
+        sel = np.zeros((64, stride), dtype=np.int32)
+        cnt = np.zeros(64, dtype=np.int32)
+        top = lib().orc_window_search(self._h, int(i), _pi(sel), _pi(cnt), stride)
+        return [sel[l, :cnt[l]].copy() for l in range(top + 1)]
+
+    def window_dry(self, nb, layer, item):
+        lost = np.zeros(8, dtype=np.int32)
+        n = ct.c_int(0)
+        code = lib().orc_window_dry(self._h, int(nb), int(layer), int(item), _pi(lost), ct.byref(n))
+        return code, (None if n.value == 255 else lost[:n.value].tolist())
+
+    def window_link(self, i, sels, stride=130):
+        sel = np.zeros((64, stride), dtype=np.int32)
+        cnt = np.zeros(64, dtype=np.int32)
+        for l, s in enumerate(sels):
+            cnt[l] = len(s)
+            sel[l, :len(s)] = s
+        lib().orc_window_link(self._h, int(i), _pi(sel), _pi(cnt), stride)
+
+    def dist_ids(self, a, b):
+        return np.float32(lib().orc_dist_ids(self._h, int(a), int(b)))
 
     def access_log(self, cap):
         """Record which adjacency lists the sequential Add reads / writes from now on (cap entries; 0 = off)."""

@@ -1651,6 +1651,126 @@ ORC_API int orc_get_edges(void *h, int id, int layer, int incoming, int *out, in
     memcpy(out, e->buf, sizeof(int) * (size_t)n);
     return e->count;
 }
+/* ------------------------------------------------------------------------------------
+ * Pieces of the exact-window schedule, one call each, for tests/test_window_model.py: a CPU model of
+ * hnsw_index.cpp::insert_exact_window (speculative searches on one snapshot, validation by read sets, the dry run of the
+ * back-edge appends, "a change the reader does not see") whose result must be the sequential graph.  NOT reference code
+ * paths: they only take the reference's steps apart.
+ * ---------------------------------------------------------------------------------- */
+/* GraphData.AddItem for n vectors (level draws in order), nothing linked yet. */
+ORC_API int orc_alloc_only(void *h, const float *v, int n, int *out_ids)
+{
+    index_t *ix = (index_t *)h;
+    float *tmp;
+    v = incoming(ix, v, n, &tmp);
+    for (int i = 0; i < n; i++) out_ids[i] = alloc_node(ix, v + (size_t)i * (size_t)ix->dim);
+    free(tmp);
+    return n;
+}
+/* ConnectNewNode for an allocated, unlinked node, exactly as add_one does after the allocation (used for items that move the
+ * entry point, and as the sequential reference of the model). */
+ORC_API void orc_connect_allocated(void *h, int id)
+{
+    index_t *ix = (index_t *)h;
+    sctx_t c = {ix, &ix->vis, 0};
+    if (ix->entry < 0) { ix->entry = id; return; }
+    node_t *cur = &ix->nodes[id];
+    int top = ix->nodes[ix->entry].max_layer;
+    int new_ep = cur->max_layer > top;
+    int best = find_entry_point(&c, cur->max_layer, item(ix, id));
+    int start = cur->max_layer < top ? cur->max_layer : top;
+    for (int layer = start; layer >= 0; --layer) best = connect_at_layer(&c, id, best, layer);
+    if (new_ep) ix->entry = id;
+    ix->n_eval += c.n_eval;
+}
+/* The search half of an insert on the graph as it stands (nothing is written): selections per layer into
+ * sel[layer * stride ..] / cnt[layer]; returns min(level, top).  With the access log on, the reads (and the farthest
+ * distance at every expansion) are recorded as for a sequential Add. */
+ORC_API int orc_window_search(void *h, int id, int *sel, int *cnt, int stride)
+{
+    index_t *ix = (index_t *)h;
+    sctx_t c = {ix, &ix->vis, 0};
+    edges_t *s = (edges_t *)calloc((size_t)ix->nodes[id].max_layer + 1, sizeof(edges_t));
+    alog_put(ix, 2, 0, id);
+    batch_search(&c, id, s);
+    int top = ix->nodes[ix->entry].max_layer, lvl = ix->nodes[id].max_layer;
+    int start = lvl < top ? lvl : top;
+    for (int l = 0; l <= start; l++) {
+        cnt[l] = s[l].count;
+        for (int e = 0; e < s[l].count && e < stride; e++) sel[l * stride + e] = s[l].buf[e];
+        free(s[l].buf);
+    }
+    free(s);
+    return start;
+}
+/* Dry run of one back-edge append: what would list (nb, layer) hold after `neighbor.OutEdges[layer].Add(item)` and, on
+ * overflow, PruneOverflow (GraphConnector.cs:207-212)?  Returns 0 when it would read exactly as before, else 1 | 2 (the item
+ * stays) and the ids it loses in lost[0 .. *n_lost) (cap 8; *n_lost = 255 beyond).  Nothing is written. */
+ORC_API int orc_window_dry(void *h, int nb_id, int layer, int item_id, int *lost, int *n_lost)
+{
+    index_t *ix = (index_t *)h;
+    sctx_t c = {ix, &ix->vis, 0};
+    node_t *nb = &ix->nodes[nb_id];
+    edges_t saved = edges_copy(&nb->out[layer]);
+    edges_t saved_in = {0};
+    int touch_in = ix->allow_removals;
+    /* prune_overflow edits in-edge lists of dropped ids when removals are allowed: run it on copies of everything it touches */
+    edges_t *in_copies = NULL;
+    int n_in = 0;
+    if (touch_in) {
+        n_in = saved.count;
+        in_copies = (edges_t *)malloc(sizeof(edges_t) * (size_t)(n_in > 0 ? n_in : 1));
+        for (int i = 0; i < n_in; i++) in_copies[i] = edges_copy(&ix->nodes[saved.buf[i]].in[layer]);
+    }
+    (void)saved_in;
+    edges_add(&nb->out[layer], item_id);
+    if (nb->out[layer].count > max_edges_at(ix, layer)) prune_overflow(&c, nb_id, layer);
+    const edges_t *now = &nb->out[layer];
+    int same = now->count == saved.count;
+    for (int i = 0; same && i < now->count; i++) same = now->buf[i] == saved.buf[i];
+    int code = 0, nl = 0;
+    if (!same) {
+        code = 1;
+        for (int i = 0; i < now->count; i++) if (now->buf[i] == item_id) code |= 2;
+        for (int i = 0; i < saved.count; i++) {
+            int keep = 0;
+            for (int u = 0; u < now->count; u++) keep |= now->buf[u] == saved.buf[i];
+            if (!keep) { if (nl < 8) lost[nl] = saved.buf[i]; nl++; }
+        }
+        if (nl > 8) nl = 255;
+    }
+    *n_lost = nl;
+    /* restore */
+    free(nb->out[layer].buf);
+    nb->out[layer] = saved;
+    if (touch_in) {
+        for (int i = 0; i < n_in; i++) { free(ix->nodes[saved.buf[i]].in[layer].buf); ix->nodes[saved.buf[i]].in[layer] = in_copies[i]; }
+        free(in_copies);
+    }
+    return code;
+}
+/* The link half of an insert with the selections a search on an OLDER graph returned. */
+ORC_API void orc_window_link(void *h, int id, const int *sel, const int *cnt, int stride)
+{
+    index_t *ix = (index_t *)h;
+    sctx_t c = {ix, &ix->vis, 0};
+    int top = ix->nodes[ix->entry].max_layer, lvl = ix->nodes[id].max_layer;
+    int start = lvl < top ? lvl : top;
+    edges_t *s = (edges_t *)calloc((size_t)lvl + 1, sizeof(edges_t));
+    for (int l = 0; l <= start; l++) {
+        s[l] = edges_new(max_edges_at(ix, l) + 1);
+        for (int e = 0; e < cnt[l]; e++) edges_add(&s[l], sel[l * stride + e]);
+    }
+    batch_link(&c, id, s);
+    free(s);
+    ix->n_eval += c.n_eval;
+}
+ORC_API float orc_dist_ids(void *h, int a, int b)
+{
+    index_t *ix = (index_t *)h;
+    return ix->dist(item(ix, a), item(ix, b), ix->dim);
+}
+
 /* access log (see index_t.alog): cap entries are recorded from now on; 0 turns it off */
 ORC_API void orc_access_log(void *h, long long cap)
 {
