@@ -1049,7 +1049,10 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
                 continue;
             }
         }
-        int hi = std::min(m, p + W), hi_up = std::min(m, p + ring);
+        // the window follows what the graph lets through: searching 64 items a round when 4 of them link (a small graph: every
+        // insert reads the same hubs) only lengthens the launch -- three times the recent prefix, within [8, W]
+        const int W_now = std::min(W, std::max(8, (int)(3.0 * xw_prefix_ema_) + 4));
+        int hi = std::min(m, p + W_now), hi_up = std::min(m, p + ring);
         for (int t = p + 1; t < hi_up; ++t) if (graph_.level[(size_t)fresh[(size_t)t]] > top) { hi_up = t; break; }
         hi = std::min(hi, hi_up);
         if (!stage_on) hi_up = hi;
@@ -1233,6 +1236,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         pend[next_set] = true;
         next_set ^= 1;
         xw_linked_ += (uint64_t)bid.size();
+        xw_prefix_ema_ = 0.75 * xw_prefix_ema_ + 0.25 * (double)bid.size();
         seq_ = cur;
         p = t;
     }

@@ -197,6 +197,7 @@ private:
     std::unordered_map<uint64_t, uint32_t> modU_;
     uint32_t seq_ = 0;
     uint64_t xw_rounds_ = 0, xw_searches_ = 0, xw_alone_ = 0, xw_linked_ = 0, xw_pairs_ = 0;
+    double xw_prefix_ema_ = 16.0;                          // items linked per round, recent average (sizes the next window)
     struct XwChange { int t, e; bool known; };             // first change of a layer-0 list in the current round: window item, selection entry
     std::unordered_map<int, XwChange> xw_first_;
     std::unordered_map<int, int> xw_second_;               // ... and the item that touches it next
