@@ -64,7 +64,11 @@ int hnsw_remove(void *handle, const int *ids, int count);
 
 /* :119-149  KnnQuery -> BatchKnnQuery (HNSWIndex.cs:129-137).  out_ids / out_dists are
  * count x k row-major; rows with fewer than k results are padded with id -1, dist NaN
- * (:144).  Returns 0 on success (and for a null handle), -1 on error. */
+ * (:144).  Returns 0 on success (and for a null handle), -1 on error.
+ * Threads (the reference: operations of one type may overlap on an index, README.md:64-65): calls on one handle
+ * from several host threads run side by side on the GPU, each on a query lane of its own; a call of 32 768
+ * queries or more has the handle to itself and uploads all but its first rows behind its launch; every other
+ * export takes the handle exclusively.  Any mix of calls from any number of threads is safe. */
 int hnsw_knn_query(void *handle, const float *vectors, int count, int dim, int k, int *out_ids, float *out_dists);
 
 /* :151-197  RangeQuery -> BatchRangeQuery (HNSWIndex.cs:144-168).  For query i, out_ids[i] /
