@@ -910,6 +910,13 @@ static int spill_cap_for_tests()
 // (10M x 96 int8: 2.19 -> 2.43 M queries/s, 1.03 -> 1.12 M adds/s; 10M x 128 f32: +3 % / +5 %), while a full
 // launch at 1M nodes is bandwidth-bound and gains nothing.  HNSW_MI355X_OVERLAP=0 disables, =2 forces it for
 // every launch (tests).
+// Shadow traversals in the search launches (graph_search_kernel): idle waves of a draining launch start the exact
+// traversal of the jobs still running.  HNSW_MI355X_SHADOW=0 disables (tests run both).
+static bool shadow_mode()
+{
+    const char *e = std::getenv("HNSW_MI355X_SHADOW");
+    return !e || std::atoi(e) != 0;
+}
 static int overlap_mode()
 {
     const char *e = std::getenv("HNSW_MI355X_OVERLAP");
@@ -968,7 +975,11 @@ bool Device::ensure_search_scratch(long long chunk, long long slots, int k, size
         HIP_OK(hipMalloc(&s_visited_, s_visited_bytes_));
         HIP_OK(hipMemsetAsync(s_visited_, 0, s_visited_bytes_, S(stream_)));
     }
-    if (!s_jobctr_) HIP_OK(hipMalloc(&s_jobctr_, sizeof(int)));
+    if (!s_jobctr_ || (size_t)chunk > s_jobs_cap_) { // [next job, next shadow, -, -, one word per job] (graph_search_kernel)
+        if (s_jobctr_) HIP_OK(hipFree(s_jobctr_));
+        s_jobctr_ = nullptr;
+        HIP_OK(hipMalloc(&s_jobctr_, sizeof(int) * (4 + std::max<size_t>((size_t)chunk, s_jobs_cap_))));
+    }
     if ((size_t)chunk > s_jobs_cap_) {
         if (s_jobs_) HIP_OK(hipFree(s_jobs_));
         if (s_cnt_) HIP_OK(hipFree(s_cnt_));
@@ -1578,7 +1589,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         const int nj = (int)std::min<long long>(chunk, njobs - off);
         memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
         HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
-        HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int), st));
+        HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int) * (4 + (size_t)nj), st));
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
@@ -1588,7 +1599,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0), \
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() ? 0x100 : 0), \
                        gate); \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \

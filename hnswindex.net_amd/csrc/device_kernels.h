@@ -1212,7 +1212,7 @@ template <int METRIC, bool HASHED>
 __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                          const GraphView &G, const SearchJob jb, int k, int cand_cap, ND *spill, int spill_cap,
                                          VisitedSet<HASHED> &V, const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals,
-                                         ReadLog &RL)
+                                         ReadLog &RL, const int *abort_word = nullptr, bool *aborted = nullptr)
 {
     const LdsHeap top{L.top};
     const SpillHeap cand{L.cand, cand_cap, spill};
@@ -1275,7 +1275,13 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
     // is already in registers and one dependent memory round trip disappears.
     int pre_id = -1, pre_a = 0, pre_b = 0;
     const int lstride = layer == 0 ? G.stride0 : G.strideU;
+    int abort_v = 0; // a shadow traversal (graph_search_kernel): bit 0 of *abort_word = the job has been answered
     while (cand_n > 0 && !overflow) {
+        if (abort_word) {
+            // read now, looked at one expansion later: the load rides with this expansion's own
+            if (__builtin_amdgcn_readfirstlane(abort_v) & 1) { *aborted = true; return false; }
+            abort_v = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         HEnt c = heap_pop<true>(cand, cand_n);          // :146
         if (c.key > far_key && top_n >= k) break;       // :147-150
         RL.put(c.id, lane);
@@ -1809,6 +1815,10 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
 // informational).  NS = 0: two-heap traversal only.
 // One job on this wave.  `vis` / `spill`: the wave's own scratch (vis all zero on entry; the caller
 // clears it afterwards).
+// Job words of a launch with SHADOW traversals (graph_search_kernel): bit 0 answered (results written), bit 1 the
+// wave that owns the job met a tie, bit 2 a shadow traversal has been started for it.
+constexpr int kJobAnswered = 1, kJobTied = 2, kJobShadowed = 4;
+
 template <int METRIC, int NS, bool HASHED>
 __device__ __forceinline__ void search_job(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
@@ -1816,7 +1826,8 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
                     const SearchJob *__restrict__ jobs, int k, int cand_cap, ND *__restrict__ spill,
                     int spill_cap, VisitedSet<HASHED> &V, int k_out, int *__restrict__ out_ids,
                     float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
-                    unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap)
+                    unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap,
+                    int *__restrict__ job_word = nullptr, bool shadow = false)
 {
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x;
@@ -1835,14 +1846,22 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
     unsigned long long evals = 0;
     int top_n = 0;
-    bool repeated = false;
+    bool repeated = shadow;
     ReadLog RL{nullptr, 0, 0};
+    // With shadows, whoever sets kJobAnswered first writes the job's results (both traversals compute the same ones).
+    auto claim_answer = [&]() -> bool {
+        if (!job_word) return true;
+        int old = 0;
+        if (lane == 0) old = atomicOr(job_word, kJobAnswered);
+        return (__builtin_amdgcn_readfirstlane(old) & kJobAnswered) == 0;
+    };
     if constexpr (NS > 0) {
-        if (jb.aux != -2) {
+        if (jb.aux != -2 && !shadow) {
         bool tie = false;
         // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
         const bool ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL);
         if (!(ok1 && tie)) {
+            if (!claim_answer()) return;
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
             // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
             for (int r = lane; r < k_out; r += 64) {
@@ -1857,14 +1876,23 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
             }
             return;
         }
-        // equal distances where the heap layout shows: this wave starts over with the exact traversal
+        // equal distances where the heap layout shows: the exact traversal answers this job -- the shadow that an
+        // idle wave has already started for it (see graph_search_kernel), or this wave, starting over
+        if (job_word) {
+            int old = 0;
+            if (lane == 0) old = atomicOr(job_word, kJobTied);
+            if (__builtin_amdgcn_readfirstlane(old) & (kJobShadowed | kJobAnswered)) return;
+        }
         V.clear(lane);
         evals = 0;
         top_n = 0;
         repeated = true;
         }
     }
-    const bool ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL);
+    bool aborted = false;
+    const bool ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL,
+                                             shadow ? job_word : nullptr, &aborted);
+    if (aborted || !claim_answer()) return;
     if (jb.aux == -2) { // SearchLayer's own return value: topCandidates.ToArray(), the heap's array (BinaryHeap.cs:41-44)
         __syncthreads();
         for (int r = lane; r < k_out; r += 64) {
@@ -1946,13 +1974,36 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     // rest is still arriving on the copy engine, and *ready (a word in host memory the uploading thread advances) says how
     // many rows are there.  Jobs are taken in order, so a wave almost never has to wait; when it does it sleeps and
     // polls, for a bounded time -- a job whose row has not arrived by then is handed back (flag 1), never waited for.
+    // SHADOW traversals (overlap bit 8; job_counter then is [next job, next shadow, -, -, one word per job ...], all zero
+    // at launch).  One traversal in 700 meets equal distances where the heap layout shows and starts over in the exact
+    // two-heap form, three times as long as the sorted one; whenever that happened to one of the LAST jobs of a launch,
+    // the whole launch waited for it -- 7 % of a 65 536-query launch at C2, 17-35 % of the 12 500-query launches
+    // (measured with the re-runs compiled out).  So a wave that finds the queue empty does not leave: it starts the
+    // exact traversal of a job another wave is still working on, latest job first.  Almost always the owner answers the
+    // job soon after and the shadow stops at its next expansion; when the owner meets a tie it finds the exact
+    // traversal already under way and leaves it to the shadow.  Results are written by whoever finishes first -- both
+    // compute the reference's answer.
+    const bool shadows = (overlap & 0x100) != 0 && NS > 0;
+    int *job_words = job_counter + 4;
     int known_ready = 0;
     for (;;) {
         int job = 0;
+        bool shadow = false;
         if (lane == 0) job = atomicAdd(job_counter, 1);
         job = __builtin_amdgcn_readfirstlane(job);
-        if (job >= njobs) break;
-        if (ready) {
+        if (job >= njobs) {
+            if (!shadows) break;
+            int t = 0;
+            if (lane == 0) t = atomicAdd(job_counter + 1, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= njobs || t >= (int)gridDim.x) break; // only the last gridDim.x jobs can still be running
+            job = njobs - 1 - t;
+            int old = 0;
+            if (lane == 0) old = atomicOr(job_words + job, kJobShadowed);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old & (kJobAnswered | kJobTied)) continue; // answered, or its owner is already starting over
+            shadow = true;
+        } else if (ready) {
             const int need = __builtin_amdgcn_readfirstlane(jobs[job].qref);
             if (need >= known_ready) {
                 // a read of host memory per poll: few polls, far apart (thousands of waves polling back to back were
@@ -1966,13 +2017,18 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the rows read next were written by the copy engine
                 if (need >= known_ready) {
-                    if (lane == 0) { out_cnt[job] = 0; out_flag[job] = 1; }
+                    if (lane == 0) {
+                        out_cnt[job] = 0;
+                        out_flag[job] = 1;
+                        if (shadows) atomicOr(job_words + job, kJobAnswered); // no shadow for a job whose row is not there
+                    }
                     continue;
                 }
             }
         }
         search_job<METRIC, NS, HASHED>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
-                               V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job, overlap);
+                               V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job, overlap, shadows ? job_words + job : nullptr,
+                               shadow);
         V.clear(lane);
     }
 }

@@ -125,6 +125,32 @@ def test_equal_distances_are_repeated_with_the_exact_traversal(Index):
     assert ix.stats()["search_repeats"] > 400
 
 
+@pytest.mark.parametrize("shadow", ["1", "0"])
+def test_draining_launch_with_ties_shadow_traversals(Index, monkeypatch, shadow):
+    # Far more queries than resident waves, on data where one query in three meets a tie: when the queue runs dry the
+    # idle waves start exact "shadow" traversals of the jobs still running (graph_search_kernel), and whoever finishes
+    # first answers.  Every answer must still be the oracle's, with the shadows on and off, and on the hashed visited
+    # set as well.
+    monkeypatch.setenv("HNSW_MI355X_SHADOW", shadow)
+    rng = np.random.default_rng(11)
+    x = rng.integers(0, 4, (6000, 12)).astype(np.float32)
+    x += rng.random((6000, 12), dtype=np.float32) * np.float32(1e-3) * (rng.random((6000, 1)) < 0.7)  # ties in a third of the rows
+    q = x[rng.integers(0, 6000, 14000)] + (rng.integers(0, 2, (14000, 12)) * 0.5).astype(np.float32)
+    ref = oracle.OracleIndex(12, max_edges=12, max_candidates=60, min_nn=48, collection_size=6000)
+    ref.add_batched(x, 16384)
+    want = ref.knn_query(q, 10)
+    for vis_hash in ("0", "1"):
+        monkeypatch.setenv("HNSW_MI355X_VIS_HASH", vis_hash)
+        ix = _build(Index, x, 12, 60, 48, 16384)
+        assert ix.graph_hash() == ref.graph_hash()
+        for _ in range(2):
+            got = ix.knn_query(q, 10)
+            assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
+        st = ix.stats()
+        assert st["search_overflows"] == 0 and st["search_repeats"] > 100
+        del ix
+
+
 def test_many_jobs_per_resident_wave(Index):
     # persistent launches: far more traversals than resident waves, so every wave reuses its visited
     # bitset (cleared in the kernel) many times; also Add in one call with a batch cap above the slots

@@ -69,6 +69,34 @@ __global__ void __launch_bounds__(256) gather_rec16(const float4 *__restrict__ t
     if (acc == 123.456f) out[0] = acc;
 }
 
+// 512-B rows with 16-byte loads.  LPR = 2: two lanes per row, lane h reads the float4 at words 8k + 4h (the AVX lanes
+// 4h..4h+3 of block k: the reference's summation order survives), 16 loads per lane, 32 rows per pass.  LPR = 8: eight
+// lanes per row, lane j reads the float4 at words 32i + 4j (whole 128-B lines per instruction; the summation order would
+// need a chain across lanes), 4 loads per lane and pass, PASSES passes in flight.
+template <int LPR, int PASSES>
+__global__ void __launch_bounds__(256) gather_vec4_512(const float4 *__restrict__ table, const int *__restrict__ ids, float *__restrict__ out, long long nrows)
+{
+    constexpr int RPP = 64 / LPR, LOADS = 32 / LPR; // rows per pass, float4 loads per lane and row
+    const int lane = threadIdx.x & 63, grp = lane / LPR, j = lane % LPR;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    float acc = 0.f;
+    for (long long r0 = wave * RPP * PASSES; r0 < nrows; r0 += nwaves * RPP * PASSES) {
+        float4 v[PASSES][LOADS];
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const long long r = r0 + p * RPP + grp;
+            const float4 *row = table + (size_t)ids[r < nrows ? r : 0] * 32;
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) v[p][k] = row[LPR * k + j];
+        }
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) acc += v[p][k].x + v[p][k].y + v[p][k].z + v[p][k].w;
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
 int main(int argc, char **argv)
 {
     const int row_bytes = argc > 1 ? atoi(argv[1]) : 512;
@@ -92,13 +120,16 @@ int main(int argc, char **argv)
     int dev = 0, cus = 256;
     CK(hipGetDevice(&dev));
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const char *names[3] = {"8 lanes x strided dwords (the product's mapping)", "8 lanes x one 16-byte load (records only)", ""};
+    const char *names[5] = {"8 lanes x strided dwords (the product's mapping)", "8 lanes x one 16-byte load (records only)", "2 lanes x 16 float4 loads, 32 rows per pass", "8 lanes x 4 float4 loads x 4 passes (whole lines)", "2 lanes x 16 float4 loads x 2 passes"};
     for (int grid_mult : {4, 8, 16}) {
         const int grid = cus * grid_mult;
         float best = 1e30f;
         for (int rep = 0; rep < 4; ++rep) {
             CK(hipEventRecord(a));
-            if (row_bytes == 128 && variant == 1) hipLaunchKernelGGL(gather_rec16<8>, dim3(grid), dim3(256), 0, 0, (const float4 *)table, ids, out, nrows);
+            if (row_bytes == 512 && variant == 2) hipLaunchKernelGGL((gather_vec4_512<2, 1>), dim3(grid), dim3(256), 0, 0, (const float4 *)table, ids, out, nrows);
+            else if (row_bytes == 512 && variant == 3) hipLaunchKernelGGL((gather_vec4_512<8, 4>), dim3(grid), dim3(256), 0, 0, (const float4 *)table, ids, out, nrows);
+            else if (row_bytes == 512 && variant == 4) hipLaunchKernelGGL((gather_vec4_512<2, 2>), dim3(grid), dim3(256), 0, 0, (const float4 *)table, ids, out, nrows);
+            else if (row_bytes == 128 && variant == 1) hipLaunchKernelGGL(gather_rec16<8>, dim3(grid), dim3(256), 0, 0, (const float4 *)table, ids, out, nrows);
             else if (row_bytes == 128) hipLaunchKernelGGL((gather_dwords<32, 8>), dim3(grid), dim3(256), 0, 0, table, ids, out, nrows);
             else if (row_bytes == 512) hipLaunchKernelGGL((gather_dwords<128, 4>), dim3(grid), dim3(256), 0, 0, table, ids, out, nrows);
             else hipLaunchKernelGGL((gather_dwords<768, 4>), dim3(grid), dim3(256), 0, 0, table, ids, out, nrows);

@@ -63,5 +63,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_host -o h -- pyth
 python3 $R/tools/prof_summary.py /tmp/p_host $O/kernel_stats_host_cabi.json hnsw:: > /dev/null; rm -rf /tmp/p_host
 echo misc done
 fi
+if [ $WHAT = issue ]; then # what bounds the int8 traversal: instruction issue against wave cycles (one pass per counter group)
+rocprofv3 --list-avail > $O/list_avail.txt 2>&1 || true
+pmc c5_issue_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $C5
+pmc c5_issue_b "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" $C5
+pmc c2_issue_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
+pmc c2_issue_b "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"
+fi
 ls -la $O
 for f in $O/bench_*.log; do echo $f; grep '^{' $f | cut -c1-300; done
