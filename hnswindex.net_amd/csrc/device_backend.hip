@@ -1636,6 +1636,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         memcpy(out_d + (size_t)off * k_out, h_d, 4u * (size_t)nj * k_out);
         for (int i = 0; i < nj; ++i) {
             if (h_flag[i] == 2) { stats_.search_repeats++; if (!keep_repeat_flag) h_flag[i] = 0; }
+            else if (h_flag[i] == 4) { stats_.tie_windows++; h_flag[i] = 0; } // informational: a group window closed cleanly
         }
         memcpy(out_flag + off, h_flag, sizeof(int) * (size_t)nj);
         const unsigned long long ev = *h_ev;

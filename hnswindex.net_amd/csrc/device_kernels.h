@@ -289,6 +289,8 @@ __device__ __forceinline__ int2 pack_ent(HEnt e) { return make_int2(e.id, (int)e
 // number of resident waves -- is set by the common case, not the worst one.
 struct LdsHeap {
     ND *b;
+    __device__ __forceinline__ int2 lane_get(int i) const { return *reinterpret_cast<const int2 *>(b + i); }
+    __device__ __forceinline__ void lane_set(int i, int2 v) const { *reinterpret_cast<int2 *>(b + i) = v; }
     __device__ __forceinline__ HEnt get(int i) const { return uniform_ent(*reinterpret_cast<const int2 *>(b + i)); }
     __device__ __forceinline__ void set(int i, HEnt v) const { *reinterpret_cast<int2 *>(b + i) = pack_ent(v); }
     // both children in one LDS round trip (entry i + 1 may be one past the heap: never used then)
@@ -304,6 +306,13 @@ struct SpillHeap {
     ND *b;
     int cap;
     ND *g;
+    // per-lane (divergent) access for the wave-parallel pop
+    __device__ __forceinline__ int2 lane_get(int i) const { return i < cap ? *reinterpret_cast<const int2 *>(b + i) : *reinterpret_cast<const int2 *>(g + (i - cap)); }
+    __device__ __forceinline__ void lane_set(int i, int2 v) const
+    {
+        if (i < cap) *reinterpret_cast<int2 *>(b + i) = v;
+        else *reinterpret_cast<int2 *>(g + (i - cap)) = v;
+    }
     __device__ __forceinline__ HEnt get(int i) const
     {
         return uniform_ent(i < cap ? *reinterpret_cast<const int2 *>(b + i) : *reinterpret_cast<const int2 *>(g + (i - cap)));
@@ -363,6 +372,70 @@ __device__ __forceinline__ HEnt heap_pop(const H &h, int &count) // BinaryHeap.c
         }
         h.set(i, item);
     }
+    return result;
+}
+
+// heap_pop with the wave's lanes side by side -- the same array afterwards, entry for entry.  The scalar loop above
+// pays one LDS round trip per level (children, compare, branch), nine levels deep in a candidate heap; but WHICH child
+// a node hands up (:76-77: the right one only if the left compares below it) does not depend on the item that sinks,
+// so the whole root-to-leaf chain of those choices can be read off in parallel: 63 lanes load the child pairs of a
+// six-level subtree, one ballot holds their choices, six scalar steps follow them, and the next subtree starts where
+// they end.  Then one lane per level of that chain loads its entry, a ballot finds where the item stops (:79), and the
+// entries above move up one level together.  Three to four round trips instead of seven to ten: the exact traversal
+// of a 1M-node graph took 1.3 ms on an idle chip against the sorted one's 0.45, nearly all of it in these loops --
+// and the exact traversal is what a launch's last jobs wait for (graph_search_kernel, shadows).
+template <bool CLOSER, class H>
+__device__ __forceinline__ HEnt heap_pop_wave(const H &h, int &count, int lane) // BinaryHeap.cs:53-87
+{
+    const HEnt result = h.get(0);
+    const int n = --count;
+    if (n == 0) return result;
+    const HEnt item = h.get(n);
+    const int half = n >> 1; // nodes below `half` have a left child (:70)
+    // the chain of chosen children from the root: lane d keeps the node of depth d + 1
+    int v_path = 0, depth = 0;
+    {
+        int cur = 0;                                                     // root of the subtree looked at
+        const int l = 31 - __builtin_clz(lane + 1), o = lane + 1 - (1 << l); // this lane's place in it: level, offset
+        while (cur < half) {
+            const int node = ((cur + 1) << l) - 1 + o;
+            const bool inner = lane < 63 && node < half;
+            bool right = false;
+            if (inner) {
+                const int2 lv = h.lane_get(2 * node + 1);
+                if (2 * node + 2 < n) {
+                    const int2 rv = h.lane_get(2 * node + 2);
+                    right = cmp_lt0<CLOSER>(HEnt{lv.x, (unsigned)lv.y}, HEnt{rv.x, (unsigned)rv.y}); // :76-77
+                }
+            }
+            const unsigned long long rm = __ballot(right), im = __ballot(inner);
+            int j = 0, nd = cur;
+#pragma unroll
+            for (int lev = 0; lev < 6; ++lev) {
+                if (!((im >> j) & 1ull)) break;
+                const int bit = (int)((rm >> j) & 1ull);
+                nd = 2 * nd + 1 + bit;
+                j = 2 * j + 1 + bit;
+                if (lane == depth) v_path = nd;
+                ++depth;
+            }
+            if (nd == cur) break;
+            cur = nd;
+            if (j < 63) break; // the chain ended inside this subtree (a node without children)
+        }
+    }
+    // where does the item stop?  (:79: at the first chosen child that does not compare above it)
+    bool stops = false;
+    int2 mine = make_int2(0, 0);
+    if (lane < depth) {
+        mine = h.lane_get(v_path);
+        stops = cmp_le0<CLOSER>(HEnt{mine.x, (unsigned)mine.y}, item);
+    }
+    const unsigned long long sm = __ballot(stops);
+    const int s = sm ? (int)__builtin_ctzll(sm) : depth; // levels the item sinks
+    if (lane < s) h.lane_set((v_path - 1) >> 1, mine);   // :80-81, all levels at once
+    const int at = s > 0 ? __builtin_amdgcn_readlane(v_path, s - 1) : 0;
+    if (lane == 0) h.lane_set(at, pack_ent(item));       // :84
     return result;
 }
 
@@ -841,13 +914,34 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
 // the array layout.  The layout shows only when (i) the farthest result is evicted while another
 // entry has the same distance, (ii) the closest candidate is popped while another open candidate
 // has the same distance, or (iii) equal distances sit next to each other in what the caller
-// consumes in order (OrderBy + Take(k), Span.Sort).  (ii) and (iii) raise `tie` and the caller
-// repeats the job with the exact two-heap traversal below.  After (i) the survivor (the reference
+// consumes in order (OrderBy + Take(k), Span.Sort).  (iii) raises `tie` and the caller
+// repeats the job with the exact two-heap traversal below; (ii) opens a GROUP WINDOW (below) and raises
+// `tie` only if the window cannot show that the order was immaterial.  After (i) the survivor (the reference
 // may hold its twin instead -- same distance, other id, possibly still a candidate there) is only
 // marked DOUBTFUL: the search goes on, and `tie` is raised if a doubtful entry is popped or is still
 // in the list at the end; usually the next few insertions push it out and nothing depended on it.
 // Equal distances elsewhere in the list are harmless.  Position p lives in lane p & 63 of register
 // set p >> 6; id bit 31 = expanded, bit 30 = doubtful (node ids stay below 2^30).
+//
+// The group window of (ii).  Open candidates A, B, .. of one distance d, one of them popped: the reference pops them in
+// an order only its heap knows, and between two of them it expands whatever closer candidates the first one's
+// expansion turned up.  Whatever that order: as long as every member is still in the list, farthestResultDist >= d,
+// so every node closer than d that any expansion turns up is accepted (:165) and expanded before anything farther than
+// d -- the nodes expanded until the first pop beyond d are the members plus everything closer than d that is
+// reachable from them through such nodes, a closure that does not depend on the order, and so are the nodes
+// evaluated (their unvisited neighbours) and the list afterwards (the k closest of what there was and what was
+// evaluated; a node turned away in one order is pushed out in the other).  A member can only leave the list when k
+// entries rank before it, and the entries closer than d at any moment of any order are a subset of those there when
+// the window closes in THIS order -- so if all members are still listed then, none was evicted in any order, and the
+// state at that point (list, marks, visited set, evaluation count) is the reference's whichever way its heap went.
+// The window therefore asks for the exact traversal only when (a) an evaluated neighbour has distance d itself (a
+// member the other order might have turned away), (b) the list's far end meets equal distances while it is open (an
+// entry turned away or evicted by equality: which twin stays depends on the order of arrival), (c) a member is missing
+// when it closes, or (d) a second group opens inside it.  Of the 100 windows a 65 536-query launch at C2 opens, 86
+// close cleanly (the others sit at the far end of the list, where the members themselves are evicted); with the ten
+// or so unresolved cases of (i) that leaves 24 exact traversals per launch where there were 75 -- which matters because
+// an exact traversal takes three times as long as a sorted one and a launch ends with its last job (17-35 % of a
+// 12 500-query launch at 10M was the wait for such jobs, measured).
 __device__ __forceinline__ int dpp_wave_shr1(int carry_in, int v)
 {
     return __builtin_amdgcn_update_dpp(carry_in, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); // lane 0 keeps carry_in
@@ -983,6 +1077,16 @@ struct SortedTop {
         boundary_tie = total > k && lds[k].y == last_key;
         __syncthreads();
     }
+    __device__ __forceinline__ int count_key(unsigned k0, int count, int lane) const // entries of that key (uniform result)
+    {
+        int c = 0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (64 * t >= count) break;
+            c += (int)__popcll(__ballot(lane + 64 * t < count && key[t] == k0));
+        }
+        return c;
+    }
     // any p in [1, upto) with key[p] == key[p - 1]?  (uniform result)
     __device__ __forceinline__ bool adjacent_equal(int upto, int lane) const
     {
@@ -1006,7 +1110,7 @@ template <int METRIC, int NS, bool HASHED>
 __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                                 const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet<HASHED> &V,
                                                 const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals,
-                                                int oflags, ReadLog &RL, bool *order_tie_out = nullptr)
+                                                int oflags, ReadLog &RL, bool *order_tie_out = nullptr, bool *window_out = nullptr)
 {
     int *nbuf = L.nbuf;
     float *dbuf = L.dbuf;
@@ -1032,13 +1136,22 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     const int lstride = layer == 0 ? G.stride0 : G.strideU;
     PH(0);
     constexpr int kDoubt = 0x40000000, kIdMask = 0x3fffffff;
+    unsigned grp_key = 0u; // the group window of (ii): its distance and its members (0: no window open)
+    int grp_cnt = 0;
     while (!unsafe && !tie) {
         const int pos = T.first_open(top_n, lane); // :146 closest candidate; none left <=> :147-150 / empty
         if (pos < 0) break;
         const HEnt c = T.at(pos);
         if (c.id & kDoubt) { tie = true; break; } // the reference may be expanding its twin instead
+        if (grp_cnt > 0 && c.key > grp_key) { // the group window closes: (c) every member still listed?
+            if (T.count_key(grp_key, top_n, lane) != grp_cnt) { tie = true; break; }
+            grp_cnt = 0;
+            if (window_out) *window_out = true;
+        }
         T.mark(pos, lane);
-        RL.put(c.id & kIdMask, lane, top_n >= k ? far_key : 0xffffffffu);
+        // inside a window the farthest distance at this pop depends on the order: no bound is logged (the reader's
+        // validation then treats every change of the list as visible)
+        RL.put(c.id & kIdMask, lane, top_n >= k && grp_cnt == 0 ? far_key : 0xffffffffu);
         PH(1);
         int n, nb_a = 0, nb_b = 0;
         if (c.id == pre_id) {
@@ -1083,7 +1196,10 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 const int nxt = T.first_open(top_n, lane);
                 if (nxt >= 0) {
                     const HEnt e = T.at(nxt);
-                    if (e.key == c.key) tie = true; // (ii)
+                    if (e.key == c.key) { // (ii)
+                        if (grp_cnt == 0) { grp_key = c.key; grp_cnt = T.count_key(c.key, top_n, lane); }
+                        else if (c.key != grp_key) tie = true; // (d)
+                    }
                     pre_id = e.id & kIdMask;
                     const int *pl = G.list(pre_id, layer);
                     pre_a = lane < lstride ? pl[lane] : 0;
@@ -1129,7 +1245,10 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             const int nxt = T.first_open(top_n, lane);
             if (nxt >= 0) {
                 const HEnt e = T.at(nxt);
-                if (e.key == c.key) tie = true; // (ii): which of the two the reference pops first is a matter of heap layout
+                if (e.key == c.key) { // (ii): which of the two the reference pops first is a matter of heap layout
+                    if (grp_cnt == 0) { grp_key = c.key; grp_cnt = T.count_key(c.key, top_n, lane); }
+                    else if (c.key != grp_key) tie = true; // (d)
+                }
                 pre_id = e.id & kIdMask;
                 const int *pl = G.list(pre_id, layer);
                 pre_a = lane < lstride ? pl[lane] : 0;
@@ -1155,6 +1274,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             const int my_id = overlapped ? lane_id : (i < m ? nbuf[i] : 0);
             const unsigned my_key = f2key(my_d);
             if (__ballot(valid && key_unsafe(my_d))) { unsafe = true; break; }
+            if (grp_cnt > 0 && __ballot(valid && (my_key == grp_key || (top_n >= k && my_key == far_key)))) { tie = true; break; } // (a), (b)
             unsigned long long maybe = __ballot(valid && (top_n < k || my_key < far_key));
 #ifndef HNSW_NO_BATCH_MERGE
             if (maybe & (maybe - 1)) { // two or more: one counting merge instead of as many list shifts
@@ -1162,7 +1282,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 bool boundary_tie = false;
                 T.merge(maybe, my_key, my_id, top_n, k, lane, reinterpret_cast<uint2 *>(L.top), last, boundary_tie);
                 if (top_n == k) {
-                    if (boundary_tie) T.mark_key(last, top_n, lane, kDoubt); // (i)
+                    if (boundary_tie) { T.mark_key(last, top_n, lane, kDoubt); if (grp_cnt > 0) tie = true; } // (i); (b)
                     far_key = last;                                          // :176-177
                 }
                 maybe = 0ull;
@@ -1177,15 +1297,19 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                     T.insert(dk, __builtin_amdgcn_readlane(my_id, src), top_n, k, lane); // :168-174
                     if (top_n == k) {
                         const unsigned nf = T.key_at(k - 1);                             // :176-177
-                        if (evicts && nf == far_key) T.mark_key(nf, top_n, lane, kDoubt); // (i): one of several equally far results was dropped
+                        if (evicts && nf == far_key) { T.mark_key(nf, top_n, lane, kDoubt); if (grp_cnt > 0) tie = true; } // (i): one of several equally far results was dropped; (b)
                         far_key = nf;
                     }
-                }
+                } else if (grp_cnt > 0 && dk == far_key) tie = true; // (b): turned away by equality
             }
         }
         PH(5);
     }
     PH_FLUSH();
+    if (grp_cnt > 0 && !tie && !unsafe && !hash_full) { // (c) at the end of the search
+        if (T.count_key(grp_key, top_n, lane) != grp_cnt) tie = true;
+        else if (window_out) *window_out = true;
+    }
     // ToArray() for the callers: with distinct distances any order-insensitive consumer (OrderBy,
     // Span.Sort) sees the same thing; ascending order is also what they would produce
     __syncthreads();
@@ -1282,7 +1406,7 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
             if (__builtin_amdgcn_readfirstlane(abort_v) & 1) { *aborted = true; return false; }
             abort_v = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        HEnt c = heap_pop<true>(cand, cand_n);          // :146
+        HEnt c = heap_pop_wave<true>(cand, cand_n, lane); // :146
         if (c.key > far_key && top_n >= k) break;       // :147-150
         RL.put(c.id, lane);
         int n, nb_a = 0, nb_b = 0; // this lane's neighbour ids (list positions lane and lane + 64)
@@ -1343,7 +1467,7 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
                     if (cand_n >= cand_limit) { overflow = true; break; }
                     heap_push<true>(cand, cand_n, sel);               // :168
                     heap_push<false>(top, top_n, sel);                // :171
-                    if (top_n > k) (void)heap_pop<false>(top, top_n); // :173-174
+                    if (top_n > k) (void)heap_pop_wave<false>(top, top_n, lane); // :173-174
                     far_key = top.get(0).key;                         // :176-177
                 }
             }
@@ -1859,7 +1983,8 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         if (jb.aux != -2 && !shadow) {
         bool tie = false;
         // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
-        const bool ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL);
+        bool window = false;
+        const bool ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL, nullptr, &window);
         if (!(ok1 && tie)) {
             if (!claim_answer()) return;
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
@@ -1871,7 +1996,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
             }
             if (lane == 0) {
                 out_cnt[job] = ok1 ? top_n : 0;
-                out_flag[job] = ok1 ? 0 : 1;
+                out_flag[job] = ok1 ? (window ? 4 : 0) : 1; // 4: informational (a group window of equal distances closed cleanly)
                 atomicAdd(eval_counter, evals);
             }
             return;

@@ -151,6 +151,25 @@ def test_draining_launch_with_ties_shadow_traversals(Index, monkeypatch, shadow)
         del ix
 
 
+def test_group_windows_of_equal_distances_close_without_a_rerun(Index):
+    # Coordinates on a 1/32 grid: squared distances are multiples of 1/1024, so two OPEN candidates of equal distance
+    # come up in most searches -- tie (ii).  The sorted traversal opens a group window and goes on (device_kernels.h);
+    # the answers, ids and distance bits, must be the oracle's two-heap answers whether the window closed cleanly
+    # (stats: tie_windows) or the search was handed to the exact traversal (search_repeats).
+    rng = np.random.default_rng(23)
+    for dim, n, M, efc, ef, k in ((24, 20000, 12, 80, 64, 10), (16, 8000, 8, 60, 100, 20), (48, 12000, 16, 100, 40, 5)):
+        x = (rng.integers(0, 32, (n, dim)) / np.float32(32)).astype(np.float32)
+        q = (rng.integers(0, 64, (6000, dim)) / np.float32(64)).astype(np.float32)
+        ref = oracle.OracleIndex(dim, max_edges=M, max_candidates=efc, min_nn=ef, collection_size=n)
+        ref.add_batched(x, 16384)
+        ix = _build(Index, x, M, efc, ef, 16384)
+        assert ix.graph_hash() == ref.graph_hash()
+        want, got = ref.knn_query(q, k), ix.knn_query(q, k)
+        assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes(), (dim, n)
+        st = ix.stats()
+        assert st["tie_windows"] > 200 and st["search_overflows"] == 0, st
+
+
 def test_many_jobs_per_resident_wave(Index):
     # persistent launches: far more traversals than resident waves, so every wave reuses its visited
     # bitset (cleared in the kernel) many times; also Add in one call with a batch cap above the slots
