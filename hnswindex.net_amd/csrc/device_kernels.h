@@ -1336,7 +1336,7 @@ template <int METRIC, bool HASHED>
 __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                          const GraphView &G, const SearchJob jb, int k, int cand_cap, ND *spill, int spill_cap,
                                          VisitedSet<HASHED> &V, const SearchLds &L, int lane, int &top_n_out, unsigned long long &evals,
-                                         ReadLog &RL, const int *abort_word = nullptr, bool *aborted = nullptr)
+                                         ReadLog &RL, const int *abort_word = nullptr, bool *aborted = nullptr, bool overlapped_form = false)
 {
     const LdsHeap top{L.top};
     const SpillHeap cand{L.cand, cand_cap, spill};
@@ -1424,6 +1424,52 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
         }
         int m = 0;
         __syncthreads();
+        bool have = false; // overlapped form: this lane holds an unvisited neighbour, its distance and id
+        float lane_d = 0.0f;
+        int lane_id = 0;
+        const bool overlapped = overlapped_form && n <= 64;
+        if (overlapped) {
+            // as in traverse_sorted: the rows of ALL listed neighbours requested together with the visited atomics -- one
+            // dependent round trip less per expansion.  This traversal runs where a launch is draining (a re-run, a
+            // shadow) or in launches that do not fill the chip; the rows of visited neighbours are bandwidth nobody misses.
+            const bool in = lane < n;
+            if (in) nbuf[lane] = nb_a;
+            __syncthreads();
+            unsigned old = 0u;
+            const unsigned bit = 1u << (nb_a & 31);
+            unsigned hpos = 0u;
+            if constexpr (HASHED) {
+                hpos = ((unsigned)nb_a * 2654435761u) & V.tab_mask;
+                if (in) old = (unsigned)atomicCAS(&V.tab[hpos], -1, nb_a);
+            } else if (in) old = atomicOr(&V.bits[nb_a >> 5], bit); // :181
+            pre_id = -1;
+            if (cand_n > 0) {
+                pre_id = cand.get(0).id;
+                const int *pl = G.list(pre_id, layer);
+                pre_a = lane < lstride ? pl[lane] : 0;
+                pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
+            }
+            if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
+            __syncthreads();
+            if constexpr (HASHED) {
+                have = in && (int)old == -1;
+                if (in && (int)old != -1 && (int)old != nb_a) { // slot taken by another id: probe on (VisitedSet::first_visit)
+                    for (unsigned probes = 0; probes <= V.tab_mask; ++probes) {
+                        hpos = (hpos + 1) & V.tab_mask;
+                        const int o2 = atomicCAS(&V.tab[hpos], -1, nb_a);
+                        if (o2 == -1) { have = true; break; }
+                        if (o2 == nb_a) break;
+                    }
+                }
+            } else have = in && (old & bit) == 0u;
+            m = (int)__popcll(__ballot(have));
+            V.seen += m;
+            if (V.crowded()) { hash_full = true; break; }
+            lane_d = in ? dbuf[lane] : 0.0f;
+            lane_id = nb_a;
+            if (m == 0) continue;
+            evals += (unsigned long long)m;
+        } else {
         for (int base = 0; base < n; base += 64) { // :158-161 keep only unvisited, in list order
             const int i = base + lane;
             bool fresh = false;
@@ -1448,16 +1494,19 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
         measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
         __syncthreads();
         evals += (unsigned long long)m;
+        }
         // Replay of the push loop (:165-178) in adjacency order.  farthest never grows once the
         // result heap is full, so a candidate that fails `d < farthest` now can never pass later:
         // only the lanes of the ballot are visited, and the exact test is repeated on each.
-        for (int base = 0; base < m && !overflow; base += 64) {
-            const int i = base + lane;
-            const float my_d = (i < m) ? dbuf[i] : 0.0f;
-            const int my_id = (i < m) ? nbuf[i] : 0;
+        const int rounds = overlapped ? 1 : (m + 63) / 64;
+        for (int r = 0; r < rounds && !overflow; ++r) {
+            const int i = r * 64 + lane;
+            const bool valid = overlapped ? have : i < m;
+            const float my_d = overlapped ? lane_d : (i < m ? dbuf[i] : 0.0f);
+            const int my_id = overlapped ? lane_id : (i < m ? nbuf[i] : 0);
             const unsigned my_key = f2key(my_d);
-            if (__ballot(i < m && key_unsafe(my_d))) { overflow = true; break; }
-            unsigned long long maybe = __ballot(i < m && (top_n < k || my_key < far_key));
+            if (__ballot(valid && key_unsafe(my_d))) { overflow = true; break; }
+            unsigned long long maybe = __ballot(valid && (top_n < k || my_key < far_key));
             while (maybe) {
                 const int src = __builtin_ctzll(maybe);
                 maybe &= maybe - 1;
@@ -2016,7 +2065,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
     }
     bool aborted = false;
     const bool ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL,
-                                             shadow ? job_word : nullptr, &aborted);
+                                             shadow ? job_word : nullptr, &aborted, (overlap & 1) != 0 || repeated);
     if (aborted || !claim_answer()) return;
     if (jb.aux == -2) { // SearchLayer's own return value: topCandidates.ToArray(), the heap's array (BinaryHeap.cs:41-44)
         __syncthreads();
@@ -2369,7 +2418,8 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                     RL.n = rl_n0; // the same lists are read again
                     V.clear(lane);
                 }
-                ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL);
+                ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL, nullptr, nullptr,
+                                              overlap != 0);
                 if (!ok) break;
             }
 #ifdef EXP_PHASE_CLOCKS
