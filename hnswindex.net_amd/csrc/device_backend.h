@@ -236,6 +236,10 @@ public:
     bool range_results(int *out_ids, float *out_d);
 
     void set_profiling(bool on) { profiling_ = on; }
+
+    // search launches of a call that shares the chip with another call (query lanes) keep no idle waves behind as shadows
+
+    void set_shadows_allowed(bool on) { shadows_allowed_ = on; }
     void get_stats(hnswdev_stats *out);
     void reset_stats();
 
@@ -362,6 +366,7 @@ private:
     void *stream_ = nullptr;
     bool profiling_ = false;
     hnswdev_stats stats_{};
+    bool shadows_allowed_ = true;
 };
 
 } // namespace hnsw

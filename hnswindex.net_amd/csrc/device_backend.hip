@@ -1599,7 +1599,7 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() ? 0x100 : 0), \
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
                        gate); \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \

@@ -1528,10 +1528,12 @@ int HnswIndex::knn_query_concurrent(const float *queries, int count, int dim, in
     // another call would gain little.  The lanes serve the smaller calls, which leave the chip part-idle.
     if (count >= kStreamMin) return 0;
     int lane = -1;
+    bool shares_chip = false;
     {
         std::unique_lock<std::mutex> lk(lane_mu_);
         lane_cv_.wait(lk, [&] { return !lane_busy_[0] || !lane_busy_[1]; });
         lane = lane_busy_[0] ? 1 : 0; // lane 0 is the primary context itself (a lone caller runs exactly where the exclusive path would)
+        shares_chip = lane_busy_[1 - lane];
         lane_busy_[lane] = true;
         if (lane > 0 && !lanes_[lane]) {
             lanes_[lane].reset(Device::create_view(dev_.get()));
@@ -1550,7 +1552,11 @@ int HnswIndex::knn_query_concurrent(const float *queries, int count, int dim, in
     const int ep = graph_.entry, top = graph_.top_layer();
     for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0, -1, 0};
     std::vector<int> flag((size_t)count);
+    // the waves a draining launch keeps behind as shadows (graph_search_kernel) are waves the other lane's launch is waiting
+    // for: a call that starts while the other lane is busy leaves none
+    d->set_shadows_allowed(!shares_chip);
     const bool ok = d->search_batch(jobs.data(), count, ef, k, out_ids, out_dists, flag.data());
+    d->set_shadows_allowed(true);
     if (!ok) { err = get_dev_error(); return 1; }
     for (int i = 0; i < count; ++i) if (flag[(size_t)i]) return 0; // something was handed back: the exclusive path answers the whole call
     rc = 0;
