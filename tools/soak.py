@@ -45,6 +45,7 @@ for seed, (M, efc, ef, k) in enumerate([(16, 200, 128, 10), (8, 100, 64, 5), (24
     same_q = bool((got[0] == want[0]).all()) and got[1].tobytes() == want[1].tobytes()
     print(f"M={M} efC={efc} ef={ef} k={k}: graph {'same' if same_graph else 'DIFFERENT'} (gpu {tb:.1f}s, oracle {tr:.1f}s, "
           f"build repeats {s0['search_repeats']}), queries {'same' if same_q else 'DIFFERENT'} "
-          f"(repeats {s1['search_repeats'] - s0['search_repeats']}, hand-backs {s1['search_overflows']})", flush=True)
+          f"(repeats {s1['search_repeats'] - s0['search_repeats']}, group windows closed {s1['tie_windows'] - s0['tie_windows']}, "
+          f"hand-backs {s1['search_overflows']})", flush=True)
     fails += (not same_graph) + (not same_q)
 sys.exit(1 if fails else 0)
