@@ -65,7 +65,7 @@ def parse():
     p.add_argument("--cpu-queries", type=int, default=4000, help="bounded cpu_baseline sample (all-cores leg)")
     p.add_argument("--seq-adds", type=int, default=2000, help="sample of sequential (B=1) inserts into the built index, GPU and CPU")
     p.add_argument("--window-adds", type=int, default=8000, help="sample inserted through the exact window (same graph as B=1), GPU; the CPU adds them one at a time")
-    p.add_argument("--window", type=int, default=64, help="items per speculative window of the exact-window Add")
+    p.add_argument("--window", type=int, default=256, help="cap of the speculative window of the exact-window Add (the live window is twice the recent prefix)")
     p.add_argument("--query-sets", type=int, default=4, help="distinct query sets the timed steps rotate through (fresh host buffers every step)")
     p.add_argument("--sharding", choices=["ranks", "native"], default="ranks",
                    help="N > 1: ranks = one process per GPU, torch.distributed over RCCL (what the driver launches); native = ONE process, "
