@@ -135,6 +135,9 @@ public:
     // results and the output is the result heap's ARRAY, the removal search's return value)
     bool search_batch(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag = false,
                       bool two_heap = false);
+    // search_batch for KnnQuery's own jobs -- resident query i from the entry point, i = 0 .. nq-1: the job array is written
+    // on this side and stays on the device while entry point and top layer do not change (a call then uploads no jobs)
+    bool search_queries(int nq, int entry, int entry_layer, int k, int k_out, int *out_ids, float *out_d, int *out_flag);
     // Remove, second half, for the `n` affected nodes of one (removed node, layer) step (graph_relink_kernel): per node
     // the new neighbour selection out_sel[i * sel_stride ..][0 .. out_cnt[i]); out_flag[i] = 1: this node's answer
     // depends on the heap-array order of the candidates (the caller repeats the step on the lock-step path).
@@ -342,7 +345,7 @@ private:
     HostGraphStage *hg_ = nullptr;
     void *h_stage_ = nullptr;
     size_t h_stage_cap_ = 0;
-    void *ev0_ = nullptr, *ev1_ = nullptr;
+    void *ev0_ = nullptr, *ev1_ = nullptr, *ev2_ = nullptr;
     struct LinkSet { // pinned staging of one in-flight link sub-batch
         int *h_in = nullptr, *h_out = nullptr;
         size_t in_cap = 0, out_cap = 0;
@@ -367,6 +370,9 @@ private:
     bool profiling_ = false;
     hnswdev_stats stats_{};
     bool shadows_allowed_ = true;
+    int uj_len_ = 0, uj_entry_ = -1, uj_layer_ = -1; // s_jobs_ holds search_queries' jobs 0 .. uj_len_-1 for that entry point
+    bool search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag,
+                           bool two_heap, int u_entry, int u_layer);
 };
 
 } // namespace hnsw

@@ -232,6 +232,7 @@ Device::~Device()
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
+    if (ev2_) (void)hipEventDestroy((hipEvent_t)ev2_);
     if (h_stage_) (void)hipHostFree(h_stage_);
     if (h_res_) (void)hipHostFree(h_res_);
     for (LinkSet &ls : lset_) {
@@ -982,6 +983,7 @@ bool Device::ensure_search_scratch(long long chunk, long long slots, int k, size
     }
     if ((size_t)chunk > s_jobs_cap_) {
         if (s_jobs_) HIP_OK(hipFree(s_jobs_));
+        uj_len_ = 0;
         if (s_cnt_) HIP_OK(hipFree(s_cnt_));
         if (s_flag_) HIP_OK(hipFree(s_flag_));
         s_jobs_cap_ = (size_t)chunk;
@@ -993,6 +995,7 @@ bool Device::ensure_search_scratch(long long chunk, long long slots, int k, size
     if (!grow_dev(&s_spill_, &s_spill_cap_, (size_t)slots * kSpillCap + 8)) return false; // +8: get2 may read one entry past a heap
     if (!s_evals_) HIP_OK(hipMalloc(&s_evals_, sizeof(unsigned long long)));
     if (!ev0_) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); ev0_ = a; ev1_ = b; }
+    if (!ev2_) { hipEvent_t c; HIP_OK(hipEventCreateWithFlags(&c, hipEventDisableTiming)); ev2_ = c; }
     return true;
 }
 
@@ -1083,6 +1086,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         const int nj = (int)std::min<long long>(chunk, njobs - off);
         memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
         HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
+        uj_len_ = 0; // search_queries' jobs are gone from s_jobs_
         // items that search several layers first (counting sort by first layer, descending; stable)
         const int *d_order = nullptr;
         {
@@ -1554,9 +1558,31 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
                           bool two_heap)
 {
     if (njobs <= 0) return true;
-    if (!jobs || !out_ids || !out_d || !out_flag || k < 1 || k_out < 1) { set_dev_error("search_batch: bad argument"); return false; }
+    if (!jobs) { set_dev_error("search_batch: bad argument"); return false; }
+    return search_batch_impl(jobs, njobs, k, k_out, out_ids, out_d, out_flag, keep_repeat_flag, two_heap, -1, -1);
+}
+
+bool Device::search_queries(int nq, int entry, int entry_layer, int k, int k_out, int *out_ids, float *out_d, int *out_flag)
+{
+    if (nq <= 0) return true;
+    if (nq > (1 << 20)) { // more than one launch: the plain path
+        std::vector<SearchJob> jobs((size_t)nq);
+        for (int i = 0; i < nq; ++i) jobs[(size_t)i] = SearchJob{i, entry, entry_layer, 0, -1, 0};
+        return search_batch(jobs.data(), nq, k, k_out, out_ids, out_d, out_flag);
+    }
+    return search_batch_impl(nullptr, nq, k, k_out, out_ids, out_d, out_flag, false, false, entry, entry_layer);
+}
+
+// jobs == nullptr: search_queries' jobs {i, u_entry, u_layer, 0, -1, 0}, i < njobs <= 2^20
+bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag,
+                               bool two_heap, int u_entry, int u_layer)
+{
+    if (!out_ids || !out_d || !out_flag || k < 1 || k_out < 1) { set_dev_error("search_batch: bad argument"); return false; }
     if (g_n_ <= 0) { set_dev_error("search_batch: no graph uploaded"); return false; }
-    if (!jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_)) { set_dev_error("search_batch: job outside the uploaded graph / rows / queries"); return false; }
+    if (jobs ? !jobs_valid(jobs, njobs, g_n_, n_queries_, n_rows_hw_) : !(u_entry >= 0 && u_entry < g_n_ && u_layer >= 0 && njobs <= n_queries_)) {
+        set_dev_error("search_batch: job outside the uploaded graph / rows / queries");
+        return false;
+    }
     const int cand_cap = cand_lds_cap(k, pitch_, false, nbcap());
     const size_t lds = search_lds_bytes(k, cand_cap, pitch_, false, nbcap());
     if (lds > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
@@ -1587,8 +1613,15 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
     struct TailGuard { Device *d; ~TailGuard() { d->tail_.n = 0; } } tail_guard{this}; // whatever happens below, nothing stays pending
     for (long long off = 0; off < njobs; off += chunk) {
         const int nj = (int)std::min<long long>(chunk, njobs - off);
-        memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
-        HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
+        if (jobs) {
+            memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
+            HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
+            uj_len_ = 0;
+        } else if (!(uj_len_ >= nj && uj_entry_ == u_entry && uj_layer_ == u_layer)) {
+            for (int i = 0; i < nj; ++i) h_jobs[i] = SearchJob{i, u_entry, u_layer, 0, -1, 0};
+            HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
+            uj_len_ = nj; uj_entry_ = u_entry; uj_layer_ = u_layer;
+        }
         HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int) * (4 + (size_t)nj), st));
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
@@ -1627,12 +1660,15 @@ bool Device::search_batch(const SearchJob *jobs, int njobs, int k, int k_out, in
 #undef LAUNCH2
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         if (tail_.n > 0 && !upload_tail()) return false; // the rest of the query set, while the launch above is running
+        // the ids are copied out to the caller's array while the distances are still crossing the link
         HIP_OK(hipMemcpyAsync(h_ids, d_ids, 4u * (size_t)nj * k_out, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipEventRecord((hipEvent_t)ev2_, st));
         HIP_OK(hipMemcpyAsync(h_d, d_d, 4u * (size_t)nj * k_out, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(h_flag, s_flag_, sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipEventSynchronize((hipEvent_t)ev2_));
         memcpy(out_ids + (size_t)off * k_out, h_ids, 4u * (size_t)nj * k_out);
+        HIP_OK(hipStreamSynchronize(st));
         memcpy(out_d + (size_t)off * k_out, h_d, 4u * (size_t)nj * k_out);
         for (int i = 0; i < nj; ++i) {
             if (h_flag[i] == 2) { stats_.search_repeats++; if (!keep_repeat_flag) h_flag[i] = 0; }
@@ -1803,6 +1839,7 @@ bool Device::range_batch(const SearchJob *jobs, int njobs, float range, RangeRes
         SearchJob *h_jobs = reinterpret_cast<SearchJob *>(hs + 16);
         for (int i = 0; i < nj; ++i) h_jobs[i] = jobs[todo[i]];
         HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, b_jobs, hipMemcpyHostToDevice, st));
+        uj_len_ = 0;
         HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int), st));
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         HIP_OK(hipMemsetAsync(s_arena_used_, 0, sizeof(unsigned long long), st));

@@ -1450,12 +1450,10 @@ int HnswIndex::knn_query_device(const float *, int count, int k, int *out_ids, f
 {
     if (!sync_graph(err)) return -1;
     const int ef = std::max(p_.min_nn, k);
-    std::vector<SearchJob> jobs((size_t)count);
     const int ep = graph_.entry, top = graph_.top_layer();
-    for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0, -1};
     std::vector<int> flag((size_t)count);
     { Tick t(g_pt.query_dev);
-    if (!dev_->search_batch(jobs.data(), count, ef, k, out_ids, out_dists, flag.data())) { err = get_dev_error(); return -1; } }
+    if (!dev_->search_queries(count, ep, top, ef, k, out_ids, out_dists, flag.data())) { err = get_dev_error(); return -1; } }
     Tick t_post(g_pt.post);
     std::vector<int> redo;
     for (int i = 0; i < count; ++i) if (flag[(size_t)i]) redo.push_back(i);
@@ -1552,14 +1550,12 @@ int HnswIndex::knn_query_concurrent(const float *queries, int count, int dim, in
     if (lane == 0) { resident_queries_ = 0; sharded_resident_ = false; } // hnsw_knn_query leaves its own queries resident on the primary
     if (!d->set_queries(queries, count)) { err = get_dev_error(); return 1; }
     if (lane == 0) resident_queries_ = count;
-    std::vector<SearchJob> jobs((size_t)count);
     const int ep = graph_.entry, top = graph_.top_layer();
-    for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0, -1, 0};
     std::vector<int> flag((size_t)count);
     // the waves a draining launch keeps behind as shadows (graph_search_kernel) are waves the other lane's launch is waiting
     // for: a call that starts while the other lane is busy leaves none
     d->set_shadows_allowed(!shares_chip);
-    const bool ok = d->search_batch(jobs.data(), count, ef, k, out_ids, out_dists, flag.data());
+    const bool ok = d->search_queries(count, ep, top, ef, k, out_ids, out_dists, flag.data());
     d->set_shadows_allowed(true);
     if (!ok) { err = get_dev_error(); return 1; }
     for (int i = 0; i < count; ++i) if (flag[(size_t)i]) return 0; // something was handed back: the exclusive path answers the whole call
@@ -1663,9 +1659,7 @@ int HnswIndex::knn_query_sharded(int k, int *out_ids, float *out_dists, std::str
         th.emplace_back([&, g] {
             const long long lo = shard_lo_[(size_t)g], hi = shard_lo_[(size_t)g + 1];
             const int cnt = (int)(hi - lo);
-            std::vector<SearchJob> jobs((size_t)cnt);
-            for (int i = 0; i < cnt; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0, -1, 0};
-            if (cnt > 0 && !context(g)->search_batch(jobs.data(), cnt, ef, k, out_ids + (size_t)lo * k, out_dists + (size_t)lo * k, flag.data() + lo))
+            if (cnt > 0 && !context(g)->search_queries(cnt, ep, top, ef, k, out_ids + (size_t)lo * k, out_dists + (size_t)lo * k, flag.data() + lo))
                 errs[(size_t)g] = get_dev_error().empty() ? "search_batch failed" : get_dev_error();
         });
     for (auto &t2 : th) t2.join(); }
