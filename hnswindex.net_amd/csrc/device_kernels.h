@@ -942,6 +942,15 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
 // or so unresolved cases of (i) that leaves 24 exact traversals per launch where there were 75 -- which matters because
 // an exact traversal takes three times as long as a sorted one and a launch ends with its last job (17-35 % of a
 // 12 500-query launch at 10M was the wait for such jobs, measured).
+// LDS ordering inside ONE wave (every traversal block is one wave): the wave's LDS instructions execute in order, so
+// all a write-then-read by other lanes needs is that the compiler keeps them in order -- not __syncthreads(), whose
+// s_waitcnt also drains the vector-memory counter and with it every load still in flight.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ int dpp_wave_shr1(int carry_in, int v)
 {
     return __builtin_amdgcn_update_dpp(carry_in, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); // lane 0 keeps carry_in
@@ -1055,7 +1064,7 @@ struct SortedTop {
             if (lane == src) rank_old = r;
             rank_new += (xk < my_key || (xk == my_key && src > lane)) ? 1 : 0;
         }
-        __syncthreads();
+        wave_lds_sync(); // (a list prefetched just before the merge stays in flight)
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int p = lane + 64 * t;
@@ -1065,7 +1074,7 @@ struct SortedTop {
             const int np = rank_old + rank_new;
             if (np <= k) lds[np] = make_uint2((unsigned)my_id, my_key);
         }
-        __syncthreads();
+        wave_lds_sync();
         const int total = count + (int)__popcll(pass);
         count = min(k, total);
 #pragma unroll
@@ -1075,7 +1084,7 @@ struct SortedTop {
         }
         last_key = lds[count - 1].y;
         boundary_tie = total > k && lds[k].y == last_key;
-        __syncthreads();
+        wave_lds_sync();
     }
     __device__ __forceinline__ int count_key(unsigned k0, int count, int lane) const // entries of that key (uniform result)
     {
@@ -1136,6 +1145,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     const int lstride = layer == 0 ? G.stride0 : G.strideU;
     PH(0);
     constexpr int kDoubt = 0x40000000, kIdMask = 0x3fffffff;
+    unsigned nxt_key = 0xffffffffu; // distance of the closest open entry once the current one is marked
     unsigned grp_key = 0u; // the group window of (ii): its distance and its members (0: no window open)
     int grp_cnt = 0;
     while (!unsafe && !tie) {
@@ -1194,8 +1204,10 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             pre_id = -1;
             {
                 const int nxt = T.first_open(top_n, lane);
+                nxt_key = 0xffffffffu;
                 if (nxt >= 0) {
                     const HEnt e = T.at(nxt);
+                    nxt_key = e.key;
                     if (e.key == c.key) { // (ii)
                         if (grp_cnt == 0) { grp_key = c.key; grp_cnt = T.count_key(c.key, top_n, lane); }
                         else if (c.key != grp_key) tie = true; // (d)
@@ -1243,8 +1255,10 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         pre_id = -1;
         {
             const int nxt = T.first_open(top_n, lane);
+            nxt_key = 0xffffffffu;
             if (nxt >= 0) {
                 const HEnt e = T.at(nxt);
+                nxt_key = e.key;
                 if (e.key == c.key) { // (ii): which of the two the reference pops first is a matter of heap layout
                     if (grp_cnt == 0) { grp_key = c.key; grp_cnt = T.count_key(c.key, top_n, lane); }
                     else if (c.key != grp_key) tie = true; // (d)
@@ -1276,6 +1290,24 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             if (__ballot(valid && key_unsafe(my_d))) { unsafe = true; break; }
             if (grp_cnt > 0 && __ballot(valid && (my_key == grp_key || (top_n >= k && my_key == far_key)))) { tie = true; break; } // (a), (b)
             unsigned long long maybe = __ballot(valid && (top_n < k || my_key < far_key));
+            if (rounds == 1 && maybe) {
+                // What the next pop returns is known before the insertions: the closest open entry, or a neighbour of this
+                // expansion that is closer.  In the second case the list prefetched above is the wrong one: request the
+                // right one now, and the insertions run under its round trip.  (A guess, like every prefetch: the pop decides.)
+                unsigned bk = 0xffffffffu;
+                int bl = 0;
+                for (unsigned long long mm = maybe; mm; mm &= mm - 1) {
+                    const int sl = __builtin_ctzll(mm);
+                    const unsigned kk = (unsigned)__builtin_amdgcn_readlane((int)my_key, sl);
+                    if (kk < bk) { bk = kk; bl = sl; }
+                }
+                if (bk < nxt_key) {
+                    pre_id = __builtin_amdgcn_readlane(my_id, bl);
+                    const int *pl = G.list(pre_id, layer);
+                    pre_a = lane < lstride ? pl[lane] : 0;
+                    pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
+                }
+            }
 #ifndef HNSW_NO_BATCH_MERGE
             if (maybe & (maybe - 1)) { // two or more: one counting merge instead of as many list shifts
                 unsigned last = 0u;
