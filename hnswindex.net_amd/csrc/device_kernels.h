@@ -920,6 +920,12 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
 // may hold its twin instead -- same distance, other id, possibly still a candidate there) is only
 // marked DOUBTFUL: the search goes on, and `tie` is raised if a doubtful entry is popped or is still
 // in the list at the end; usually the next few insertions push it out and nothing depended on it.
+// A search (OrderBy + Take(k_out) with k_out far below k) goes one step further with (i): when the entry that left AND
+// every survivor of its distance had already been expanded, the two lists differ in ONE id of equal distance at the far
+// end and in nothing that can still happen -- neither twin is a candidate any more, the farthest distance is the same --
+// so such an event is only remembered as an identity doubt, which asks for the exact traversal only if a doubtful entry
+// ends inside the ordered prefix the caller reads (never, with k = 128 and k_out = 10) and does not fail a group window.
+// An insert reads all k entries (the heuristic's candidates): every doubt stays a doubt there.
 // Equal distances elsewhere in the list are harmless.  Position p lives in lane p & 63 of register
 // set p >> 6; id bit 31 = expanded, bit 30 = doubtful (node ids stay below 2^30).
 //
@@ -1043,7 +1049,7 @@ struct SortedTop {
     // boundary_tie: entries were dropped and the first one dropped has the key of the last one kept (the
     // reference's list may hold that twin instead: the caller marks the survivors DOUBTFUL, rule (i)).
     __device__ __forceinline__ void merge(unsigned long long pass, unsigned my_key, int my_id, int &count, int k, int lane,
-                                          uint2 *lds, unsigned &last_key, bool &boundary_tie)
+                                          uint2 *lds, unsigned &last_key, bool &boundary_tie, bool &dropped_expanded)
     {
         int shift[NS];
 #pragma unroll
@@ -1084,7 +1090,25 @@ struct SortedTop {
         }
         last_key = lds[count - 1].y;
         boundary_tie = total > k && lds[k].y == last_key;
+        dropped_expanded = boundary_tie && (int)lds[k].x < 0; // the twin that left had been expanded (bit 31 of its id word)
         wave_lds_sync();
+    }
+    __device__ __forceinline__ bool any_open_key(unsigned k0, int count, int lane) const // an entry of that key not yet expanded? (uniform)
+    {
+        bool o = false;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) o |= lane + 64 * t < count && key[t] == k0 && id[t] >= 0;
+        return __ballot(o) != 0ull;
+    }
+    __device__ __forceinline__ int first_flagged(int count, int lane, int bit) const // position of the first entry with that bit, or count
+    {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (64 * t >= count) break;
+            const unsigned long long m = __ballot(lane + 64 * t < count && (id[t] & bit) != 0);
+            if (m) return 64 * t + (int)__builtin_ctzll(m);
+        }
+        return count;
     }
     __device__ __forceinline__ int count_key(unsigned k0, int count, int lane) const // entries of that key (uniform result)
     {
@@ -1145,6 +1169,8 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     const int lstride = layer == 0 ? G.stride0 : G.strideU;
     PH(0);
     constexpr int kDoubt = 0x40000000, kIdMask = 0x3fffffff;
+    const bool ids_matter_everywhere = order_tie_out != nullptr; // an insert's heuristic reads the whole list; a search its first entries
+    bool doubt_hard = false; // some doubt of (i) was more than one id of equal distance among expanded entries
     unsigned nxt_key = 0xffffffffu; // distance of the closest open entry once the current one is marked
     unsigned grp_key = 0u; // the group window of (ii): its distance and its members (0: no window open)
     int grp_cnt = 0;
@@ -1311,10 +1337,15 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
 #ifndef HNSW_NO_BATCH_MERGE
             if (maybe & (maybe - 1)) { // two or more: one counting merge instead of as many list shifts
                 unsigned last = 0u;
-                bool boundary_tie = false;
-                T.merge(maybe, my_key, my_id, top_n, k, lane, reinterpret_cast<uint2 *>(L.top), last, boundary_tie);
+                bool boundary_tie = false, dropped_expanded = false;
+                T.merge(maybe, my_key, my_id, top_n, k, lane, reinterpret_cast<uint2 *>(L.top), last, boundary_tie, dropped_expanded);
                 if (top_n == k) {
-                    if (boundary_tie) { T.mark_key(last, top_n, lane, kDoubt); if (grp_cnt > 0) tie = true; } // (i); (b)
+                    if (boundary_tie) { // (i); (b)
+                        const bool hard = ids_matter_everywhere || !dropped_expanded || T.any_open_key(last, top_n, lane);
+                        doubt_hard |= hard;
+                        T.mark_key(last, top_n, lane, kDoubt);
+                        if (grp_cnt > 0 && hard) tie = true;
+                    }
                     far_key = last;                                          // :176-177
                 }
                 maybe = 0ull;
@@ -1326,10 +1357,16 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 const unsigned dk = (unsigned)__builtin_amdgcn_readlane((int)my_key, src);
                 if (top_n < k || dk < far_key) { // :165
                     const bool evicts = top_n == k;
+                    const bool last_expanded = evicts && T.at(k - 1).id < 0; // the entry this insertion pushes out
                     T.insert(dk, __builtin_amdgcn_readlane(my_id, src), top_n, k, lane); // :168-174
                     if (top_n == k) {
                         const unsigned nf = T.key_at(k - 1);                             // :176-177
-                        if (evicts && nf == far_key) { T.mark_key(nf, top_n, lane, kDoubt); if (grp_cnt > 0) tie = true; } // (i): one of several equally far results was dropped; (b)
+                        if (evicts && nf == far_key) { // (i): one of several equally far results was dropped; (b)
+                            const bool hard = ids_matter_everywhere || !last_expanded || T.any_open_key(nf, top_n, lane);
+                            doubt_hard |= hard;
+                            T.mark_key(nf, top_n, lane, kDoubt);
+                            if (grp_cnt > 0 && hard) tie = true;
+                        }
                         far_key = nf;
                     }
                 } else if (grp_cnt > 0 && dk == far_key) tie = true; // (b): turned away by equality
@@ -1352,7 +1389,8 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     }
     __syncthreads();
     top_n_out = top_n;
-    if (T.any_flagged(top_n, lane, kDoubt)) tie = true;                  // (i) left unresolved
+    if (T.any_flagged(top_n, lane, kDoubt) && (doubt_hard || T.first_flagged(top_n, lane, kDoubt) < min(top_n, ordered_prefix)))
+        tie = true;                                                      // (i) left unresolved
     // (iii): the SET is the reference's, only its order among equal distances is open.  A caller that can tell
     // whether that order shows in what it makes of the list asks for this case separately (insert_job).
     const bool order_tie = T.adjacent_equal(min(top_n, ordered_prefix), lane);
