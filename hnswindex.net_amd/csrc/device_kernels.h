@@ -945,7 +945,8 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
 // entry turned away or evicted by equality: which twin stays depends on the order of arrival), (c) a member is missing
 // when it closes, or (d) a second group opens inside it.  Of the 100 windows a 65 536-query launch at C2 opens, 86
 // close cleanly (the others sit at the far end of the list, where the members themselves are evicted); with the ten
-// or so unresolved cases of (i) that leaves 24 exact traversals per launch where there were 75 -- which matters because
+// or so unresolved cases of (i) that leaves 24 exact traversals per launch where there were 75 (15-20 with the identity
+// doubts above) -- which matters because
 // an exact traversal takes three times as long as a sorted one and a launch ends with its last job (17-35 % of a
 // 12 500-query launch at 10M was the wait for such jobs, measured).
 // LDS ordering inside ONE wave (every traversal block is one wave): the wave's LDS instructions execute in order, so
