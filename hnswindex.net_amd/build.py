@@ -12,7 +12,7 @@ LIB = PKG / "artifacts" / "native" / "linux-x64" / "HNSWIndex.Native.so"
 # device_backend.hip: host side + the small kernels; traverse_<metric>_<kernel>.hip: the instantiations of the two
 # big traversal kernel templates (device code in device_kernels.h) -- separate units so that they
 # compile in parallel (one unit took two minutes).
-SOURCES = ["device_backend.hip", *[f"traverse_{m}_{k}.hip" for m in ("sq", "cos", "ucos", "i8") for k in ("insert", "search")],
+SOURCES = ["device_backend.hip", *[f"traverse_{m}_{k}{v}.hip" for m in ("sq", "cos", "ucos", "i8") for k in ("insert", "search") for v in ("", "_lat")],
            "search_engine.cpp", "hnsw_index.cpp", "exports.cpp"]
 # -ffp-contract=off: the kernels fuse a*b+c only where __builtin_fmaf is written -- the
 # reference's AVX path fuses in sq_euclid (Fma.MultiplyAdd) and nowhere else.
@@ -35,15 +35,20 @@ def needs_build() -> bool:
     return any(p.stat().st_mtime > t for p in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, out: Path = None) -> Path:
+    """out: build a diagnostic variant (HNSW_MI355X_EXTRA_FLAGS) beside the product library instead of replacing it;
+    load it with HNSW_MI355X_LIB=<out>."""
+    global LIB, OBJ
+    if out is not None:
+        LIB, OBJ = Path(out).resolve(), PKG / "artifacts" / ("obj_" + Path(out).stem)
+    elif not force and not needs_build():
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     LIB.parent.mkdir(parents=True, exist_ok=True)
     OBJ.mkdir(parents=True, exist_ok=True)
     extra = os.environ.get("HNSW_MI355X_EXTRA_FLAGS", "").split()  # kernel experiments (-D...)
     sources = list(SOURCES)
-    if "-DHNSW_SINGLE_TU" in extra or "-DEXP_PHASE_CLOCKS" in extra:  # diagnostic builds: every kernel in one unit
+    if "-DHNSW_SINGLE_TU" in extra:  # diagnostic builds: every kernel in one unit
         extra = sorted(set(extra) | {"-DHNSW_SINGLE_TU"})
         sources = [s for s in sources if not s.startswith("traverse_")]
 
@@ -70,4 +75,5 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, out=Path(sys.argv[1]) if len(sys.argv) > 1 else None))

@@ -89,17 +89,79 @@ static bool grow_dev(T **p, size_t *cap, size_t need)
     return true;
 }
 
+#ifdef EXP_PHASE_CLOCKS
+HNSW_PHASE_BIND(backend)
+extern "C" {
+hipError_t hnsw_phase_bind_sq_insert(unsigned long long *); hipError_t hnsw_phase_bind_sq_search(unsigned long long *);
+hipError_t hnsw_phase_bind_cos_insert(unsigned long long *); hipError_t hnsw_phase_bind_cos_search(unsigned long long *);
+hipError_t hnsw_phase_bind_ucos_insert(unsigned long long *); hipError_t hnsw_phase_bind_ucos_search(unsigned long long *);
+hipError_t hnsw_phase_bind_i8_insert(unsigned long long *); hipError_t hnsw_phase_bind_i8_search(unsigned long long *);
+hipError_t hnsw_phase_bind_sq_insert_lat(unsigned long long *); hipError_t hnsw_phase_bind_sq_search_lat(unsigned long long *);
+hipError_t hnsw_phase_bind_cos_insert_lat(unsigned long long *); hipError_t hnsw_phase_bind_cos_search_lat(unsigned long long *);
+hipError_t hnsw_phase_bind_ucos_insert_lat(unsigned long long *); hipError_t hnsw_phase_bind_ucos_search_lat(unsigned long long *);
+hipError_t hnsw_phase_bind_i8_insert_lat(unsigned long long *); hipError_t hnsw_phase_bind_i8_search_lat(unsigned long long *);
+}
+static unsigned long long *g_phase_buf = nullptr; // one buffer per process (diagnostic builds run one index at a time)
+static bool phase_bind_all()
+{
+    if (g_phase_buf) return true;
+    if (hipMalloc(&g_phase_buf, sizeof(unsigned long long) * hnsw::kPhaseWords) != hipSuccess) return false;
+    (void)hipMemset(g_phase_buf, 0, sizeof(unsigned long long) * hnsw::kPhaseWords);
+    bool ok = hnsw_phase_bind_backend(g_phase_buf) == hipSuccess;
+#ifndef HNSW_SINGLE_TU
+    ok = ok && hnsw_phase_bind_sq_insert(g_phase_buf) == hipSuccess && hnsw_phase_bind_sq_search(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_cos_insert(g_phase_buf) == hipSuccess && hnsw_phase_bind_cos_search(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_ucos_insert(g_phase_buf) == hipSuccess && hnsw_phase_bind_ucos_search(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_i8_insert(g_phase_buf) == hipSuccess && hnsw_phase_bind_i8_search(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_sq_insert_lat(g_phase_buf) == hipSuccess && hnsw_phase_bind_sq_search_lat(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_cos_insert_lat(g_phase_buf) == hipSuccess && hnsw_phase_bind_cos_search_lat(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_ucos_insert_lat(g_phase_buf) == hipSuccess && hnsw_phase_bind_ucos_search_lat(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_i8_insert_lat(g_phase_buf) == hipSuccess && hnsw_phase_bind_i8_search_lat(g_phase_buf) == hipSuccess;
+#endif
+    return ok;
+}
+static bool phase_read(unsigned long long *h) { return g_phase_buf && hipMemcpy(h, g_phase_buf, sizeof(unsigned long long) * hnsw::kPhaseWords, hipMemcpyDeviceToHost) == hipSuccess; }
+static void phase_zero() { if (g_phase_buf) (void)hipMemset(g_phase_buf, 0, sizeof(unsigned long long) * hnsw::kPhaseWords); }
+static void phase_report(const char *when)
+{
+    unsigned long long w[hnsw::kPhaseWords] = {0};
+    if (!phase_read(w)) return;
+    const unsigned long long *h = w, *hl = w + 12, *hx = w + 24;
+    double tot = 0, tl = 0;
+    for (int i = 0; i < 6; ++i) tot += (double)h[i];
+    for (int i = 0; i < 5; ++i) tl += (double)hl[i];
+    if (hl[7])
+        fprintf(stderr, "[phase clocks, link] stage %.1f%% measure %.1f%% sort %.1f%% heuristic %.1f%% rest %.1f%% | appends %llu, prunes %llu, cycles/prune %.0f\n",
+                100 * hl[0] / tl, 100 * hl[1] / tl, 100 * hl[2] / tl, 100 * hl[3] / tl, 100 * hl[4] / tl, hl[6], hl[7], tl / (double)std::max(1ull, hl[7]));
+    if (h[9]) fprintf(stderr, "[phase clocks, insert] RelativeNeighborPruning %.1f%% of the insert jobs' cycles; heuristic cycles %.0f, job cycles %.0f\n", 100.0 * (double)h[8] / (double)h[9], (double)h[8], (double)h[9]);
+    if (!h[7]) return;
+    const double e = (double)h[7];
+    fprintf(stderr, "[phase clocks, %s] descent %.1f%% pop %.1f%% list %.1f%% visited %.1f%% rows %.1f%% push %.1f%% | expansions %llu, prefetch hits %.1f%%, cycles/expansion %.0f\n", when,
+            100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, h[7], 100.0 * h[6] / e, tot / e);
+    fprintf(stderr, "[phase clocks, per expansion] descent %.0f pop %.0f list %.0f visited %.0f rows %.0f (before %.0f, measure %.0f, after %.0f) push %.0f (checks %.0f, next-pop guess %.0f, merge %.0f, single inserts %.0f) | merges %.2f, single inserts %.2f, candidates passing %.2f\n",
+            h[0] / e, h[1] / e, h[2] / e, h[3] / e, h[4] / e, hx[0] / e, hx[1] / e, hx[2] / e, h[5] / e, hx[8] / e, hx[9] / e, hx[10] / e, hx[11] / e, hx[3] / e, hx[4] / e, hx[5] / e);
+}
+#endif
+
 #ifdef HNSW_SINGLE_TU
-// one translation unit (diagnostic builds: the phase-clock counters are per-unit device globals)
+// one translation unit (diagnostic builds)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_TRAVERSAL, M_SQ)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_TRAVERSAL, M_COS)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_TRAVERSAL, M_UCOS)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_TRAVERSAL, M_I8)
+HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DEFINE_TRAVERSAL, M_SQ)
+HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DEFINE_TRAVERSAL, M_COS)
+HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DEFINE_TRAVERSAL, M_UCOS)
+HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DEFINE_TRAVERSAL, M_I8)
 #else
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DECLARE_TRAVERSAL, M_SQ)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DECLARE_TRAVERSAL, M_COS)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DECLARE_TRAVERSAL, M_UCOS)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DECLARE_TRAVERSAL, M_I8)
+HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DECLARE_TRAVERSAL, M_SQ)
+HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DECLARE_TRAVERSAL, M_COS)
+HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DECLARE_TRAVERSAL, M_UCOS)
+HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DECLARE_TRAVERSAL, M_I8)
 #endif
 
 // ------------------------------------------------------------------------------------
@@ -156,6 +218,9 @@ Device *Device::create(int device, int dim, int metric, long long capacity)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) d->num_cu_ = cus;
     }
     if (!d->reserve(capacity > 0 ? capacity : 1)) return fail();
+#ifdef EXP_PHASE_CLOCKS
+    if (!phase_bind_all()) { set_dev_error("phase-clock buffer: bind failed"); return fail(); }
+#endif
     return d;
 }
 
@@ -209,23 +274,7 @@ Device::~Device()
     if (d_queries_) (void)hipFree(d_queries_);
     if (d_q_sn_) (void)hipFree(d_q_sn_);
 #ifdef EXP_PHASE_CLOCKS
-    {
-        unsigned long long h[12] = {0};
-        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) == hipSuccess) {
-            double tot = 0;
-            for (int i = 0; i < 6; ++i) tot += (double)h[i];
-            unsigned long long hl[12] = {0};
-            (void)hipMemcpyFromSymbol(hl, HIP_SYMBOL(g_phase_link), sizeof hl);
-            double tl = 0;
-            for (int i = 0; i < 5; ++i) tl += (double)hl[i];
-            fprintf(stderr, "[phase clocks, link] stage %.1f%% measure %.1f%% sort %.1f%% heuristic %.1f%% rest %.1f%% | appends %llu, prunes %llu, cycles/prune %.0f\n",
-                    100 * hl[0] / tl, 100 * hl[1] / tl, 100 * hl[2] / tl, 100 * hl[3] / tl, 100 * hl[4] / tl, hl[6], hl[7], tl / (double)std::max(1ull, hl[7]));
-            if (h[9]) fprintf(stderr, "[phase clocks, insert] RelativeNeighborPruning %.1f%% of the insert jobs' cycles\n", 100.0 * (double)h[8] / (double)h[9]);
-            fprintf(stderr, "[phase clocks] descent %.1f%% pop %.1f%% list %.1f%% visited %.1f%% rows %.1f%% push %.1f%% | expansions %llu, prefetch hits %llu (%.1f%%), cycles/expansion %.0f\n",
-                    100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, h[7], h[6],
-                    100.0 * h[6] / (double)std::max(1ull, h[7]), tot / (double)std::max(1ull, h[7]));
-        }
-    }
+    phase_report("teardown");
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
                     (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_rlog_, (void *)s_dry_, (void *)s_wdry_, (void *)s_win_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
@@ -800,18 +849,9 @@ void Device::reset_stats()
     stats_ = hnswdev_stats{};
     stats_.row_bytes = rb;
 #ifdef EXP_PHASE_CLOCKS
-    unsigned long long z[12] = {0}, h[12] = {0};
     (void)hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) == hipSuccess && h[9]) {
-        double tot = 0;
-        for (int i = 0; i < 6; ++i) tot += (double)h[i];
-        fprintf(stderr, "[phase clocks, insert] RelativeNeighborPruning %.1f%% of the insert jobs' cycles; descent %.1f%% of their traversal cycles\n",
-                100.0 * (double)h[8] / (double)h[9], 100.0 * (double)h[0] / tot);
-        fprintf(stderr, "[phase clocks] descent %.1f%% pop %.1f%% list %.1f%% visited %.1f%% rows %.1f%% push %.1f%% | expansions %llu, prefetch hits %llu, cycles/expansion %.0f, heuristic cycles/job %.0f, job cycles %.0f\n",
-                100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, h[7], h[6],
-                tot / (double)std::max(1ull, h[7]), (double)h[8], (double)h[9]);
-    }
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z);
+    phase_report("reset_stats");
+    phase_zero();
 #endif
 }
 
@@ -921,6 +961,14 @@ static bool shadow_mode()
 static int overlap_mode()
 {
     const char *e = std::getenv("HNSW_MI355X_OVERLAP");
+    return e ? std::atoi(e) : 1;
+}
+// The latency variants of the traversal kernels (device_kernels.h, LAT) for launches that do not fill the chip -- B = 1
+// Add, the exact window's rounds, small query calls: 0 never, 1 (default) when the jobs fit the variant's resident waves,
+// 2 whenever the graph allows it (adjacency lists of at most 64 entries; tests).
+static int lat_mode()
+{
+    const char *e = std::getenv("HNSW_MI355X_LAT");
     return e ? std::atoi(e) : 1;
 }
 
@@ -1104,15 +1152,21 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         HIP_OK(hipMemsetAsync(p_evals, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-#define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
-    do { \
-        const int slots_ = std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_>, LDS, num_cu_)); \
-        hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
+#define LAUNCH2L(M, NS_, H_, LAT_, SLOTS, GRID, LDS, CAP) \
+        hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_, H_, LAT_>), dim3(std::min<int>(GRID, SLOTS)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, p_sel0 + (size_t)off * sel_stride, p_cnt0 + off, p_selU, p_cntU,        \
-                       sel_stride, p_flag + off, p_evals, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
-                       windowed ? p_log : (int *)nullptr, read_log_cap); \
+                       sel_stride, p_flag + off, p_evals, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
+                       windowed ? p_log : (int *)nullptr, read_log_cap)
+#define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
+    do { \
+        const int lslots_ = NS_ > 0 && lat_mode() != 0 && g_stride0_ - 2 <= 64 ? std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, (NS_ > 0 ? NS_ : 1), H_, true>, LDS, num_cu_)) : 0; \
+        if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, (NS_ > 0 ? NS_ : 1), H_, true, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
+        else { \
+            const int slots_ = std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_, false>, LDS, num_cu_)); \
+            LAUNCH2L(M, NS_, H_, false, slots_, GRID, LDS, CAP); \
+        } \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
     do {                                                                                                                   \
@@ -1137,6 +1191,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
 #undef LAUNCH
 #undef LAUNCH3
 #undef LAUNCH2
+#undef LAUNCH2L
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         if (!windowed) HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         if (windowed) { // one launch (njobs <= chunk): everything the host validates with rides on the same wait
@@ -1610,7 +1665,10 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
     float *d_d = reinterpret_cast<float *>(s_hits_) + (size_t)chunk * k_out;
     // a query set whose tail is still on the host (set_queries_streamed): the launch is gated on the rows' arrival
     const int *gate = tail_.n > 0 ? d_ready_ : nullptr;
-    struct TailGuard { Device *d; ~TailGuard() { d->tail_.n = 0; } } tail_guard{this}; // whatever happens below, nothing stays pending
+    // whatever happens below, nothing stays pending -- and a tail that never went up (an error between the launch and
+    // upload_tail) leaves no resident query set behind: hnsw_mi355x_knn_query_resident must not answer from rows that
+    // were never uploaded
+    struct TailGuard { Device *d; ~TailGuard() { if (d->tail_.n > 0) d->n_queries_ = 0; d->tail_.n = 0; } } tail_guard{this};
     for (long long off = 0; off < njobs; off += chunk) {
         const int nj = (int)std::min<long long>(chunk, njobs - off);
         if (jobs) {
@@ -1626,14 +1684,20 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
-#define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
-    do { \
-        const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_>, LDS, num_cu_)); \
-        hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_>), dim3(std::min<int>(GRID, slots_)), \
+#define LAUNCH2L(M, NS_, H_, LAT_, SLOTS, GRID, LDS, CAP) \
+        hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_, LAT_>), dim3(std::min<int>(GRID, SLOTS)), \
                        dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= slots_ || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
-                       gate); \
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
+                       gate)
+#define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
+    do { \
+        const int lslots_ = NS_ > 0 && lat_mode() != 0 && g_stride0_ - 2 <= 64 ? std::min(max_slots(), resident_blocks(graph_search_kernel<M, (NS_ > 0 ? NS_ : 1), H_, true>, LDS, num_cu_)) : 0; \
+        if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, (NS_ > 0 ? NS_ : 1), H_, true, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
+        else { \
+            const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_, false>, LDS, num_cu_)); \
+            LAUNCH2L(M, NS_, H_, false, slots_, GRID, LDS, CAP); \
+        } \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
     do {                                                                                                                   \
@@ -1658,6 +1722,7 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
 #undef LAUNCH
 #undef LAUNCH3
 #undef LAUNCH2
+#undef LAUNCH2L
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         if (tail_.n > 0 && !upload_tail()) return false; // the rest of the query set, while the launch above is running
         // the ids are copied out to the caller's array while the distances are still crossing the link

@@ -9,6 +9,12 @@
 
 #include "device_backend.h"
 
+#ifdef EXP_LAT_REGS // experiment: no occupancy target for the traversal kernels (every register the wave can have: no spills)
+#define HNSW_WAVES(x) 1
+#else
+#define HNSW_WAVES(x) (x)
+#endif
+
 namespace hnsw {
 
 // ------------------------------------------------------------------------------------
@@ -587,10 +593,92 @@ __device__ __forceinline__ void measure_pass_i8_any(const float *rows, int pitch
     else measure_pass_i8<NP, 0>(rows, pitch, qs, nbuf, dbuf, p0, m, lane);
 }
 
+// ---- the same distances with TWO lanes per row and 16-byte loads (latency form) -------------------------
+// A launch that does not fill the chip is bound by how long ONE wave takes over an expansion, and measure_pass
+// above issues 64 dword loads per lane for 32 rows of 128 floats: the wave's memory instructions alone (16+ cycles
+// of address processing each, eight 32-byte pieces per instruction) outlast the HBM round trip several times over.
+// Here lane 2r holds the AVX lanes 0-3 of row r and lane 2r + 1 the lanes 4-7: one dwordx4 load per eight elements
+// and lane, 16 loads for a 128-float row, all 32 rows of an expansion in one pass; lane partial j still walks
+// elements j, j + 8, ... in order with the same operations (two-wide packed where the ISA has them: v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32 round each half like the scalar instruction), p_j + p_{j+4} is one exchange inside
+// the lane pair (DPP quad_perm, no LDS), and the rest of the collapse tree is in-lane: EuclideanMetric.cs:45-50
+// (t0 + t1) + (t2 + t3), CosineMetric.cs:145-171 (u0 + u2) + (u1 + u3).  Bit for bit the value of measure_pass.
+// Rows of a multiple of 8 floats (16-byte aligned pieces); float metrics.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float dpp_pair_swap(float v) // the other lane of the pair (lane ^ 1)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true));
+}
 template <int METRIC>
+__device__ __forceinline__ void measure_pass2(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
+                                              const float *qs, double sb, const int *nbuf, float *dbuf, int p0, int m, int lane)
+{
+    const int r = lane >> 1, h = lane & 1;
+    const int c = p0 + r;
+    const int id = nbuf[c < m ? c : p0]; // idle pairs shadow a valid row
+    const float *a = rows + (size_t)id * dim + 4 * h;
+    const float *q = qs + 4 * h;
+    f32x2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f}; // lane partials 4h + 0, 1 and 4h + 2, 3
+    const int nblk = dim >> 3;
+    int k = 0;
+    auto step = [&](const f32x4 x, const f32x4 y) {
+        const f32x2 x01 = {x.x, x.y}, x23 = {x.z, x.w}, y01 = {y.x, y.y}, y23 = {y.z, y.w};
+        if (METRIC == M_SQ) {
+            const f32x2 d01 = x01 - y01, d23 = x23 - y23;
+            acc01 = __builtin_elementwise_fma(d01, d01, acc01);
+            acc23 = __builtin_elementwise_fma(d23, d23, acc23);
+        } else {
+            const f32x2 p01 = x01 * y01, p23 = x23 * y23;
+            acc01 = acc01 + p01;
+            acc23 = acc23 + p23;
+        }
+    };
+    for (; k + 16 <= nblk; k += 16) { // one memory round trip per 128-float chunk (see measure_pass)
+        f32x4 x[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) x[kk] = *reinterpret_cast<const f32x4 *>(a + 8 * (k + kk));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) step(x[kk], *reinterpret_cast<const f32x4 *>(q + 8 * (k + kk)));
+    }
+    if (k + 8 <= nblk) {
+        f32x4 x[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) x[kk] = *reinterpret_cast<const f32x4 *>(a + 8 * (k + kk));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) step(x[kk], *reinterpret_cast<const f32x4 *>(q + 8 * (k + kk)));
+        k += 8;
+    }
+#pragma unroll 4
+    for (; k < nblk; ++k) step(*reinterpret_cast<const f32x4 *>(a + 8 * k), *reinterpret_cast<const f32x4 *>(q + 8 * k));
+    // p_j + p_{j+4}: the two lanes of the pair exchange their partials (the sum is commutative: both get t_j)
+    const float t0 = acc01.x + dpp_pair_swap(acc01.x), t1 = acc01.y + dpp_pair_swap(acc01.y);
+    const float t2 = acc23.x + dpp_pair_swap(acc23.x), t3 = acc23.y + dpp_pair_swap(acc23.y);
+    float s;
+    if (METRIC == M_SQ) { const float u = t0 + t1, v = t2 + t3; s = u + v; }
+    else { const float u = t0 + t2, v = t1 + t3; s = u + v; }
+    float res;
+    if (METRIC == M_SQ) res = s;
+    else if (METRIC == M_UCOS) res = 1.0f - s;
+    else {
+        const float denom = (float)(row_sn[id] * sb);
+        res = (denom < 1e-30f) ? 1.0f : 1.0f - s / denom;
+    }
+    if (h == 0 && c < m) dbuf[c] = res;
+}
+
+template <int METRIC, bool TWO = false>
 __device__ __forceinline__ void measure_all(const float *rows, const double *row_sn, int dim, const float *qs, double sb,
                                             const int *nbuf, float *dbuf, int m, int lane)
 {
+    if constexpr (METRIC != M_I8 && TWO) {
+        if (m > 8 && (dim & 7) == 0) { // latency form: two lanes per row (up to 8 rows the eight-lane pass issues as few loads)
+            for (int p0 = 0; p0 < m; p0 += 32) measure_pass2<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, p0, m, lane);
+            return;
+        }
+    }
     if constexpr (METRIC == M_I8) {
         for (int p0 = 0; p0 < m; p0 += 32) {
             const int left = m - p0;
@@ -730,7 +818,7 @@ struct SearchLds {
 // nbcap: capacity of the id / distance scratch = longest adjacency list, rounded up to 8
 __host__ __device__ inline size_t search_lds_bytes(int k, int cand_cap, int dim, bool heur, int nbcap)
 {
-    size_t b = sizeof(ND) * (size_t)(k + 1 + cand_cap) + sizeof(float) * (size_t)((dim + 3) & ~3) + 2u * 4u * (size_t)nbcap;
+    size_t b = ((sizeof(ND) * (size_t)(k + 1 + cand_cap) + 15u) & ~(size_t)15u) + sizeof(float) * (size_t)((dim + 3) & ~3) + 2u * 4u * (size_t)nbcap;
     if (heur) b += 2u * sizeof(float) * (size_t)((dim + 3) & ~3) + 4u * (size_t)nbcap + 4u * 3u * 40u;
     return b;
 }
@@ -739,7 +827,7 @@ __device__ __forceinline__ SearchLds carve_lds(unsigned char *smem, int k, int c
     SearchLds L;
     L.top = reinterpret_cast<ND *>(smem);
     L.cand = L.top + (k + 1);
-    L.qs = reinterpret_cast<float *>(L.cand + cand_cap);
+    L.qs = reinterpret_cast<float *>(smem + ((sizeof(ND) * (size_t)(k + 1 + cand_cap) + 15u) & ~(size_t)15u)); // 16-byte aligned: read in 16-byte pieces (measure_pass2)
     L.nbuf = reinterpret_cast<int *>(L.qs + ((dim + 3) & ~3));
     L.dbuf = reinterpret_cast<float *>(L.nbuf + nbcap);
     // heuristic-only regions (present when the launch sized LDS with heur = true)
@@ -812,18 +900,29 @@ struct VisitedSet {
 };
 
 #ifdef EXP_PHASE_CLOCKS // experiment build: shader-clock cycles per traversal phase, summed over waves
-#ifndef HNSW_SINGLE_TU
-#error "EXP_PHASE_CLOCKS needs -DHNSW_SINGLE_TU: the counters below are per-translation-unit device globals"
-#endif
-__device__ unsigned long long g_phase[12];
-__device__ unsigned long long g_phase_link[12];
+// The counters live in ONE device buffer owned by the host unit; every translation unit keeps a pointer to it in a
+// device global of its own, bound by that unit's hnsw_phase_bind_<unit>() (device_backend.hip calls them all).
+static __device__ unsigned long long *g_phase_ptr;
+#define g_phase (g_phase_ptr)             // [12]
+#define g_phase_link (g_phase_ptr + 12)   // [12]
+#define g_phase_x (g_phase_ptr + 24)      // [16] finer split of an expansion (traverse_sorted)
+constexpr int kPhaseWords = 40;
+static inline hipError_t hnsw_phase_bind_tu(unsigned long long *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ptr), &p, sizeof p); }
+#define HNSW_PHASE_BIND(UNIT) extern "C" hipError_t hnsw_phase_bind_##UNIT(unsigned long long *p) { return hnsw::hnsw_phase_bind_tu(p); }
 #define PH_FLUSH_LINK() do { if (lane == 0) for (int ph_i = 0; ph_i < 8; ++ph_i) atomicAdd(&g_phase_link[ph_i], (unsigned long long)ph_acc[ph_i]); } while (0)
-#define PH_DECL() long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_t = __builtin_readcyclecounter()
+#define PH_DECL() long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_x[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long ph_t = __builtin_readcyclecounter()
 #define PH(i) do { long long ph_n = __builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; } while (0)
+#define PHX(i) do { long long ph_n = __builtin_readcyclecounter(); ph_x[i] += ph_n - ph_t; ph_acc[4] += ph_n - ph_t; ph_t = ph_n; } while (0)
+#define PHX_COUNT(i, v) ph_x[i] += (v)
+#define PHY(i) do { long long ph_n = __builtin_readcyclecounter(); ph_x[i] += ph_n - ph_t; ph_acc[5] += ph_n - ph_t; ph_t = ph_n; } while (0)
 #define PH_COUNT(i, v) ph_acc[i] += (v)
-#define PH_FLUSH() do { if (lane == 0) for (int ph_i = 0; ph_i < 8; ++ph_i) atomicAdd(&g_phase[ph_i], (unsigned long long)ph_acc[ph_i]); } while (0)
+#define PH_FLUSH() do { if (lane == 0) { for (int ph_i = 0; ph_i < 8; ++ph_i) atomicAdd(&g_phase[ph_i], (unsigned long long)ph_acc[ph_i]); for (int ph_i = 0; ph_i < 16; ++ph_i) atomicAdd(&g_phase_x[ph_i], (unsigned long long)ph_x[ph_i]); } } while (0)
 #else
 #define PH_DECL() do {} while (0)
+#define PHX(i) do {} while (0)
+#define PHX_COUNT(i, v) do {} while (0)
+#define PHY(i) do {} while (0)
+#define HNSW_PHASE_BIND(UNIT)
 #define PH(i) do {} while (0)
 #define PH_COUNT(i, v) do {} while (0)
 #define PH_FLUSH() do {} while (0)
@@ -857,7 +956,7 @@ struct ReadLog {
 // FindEntryPoint / FindEntryAtLayer (GraphNavigator.cs:27-82): greedy descent from jb.entry at
 // jb.entry_layer down to (not including) jb.search_layer.  Leaves the entry of the search layer
 // in `best` and its distance in `cur` (both wave-uniform).
-template <int METRIC>
+template <int METRIC, bool TWO = false>
 __device__ __forceinline__ void descend(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                         const GraphView &G, const SearchJob jb, const SearchLds &L, int lane, int &best, float &cur,
                                         unsigned long long &evals, ReadLog &RL)
@@ -884,7 +983,7 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
             __syncthreads();
             for (int i = lane; i < n; i += 64) nbuf[i] = l[1 + i]; // :65 span taken once per pass
             __syncthreads();
-            if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane);
+            if (n > 0) measure_all<METRIC, TWO>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane);
             __syncthreads();
             evals += (unsigned long long)n;
             for (int i = 0; i < n; ++i) { // :67-78
@@ -1140,7 +1239,9 @@ struct SortedTop {
 
 // Returns false on a NaN / -0 distance (exact host re-run); `tie` asks for the exact two-heap
 // traversal.  Result: L.top[0..top_n) ascending by distance.  The query must be staged in L.qs.
-template <int METRIC, int NS, bool HASHED>
+// LAT: the kernel variant for launches that do not fill the chip (one wave per job and CUs to spare): the overlapped form
+// only (rows requested with the visited atomics, lists of at most 64 entries), rows measured two lanes apiece.
+template <int METRIC, int NS, bool HASHED, bool LAT = false>
 __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                                 const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet<HASHED> &V,
                                                 const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals,
@@ -1152,7 +1253,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     PH_DECL();
     int best;
     float cur;
-    descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals, RL);
+    descend<METRIC, LAT>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals, RL);
     // ---- SearchLayer (GraphNavigator.cs:123-189) ----
     const int layer = jb.search_layer;
     RL.layer(layer, lane);
@@ -1212,7 +1313,8 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         bool have = false;     // this lane holds an unvisited neighbour
         float lane_d = 0.0f;
         int lane_id = 0;
-        const bool overlapped = (oflags & 1) != 0 && n <= 64; // oflags bit 0: rows requested with the visited atomics
+        if constexpr (LAT) { if (n > 64) { hash_full = true; break; } } // (the host never launches this variant on such a graph: handed back)
+        const bool overlapped = LAT || ((oflags & 1) != 0 && n <= 64); // oflags bit 0: rows requested with the visited atomics
         if (overlapped) {
             // Latency-bound launch (fewer jobs than resident waves): the rows of ALL listed neighbours
             // are fetched together with the visited atomics instead of after them -- one dependent
@@ -1245,7 +1347,9 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                     pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
                 }
             }
-            if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
+            PHX(0);
+            if (n > 0) measure_all<METRIC, LAT>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
+            PHX(1);
             __syncthreads();
             if constexpr (HASHED) {
                 have = in && (int)old == -1;
@@ -1264,10 +1368,10 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             if (V.crowded()) { hash_full = true; break; }
             lane_d = in ? dbuf[lane] : 0.0f;
             lane_id = nb_a;
-            PH(4);
+            PHX(2);
             if (m == 0) continue;
             evals += (unsigned long long)m;
-        } else {
+        } else if constexpr (!LAT) {
         for (int base = 0; base < n; base += 64) { // :158-161 keep only unvisited, in list order
             const int i = base + lane;
             bool fresh = false;
@@ -1317,6 +1421,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             if (__ballot(valid && key_unsafe(my_d))) { unsafe = true; break; }
             if (grp_cnt > 0 && __ballot(valid && (my_key == grp_key || (top_n >= k && my_key == far_key)))) { tie = true; break; } // (a), (b)
             unsigned long long maybe = __ballot(valid && (top_n < k || my_key < far_key));
+            PHY(8);
             if (rounds == 1 && maybe) {
                 // What the next pop returns is known before the insertions: the closest open entry, or a neighbour of this
                 // expansion that is closer.  In the second case the list prefetched above is the wrong one: request the
@@ -1336,7 +1441,10 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 }
             }
 #ifndef HNSW_NO_BATCH_MERGE
+            PHY(9);
+            PHX_COUNT(5, __popcll(maybe));
             if (maybe & (maybe - 1)) { // two or more: one counting merge instead of as many list shifts
+                PHX_COUNT(3, 1);
                 unsigned last = 0u;
                 bool boundary_tie = false, dropped_expanded = false;
                 T.merge(maybe, my_key, my_id, top_n, k, lane, reinterpret_cast<uint2 *>(L.top), last, boundary_tie, dropped_expanded);
@@ -1352,9 +1460,11 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 maybe = 0ull;
             }
 #endif
+            PHY(10);
             while (maybe) {
                 const int src = __builtin_ctzll(maybe);
                 maybe &= maybe - 1;
+                PHX_COUNT(4, 1);
                 const unsigned dk = (unsigned)__builtin_amdgcn_readlane((int)my_key, src);
                 if (top_n < k || dk < far_key) { // :165
                     const bool evicts = top_n == k;
@@ -1372,6 +1482,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                     }
                 } else if (grp_cnt > 0 && dk == far_key) tie = true; // (b): turned away by equality
             }
+            PHY(11);
         }
         PH(5);
     }
@@ -2063,7 +2174,7 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
 // wave that owns the job met a tie, bit 2 a shadow traversal has been started for it.
 constexpr int kJobAnswered = 1, kJobTied = 2, kJobShadowed = 4;
 
-template <int METRIC, int NS, bool HASHED>
+template <int METRIC, int NS, bool HASHED, bool LAT = false>
 __device__ __forceinline__ void search_job(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
@@ -2104,7 +2215,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         bool tie = false;
         // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
         bool window = false;
-        const bool ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL, nullptr, &window);
+        const bool ok1 = traverse_sorted<METRIC, NS, HASHED, LAT>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL, nullptr, &window);
         if (!(ok1 && tie)) {
             if (!claim_answer()) return;
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
@@ -2136,7 +2247,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
     }
     bool aborted = false;
     const bool ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL,
-                                             shadow ? job_word : nullptr, &aborted, (overlap & 1) != 0 || repeated);
+                                             shadow ? job_word : nullptr, &aborted, LAT || (overlap & 1) != 0 || repeated);
     if (aborted || !claim_answer()) return;
     if (jb.aux == -2) { // SearchLayer's own return value: topCandidates.ToArray(), the heap's array (BinaryHeap.cs:41-44)
         __syncthreads();
@@ -2198,9 +2309,11 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
 // shared counter until none are left.  A wave owns one visited bitset and one spill area for the
 // whole launch and leaves the bitset clean after every job, so the scratch is sized by the
 // resident waves (not by the batch) and nothing is memset between launches.
-template <int METRIC, int NS, bool HASHED>
-// float rows: 168 VGPRs, three waves per SIMD; int8 records keep 16 registers of rows in flight, not 64: five waves
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(METRIC == M_I8 ? (NS <= 2 ? 5 : 4) : (NS <= 4 ? 3 : 2))))
+template <int METRIC, int NS, bool HASHED, bool LAT = false>
+// float rows: 168 VGPRs, three waves per SIMD; int8 records keep 16 registers of rows in flight, not 64: five waves.
+// LAT (launches that do not fill the chip): no occupancy to buy -- every spilled register is a memory round trip a lone wave
+// waits out in full -- so two waves per SIMD at most (256 VGPRs), one with eight register sets
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(LAT ? (NS <= 4 ? 2 : 1) : METRIC == M_I8 ? (NS <= 2 ? 5 : 4) : (NS <= 4 ? 3 : 2)))))
 graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
@@ -2243,6 +2356,18 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
             t = __builtin_amdgcn_readfirstlane(t);
             if (t >= njobs || t >= (int)gridDim.x) break; // only the last gridDim.x jobs can still be running
             job = njobs - 1 - t;
+            if (ready) {
+                // a gated launch (query rows still arriving): no shadow for a job whose row has not landed -- its owner is
+                // asleep at the gate and search_job would read whatever the previous call left in that row
+                const int need = __builtin_amdgcn_readfirstlane(jobs[job].qref);
+                if (need >= known_ready) {
+                    int r = 0;
+                    if (lane == 0) r = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    known_ready = __builtin_amdgcn_readfirstlane(r);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (need >= known_ready) continue;
+                }
+            }
             int old = 0;
             if (lane == 0) old = atomicOr(job_words + job, kJobShadowed);
             old = __builtin_amdgcn_readfirstlane(old);
@@ -2262,16 +2387,23 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the rows read next were written by the copy engine
                 if (need >= known_ready) {
-                    if (lane == 0) {
+                    // handed back.  With shadows the job word decides who answers, exactly as for a tie (search_job): a
+                    // shadow that started because the row landed meanwhile keeps the job; otherwise this wave claims it.
+                    int old = 0;
+                    if (shadows && lane == 0) {
+                        old = atomicOr(job_words + job, kJobTied);
+                        if (!(old & (kJobShadowed | kJobAnswered))) old = atomicOr(job_words + job, kJobAnswered) & kJobAnswered;
+                    }
+                    old = __builtin_amdgcn_readfirstlane(old);
+                    if (old == 0 && lane == 0) {
                         out_cnt[job] = 0;
                         out_flag[job] = 1;
-                        if (shadows) atomicOr(job_words + job, kJobAnswered); // no shadow for a job whose row is not there
                     }
                     continue;
                 }
             }
         }
-        search_job<METRIC, NS, HASHED>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
+        search_job<METRIC, NS, HASHED, LAT>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
                                V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job, overlap, shadows ? job_words + job : nullptr,
                                shadow);
         V.clear(lane);
@@ -2436,7 +2568,7 @@ graph_range_kernel(const float *__restrict__ rows, const double *__restrict__ ro
 // clear their visited bitset between layers).  Output per (job, layer): the selected ids in
 // selection order (layer 0 -> slot `job`; layer L >= 1 -> upper slot jobs[].aux + L - 1).
 // jobs[].search_layer = the item's first layer min(level, top).
-template <int METRIC, int NS, bool HASHED>
+template <int METRIC, int NS, bool HASHED, bool LAT = false>
 __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
@@ -2473,7 +2605,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         const unsigned long long ev0 = evals;
         if constexpr (NS > 0) {
             bool tie = false;
-            ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap, RL, &order_tie); // Span.Sort consumes all
+            ok = traverse_sorted<METRIC, NS, HASHED, LAT>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap, RL, &order_tie); // Span.Sort consumes all
             if (!ok) break;
             // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
             // then returns them in HEAP order, Heuristic.cs:13-18): this layer again, exact traversal
@@ -2490,7 +2622,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                     V.clear(lane);
                 }
                 ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL, nullptr, nullptr,
-                                              overlap != 0);
+                                              LAT || overlap != 0);
                 if (!ok) break;
             }
 #ifdef EXP_PHASE_CLOCKS
@@ -2547,8 +2679,8 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     }
 }
 
-template <int METRIC, int NS, bool HASHED>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS <= 4 ? 3 : 2))) // up to 256 candidates: 168 VGPRs, three waves per SIMD
+template <int METRIC, int NS, bool HASHED, bool LAT = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(LAT ? (NS <= 4 ? 2 : 1) : NS <= 4 ? 3 : 2)))) // up to 256 candidates: 168 VGPRs, three waves per SIMD (LAT: see graph_search_kernel)
 graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
@@ -2572,7 +2704,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         // longest; started last they would be the tail of the launch).  Results are filed by item, so the
         // order of processing changes nothing else.
         if (order) job = __builtin_amdgcn_readfirstlane(order[job]);
-        insert_job<METRIC, NS, HASHED>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
+        insert_job<METRIC, NS, HASHED, LAT>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
                                out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap, read_log, read_log_cap);
         V.clear(lane);
     }
@@ -3153,24 +3285,28 @@ __global__ void sqrt_rn_kernel(const double *in, double *out, int n)
 // Explicit instantiations of the two traversal kernels live in traverse_<metric>_<search|insert>.hip;
 // every other unit only declares them.
 #define HNSW_FOR_EACH_TRAVERSAL(X, M) \
-    X(M, 0, false) X(M, 1, false) X(M, 2, false) X(M, 4, false) X(M, 8, false) \
-    X(M, 0, true) X(M, 1, true) X(M, 2, true) X(M, 4, true) X(M, 8, true)
-#define HNSW_SEARCH_SIGNATURE(PREFIX, M, NS, H)                                                                                  \
-    PREFIX template __global__ void graph_search_kernel<M, NS, H>(                                                              \
+    X(M, 0, false, false) X(M, 1, false, false) X(M, 2, false, false) X(M, 4, false, false) X(M, 8, false, false) \
+    X(M, 0, true, false) X(M, 1, true, false) X(M, 2, true, false) X(M, 4, true, false) X(M, 8, true, false)
+// the latency variants (sorted-list kernels only): units of their own
+#define HNSW_FOR_EACH_TRAVERSAL_LAT(X, M) \
+    X(M, 1, false, true) X(M, 2, false, true) X(M, 4, false, true) X(M, 8, false, true) \
+    X(M, 1, true, true) X(M, 2, true, true) X(M, 4, true, true) X(M, 8, true, true)
+#define HNSW_SEARCH_SIGNATURE(PREFIX, M, NS, H, LT)                                                                                  \
+    PREFIX template __global__ void graph_search_kernel<M, NS, H, LT>(                                                              \
         const float *__restrict__, const double *__restrict__, const float *__restrict__, const double *__restrict__, int,      \
         const int *__restrict__, int, const int64_t *__restrict__, const int *__restrict__, int, const SearchJob *__restrict__,  \
         int, int, ND *__restrict__, int, unsigned *__restrict__, long long, int *__restrict__, int, int, int *__restrict__,      \
         float *__restrict__, int *__restrict__, int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int, \
         const int *__restrict__);
-#define HNSW_INSERT_SIGNATURE(PREFIX, M, NS, H)                                                                                  \
-    PREFIX template __global__ void graph_insert_search_kernel<M, NS, H>(                                                       \
+#define HNSW_INSERT_SIGNATURE(PREFIX, M, NS, H, LT)                                                                                  \
+    PREFIX template __global__ void graph_insert_search_kernel<M, NS, H, LT>(                                                       \
         const float *__restrict__, const double *__restrict__, int, const int *__restrict__, int, const int64_t *__restrict__,   \
         const int *__restrict__, int, const SearchJob *__restrict__, int, int, ND *__restrict__, int, int, unsigned *__restrict__, \
         long long, int *__restrict__, int, int *__restrict__, int *__restrict__, int *__restrict__, int *__restrict__, int,      \
         int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int, const int *__restrict__, int *__restrict__, int);
-#define HNSW_DECLARE_TRAVERSAL(M, NS, H) HNSW_SEARCH_SIGNATURE(extern, M, NS, H) HNSW_INSERT_SIGNATURE(extern, M, NS, H)
-#define HNSW_DEFINE_TRAVERSAL(M, NS, H) HNSW_SEARCH_SIGNATURE(, M, NS, H) HNSW_INSERT_SIGNATURE(, M, NS, H)
-#define HNSW_DEFINE_SEARCH(M, NS, H) HNSW_SEARCH_SIGNATURE(, M, NS, H)
-#define HNSW_DEFINE_INSERT(M, NS, H) HNSW_INSERT_SIGNATURE(, M, NS, H)
+#define HNSW_DECLARE_TRAVERSAL(M, NS, H, LT) HNSW_SEARCH_SIGNATURE(extern, M, NS, H, LT) HNSW_INSERT_SIGNATURE(extern, M, NS, H, LT)
+#define HNSW_DEFINE_TRAVERSAL(M, NS, H, LT) HNSW_SEARCH_SIGNATURE(, M, NS, H, LT) HNSW_INSERT_SIGNATURE(, M, NS, H, LT)
+#define HNSW_DEFINE_SEARCH(M, NS, H, LT) HNSW_SEARCH_SIGNATURE(, M, NS, H, LT)
+#define HNSW_DEFINE_INSERT(M, NS, H, LT) HNSW_INSERT_SIGNATURE(, M, NS, H, LT)
 
 } // namespace hnsw

@@ -997,6 +997,11 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         int blocker = -1;         // this round: the first item of the window whose linking invalidates this result (-1: none)
     };
     std::vector<Spec> spec((size_t)ring);
+    // Write stamps are compared with snapshots taken inside THIS call only, and every stamp an earlier call left is at most
+    // the seq_ this call starts from -- as good as none.  So the upper-layer map starts empty each call (it would otherwise
+    // grow by one entry per upper-layer list ever written), and the counter restarts long before it can wrap.
+    modU_.clear();
+    if (seq_ > 0x7fff0000u) { std::fill(mod0_.begin(), mod0_.end(), 0u); seq_ = 0; }
     if (mod0_.size() < (size_t)graph_.length) mod0_.resize((size_t)graph_.length, 0u);
     auto modU_at = [&](uint64_t k) -> uint32_t { auto it = modU_.find(k); return it == modU_.end() ? 0u : it->second; };
     auto up_valid = [&](const Spec &s, uint32_t cur) {
@@ -1476,6 +1481,7 @@ int HnswIndex::knn_query(const float *queries, int count, int dim, int k, int *o
     if (set_resident_queries(queries, count, dim, err, streamed) < 0) return -1;
     const int rc = knn_query_resident(k, out_ids, out_dists, err);
     for (int g = 0; g < (sharded_resident_ ? p_.devices : 1); ++g) context(g)->cancel_streamed(); // (only after an error: `queries` is borrowed for this call)
+    if (rc < 0) resident_queries_ = 0; // a failed call leaves no resident set: part of it may never have been uploaded
     return rc;
 }
 
@@ -1576,7 +1582,7 @@ void HnswIndex::collect_stats(hnswdev_stats *out)
         out->search_launches += s.search_launches; out->search_evals += s.search_evals; out->search_timed_launches += s.search_timed_launches;
         out->search_timed_evals += s.search_timed_evals; out->search_kernel_ms += s.search_kernel_ms; out->search_overflows += s.search_overflows;
         out->search_repeats += s.search_repeats; out->visited_hash_launches += s.visited_hash_launches;
-        out->tie_windows += s.tie_windows;
+        out->tie_windows += s.tie_windows; out->lat_launches += s.lat_launches;
     }
 }
 
@@ -1772,12 +1778,23 @@ int HnswIndex::remove(const int *ids, int count, std::string &err)
     ++graph_epoch_;
     if (!refresh_host_lists(err)) return -1;
     {
-        std::vector<unsigned char> listed((size_t)graph_.length, 0); // duplicates in O(count)
+        // duplicates: a bitmap over the slots only when the call is large enough to pay for zeroing it (hnsw_remove's usual
+        // call names ONE id; a 10M-node index would allocate and clear 10 MB for it), a sorted copy otherwise
+        const bool bitmap = (long long)count * 64 > (long long)graph_.length;
+        std::vector<unsigned char> listed(bitmap ? (size_t)graph_.length : 0, 0);
         for (int t = 0; t < count; ++t) {
             const int id = ids[t];
             if (id < 0 || id >= graph_.length || graph_.removed[(size_t)id]) { err = "System.IndexOutOfRangeException: hnsw_remove: id " + std::to_string(id) + " is not in the index"; return -1; }
-            if (listed[(size_t)id]) { err = "System.ArgumentException: hnsw_remove: duplicate id " + std::to_string(id); return -1; }
-            listed[(size_t)id] = 1;
+            if (bitmap) {
+                if (listed[(size_t)id]) { err = "System.ArgumentException: hnsw_remove: duplicate id " + std::to_string(id); return -1; }
+                listed[(size_t)id] = 1;
+            }
+        }
+        if (!bitmap && count > 1) {
+            std::vector<int> sorted(ids, ids + count);
+            std::sort(sorted.begin(), sorted.end());
+            const auto dup = std::adjacent_find(sorted.begin(), sorted.end());
+            if (dup != sorted.end()) { err = "System.ArgumentException: hnsw_remove: duplicate id " + std::to_string(*dup); return -1; }
         }
     }
     Graph &g = graph_;

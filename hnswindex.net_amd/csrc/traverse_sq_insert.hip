@@ -5,3 +5,4 @@
 namespace hnsw {
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DEFINE_INSERT, M_SQ)
 } // namespace hnsw
+HNSW_PHASE_BIND(sq_insert)
