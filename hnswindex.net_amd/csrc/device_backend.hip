@@ -140,6 +140,8 @@ static void phase_report(const char *when)
             100 * h[0] / tot, 100 * h[1] / tot, 100 * h[2] / tot, 100 * h[3] / tot, 100 * h[4] / tot, 100 * h[5] / tot, h[7], 100.0 * h[6] / e, tot / e);
     fprintf(stderr, "[phase clocks, per expansion] descent %.0f pop %.0f list %.0f visited %.0f rows %.0f (before %.0f, measure %.0f, after %.0f) push %.0f (checks %.0f, next-pop guess %.0f, merge %.0f, single inserts %.0f) | merges %.2f, single inserts %.2f, candidates passing %.2f\n",
             h[0] / e, h[1] / e, h[2] / e, h[3] / e, h[4] / e, hx[0] / e, hx[1] / e, hx[2] / e, h[5] / e, hx[8] / e, hx[9] / e, hx[10] / e, hx[11] / e, hx[3] / e, hx[4] / e, hx[5] / e);
+    if (hx[13]) fprintf(stderr, "[phase clocks, memory wave, per expansion] waiting for a request %.0f, list %.0f, marks + rows + distances %.0f, keys + answer %.0f\n",
+                        hx[12] / e, hx[13] / e, hx[14] / e, hx[15] / e);
 }
 #endif
 
@@ -924,10 +926,10 @@ int Device::max_waves_per_cu()
 
 // Blocks (= waves) of a persistent traversal launch: what stays resident on the chip.
 template <class K>
-static int resident_blocks(K kernel, size_t lds, int num_cu)
+static int resident_blocks(K kernel, size_t lds, int num_cu, int threads = 64)
 {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1) per_cu = threads > 64 ? 4 : 8;
     if (const char *e = std::getenv("HNSW_MI355X_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e))); // experiments: fewer persistent waves
     return per_cu * std::max(1, num_cu);
 }
@@ -966,6 +968,7 @@ static int overlap_mode()
 // The latency variants of the traversal kernels (device_kernels.h, LAT) for launches that do not fill the chip -- B = 1
 // Add, the exact window's rounds, small query calls: 0 never, 1 (default) when the jobs fit the variant's resident waves,
 // 2 whenever the graph allows it (adjacency lists of at most 64 entries; tests).
+static constexpr size_t kTeamLds = ((sizeof(TeamMail) + 15) & ~(size_t)15) + 16; // the latency variants' mailbox, behind the traversal's LDS
 static int lat_mode()
 {
     const char *e = std::getenv("HNSW_MI355X_LAT");
@@ -1154,14 +1157,14 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
 #define LAUNCH2L(M, NS_, H_, LAT_, SLOTS, GRID, LDS, CAP) \
         hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_, H_, LAT_>), dim3(std::min<int>(GRID, SLOTS)), \
-                       dim3(64), LDS, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
+                       dim3(LAT_ ? 128 : 64), (LDS) + (LAT_ ? kTeamLds : 0), st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, p_sel0 + (size_t)off * sel_stride, p_cnt0 + off, p_selU, p_cntU,        \
                        sel_stride, p_flag + off, p_evals, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
                        windowed ? p_log : (int *)nullptr, read_log_cap)
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \
-        const int lslots_ = NS_ > 0 && lat_mode() != 0 && g_stride0_ - 2 <= 64 ? std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, (NS_ > 0 ? NS_ : 1), H_, true>, LDS, num_cu_)) : 0; \
+        const int lslots_ = NS_ > 0 && lat_mode() != 0 && g_stride0_ - 2 <= 64 && (LDS) + kTeamLds <= 64 * 1024 ? std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, (NS_ > 0 ? NS_ : 1), H_, true>, (LDS) + kTeamLds, num_cu_, 128)) : 0; \
         if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, (NS_ > 0 ? NS_ : 1), H_, true, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
         else { \
             const int slots_ = std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_, false>, LDS, num_cu_)); \
@@ -1686,13 +1689,13 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
 #define LAUNCH2L(M, NS_, H_, LAT_, SLOTS, GRID, LDS, CAP) \
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_, LAT_>), dim3(std::min<int>(GRID, SLOTS)), \
-                       dim3(64), LDS, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
+                       dim3(LAT_ ? 128 : 64), (LDS) + (LAT_ ? kTeamLds : 0), st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
                        spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
                        gate)
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \
-        const int lslots_ = NS_ > 0 && lat_mode() != 0 && g_stride0_ - 2 <= 64 ? std::min(max_slots(), resident_blocks(graph_search_kernel<M, (NS_ > 0 ? NS_ : 1), H_, true>, LDS, num_cu_)) : 0; \
+        const int lslots_ = NS_ > 0 && lat_mode() != 0 && g_stride0_ - 2 <= 64 && (LDS) + kTeamLds <= 64 * 1024 ? std::min(max_slots(), resident_blocks(graph_search_kernel<M, (NS_ > 0 ? NS_ : 1), H_, true>, (LDS) + kTeamLds, num_cu_, 128)) : 0; \
         if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, (NS_ > 0 ? NS_ : 1), H_, true, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
         else { \
             const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_, false>, LDS, num_cu_)); \

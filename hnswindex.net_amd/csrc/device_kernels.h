@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 
 #include "device_backend.h"
@@ -17,6 +18,27 @@
 
 namespace hnsw {
 
+// Every block of the kernels below that stage data through LDS is ONE wavefront working on its own job (the latency
+// variants add a second wave with a role of its own, which never meets the first at a barrier): what the phases of
+// such a wave need between a write and the reads of other lanes is that its own memory operations have completed and
+// that the compiler keeps the order -- what __syncthreads() does in front of its s_barrier, without the barrier.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+// LDS ordering inside ONE wave (every traversal block is one wave): the wave's LDS instructions execute in order, so
+// all a write-then-read by other lanes needs is that the compiler keeps them in order -- not wave_sync(), whose
+// s_waitcnt also drains the vector-memory counter and with it every load still in flight.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // ------------------------------------------------------------------------------------
 // device code
 // ------------------------------------------------------------------------------------
@@ -884,7 +906,7 @@ struct VisitedSet {
     __device__ __forceinline__ bool crowded() const { return HASHED && seen > limit; }
     __device__ __forceinline__ void clear(int lane)
     {
-        __syncthreads();
+        wave_sync();
         if constexpr (HASHED) {
             uint4 *t4 = reinterpret_cast<uint4 *>(tab);
             const uint4 e = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -895,7 +917,7 @@ struct VisitedSet {
             for (long long w = lane; w < (words >> 2); w += 64) v4[w] = z;
         }
         seen = 0;
-        __syncthreads();
+        wave_sync();
     }
 };
 
@@ -965,11 +987,11 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
     float *dbuf = L.dbuf;
     const float *qs = L.qs;
     best = jb.entry;
-    __syncthreads();
+    wave_sync();
     if (lane == 0) nbuf[0] = best;
-    __syncthreads();
+    wave_sync();
     measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, 1, lane);
-    __syncthreads();
+    wave_sync();
     cur = dbuf[0]; // :57
     evals += 1;
     for (int layer = jb.entry_layer; layer > jb.search_layer; --layer) {
@@ -980,11 +1002,11 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
             const int *l = G.list(best, layer);
             const int n = l[0];
             RL.put(best, lane);
-            __syncthreads();
+            wave_sync();
             for (int i = lane; i < n; i += 64) nbuf[i] = l[1 + i]; // :65 span taken once per pass
-            __syncthreads();
+            wave_sync();
             if (n > 0) measure_all<METRIC, TWO>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane);
-            __syncthreads();
+            wave_sync();
             evals += (unsigned long long)n;
             for (int i = 0; i < n; ++i) { // :67-78
                 float d = dbuf[i];
@@ -1048,15 +1070,6 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
 // doubts above) -- which matters because
 // an exact traversal takes three times as long as a sorted one and a launch ends with its last job (17-35 % of a
 // 12 500-query launch at 10M was the wait for such jobs, measured).
-// LDS ordering inside ONE wave (every traversal block is one wave): the wave's LDS instructions execute in order, so
-// all a write-then-read by other lanes needs is that the compiler keeps them in order -- not __syncthreads(), whose
-// s_waitcnt also drains the vector-memory counter and with it every load still in flight.
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 __device__ __forceinline__ int dpp_wave_shr1(int carry_in, int v)
 {
     return __builtin_amdgcn_update_dpp(carry_in, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); // lane 0 keeps carry_in
@@ -1239,9 +1252,207 @@ struct SortedTop {
 
 // Returns false on a NaN / -0 distance (exact host re-run); `tie` asks for the exact two-heap
 // traversal.  Result: L.top[0..top_n) ascending by distance.  The query must be staged in L.qs.
-// LAT: the kernel variant for launches that do not fill the chip (one wave per job and CUs to spare): the overlapped form
-// only (rows requested with the visited atomics, lists of at most 64 entries), rows measured two lanes apiece.
-template <int METRIC, int NS, bool HASHED, bool LAT = false>
+// wave-wide minimum / maximum: four DPP steps inside the rows of 16 lanes, then the four rows' results
+// (v_min / v_max with the DPP operand fused, written out: the compiler keeps a v_mov_dpp and the hazard nops apart from the
+// operation.  A DPP operand needs two wait states after the VALU write of its register: s_nop 1.  Rows are the wave's
+// groups of 16 lanes; row_bcast:15 / :31 carry a row's result into the next row / the upper half, so lane 63 ends up with
+// the whole wave's.)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) // uniform result
+{
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long lds_uniform_u64(const unsigned long long *p) // a word every lane reads alike, as two scalars
+{
+    const unsigned long long v = *p;
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+}
+// ---- the latency variants' second wave ------------------------------------------------------------------
+// One wavefront issues at most one instruction every four clocks, and a traversal is a chain of expansions: in a launch
+// that does not fill the chip (B = 1 Add, a round of the exact window, a small query call) the chain's length IS the
+// launch, and the phase clocks of such a launch show an expansion of 11 000-12 000 clocks of which the memory round trip
+// is 1 800 (tools/latency_probe.hip) -- the rest is one wave's instruction stream: list, visited atomics, 64 loads and
+// 128 multiply-adds, then the ranked insertions.  The chip has SIMDs to spare in such a launch, so the latency variants
+// run a job on TWO waves of one block with roles of their own:
+//   * the LOGIC wave (wave 0) is the traversal as everywhere else: the sorted list, the pops, the tie rules, the
+//     insertions, the read log, the heuristic;
+//   * the MEMORY wave (wave 1) serves requests "expand node v on layer l": out-edge list, visited atomics, the rows of
+//     all listed neighbours (overlapped form), their distances (two lanes per row) -- and answers with ids, distances
+//     and the mask of first visits in the block's LDS mailbox.
+// What the NEXT pop returns is known before the insertions -- the closest open entry, or a neighbour of this expansion
+// that is closer (see the guess below) -- so the logic wave posts the next request BEFORE it merges, and the merge runs
+// under the memory wave's round trip.  The prediction is checked when the pop actually happens; a mismatch (never
+// observed: equal keys are not predicted) or any early exit abandons the traversal's state as a tie would, which clears
+// the visited set the early request has touched.  The waves meet only through LDS words (release / acquire at
+// workgroup scope, in-order LDS): never at a barrier.
+struct TeamMail {
+    int req_seq, req_node, req_layer;       // written by the logic wave; node < 0: the launch is over
+    unsigned req_far;                       // ... and an upper bound of the farthest result's key while this request is served (0xffffffff: none)
+    // the answer's header, two 16-byte reads for the logic wave:
+    int rsp_seq;                            // written last by the memory wave
+    int n;                                  // length of the list (> 64: not served); bit 16: a first-visited neighbour's distance is NaN / -0
+    unsigned best_key;                      // the smallest key among the neighbours in `pass` (0xffffffff: none) ...
+    int best_lane;                          // ... the first lane holding it, bit 31 set if another one holds it too
+    unsigned long long fresh;               // bit i: neighbour i had not been visited
+    unsigned long long pass;                // ... and its key is below req_far (a superset of what the push test lets through: the bound only shrinks)
+    double sb;                              // cosine: sqrt-norm of the job's vector
+    int hint_node, pad0;                    // the logic wave's guess at the NEXT node (its closest open entry; -1: none): a list to prefetch, no more
+    int ids[64];                            // the listed neighbours, in list order
+    float dist[64];                         // distances to the job's vector (staged in L.qs by the logic wave); on answer: their KEYS (f2key), as bits
+};
+static_assert(offsetof(TeamMail, rsp_seq) == 16 && offsetof(TeamMail, fresh) == 32 && offsetof(TeamMail, ids) % 16 == 0, "TeamMail layout");
+struct TeamPort { // the logic wave's end
+    TeamMail *m;
+    int sent, got;
+
+    __device__ __forceinline__ void post(int node, int layer, int lane, unsigned far = 0xffffffffu)
+    {
+        ++sent;
+        if (lane == 0) {
+            m->req_node = node;
+            m->req_layer = layer;
+            m->req_far = far;
+            __hip_atomic_store(&m->req_seq, sent, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __device__ __forceinline__ bool pending() const { return sent != got; }
+    __device__ __forceinline__ void wait()
+    {
+        while (__hip_atomic_load(&m->rsp_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != sent) __builtin_amdgcn_s_sleep(1);
+        got = sent;
+    }
+};
+
+// The memory wave's loop (until a request names node -1).  V: the block's visited set (the logic wave clears it between
+// jobs and counts its entries; this wave only marks).
+template <int METRIC, bool HASHED>
+__device__ __forceinline__ void memory_wave(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, const GraphView &G,
+                                            VisitedSet<HASHED> &V, const float *qs, TeamMail *mail, int lane)
+{
+#ifdef EXP_PHASE_CLOCKS
+    long long mw_t = __builtin_readcyclecounter(), mw_acc[4] = {0, 0, 0, 0};
+#define MW_PH(i) do { const long long mw_n = __builtin_readcyclecounter(); mw_acc[i] += mw_n - mw_t; mw_t = mw_n; } while (0)
+#define MW_FLUSH() do { if (lane == 0) for (int mw_i = 0; mw_i < 4; ++mw_i) atomicAdd(&g_phase_x[12 + mw_i], (unsigned long long)mw_acc[mw_i]); } while (0)
+#else
+#define MW_PH(i) do {} while (0)
+#define MW_FLUSH() do {} while (0)
+#endif
+    // Two lists requested ahead of their node's expansion (a list is a dependent HBM round trip of its own, 1 900 clocks in
+    // front of the rows'): the logic wave's hint -- its closest open entry, the next pop unless this expansion finds something
+    // closer -- while the rows are in flight, and the closest neighbour passing the push test as soon as the distances are
+    // known -- the next pop in the other case.  [count, e0 .. e63] in one register per lane plus the 64th entry.
+    int ha_node = -1, ha_layer = 0, ha_v = 0, ha_w = 0; // the hint's list
+    int hc_node = -1, hc_layer = 0, hc_v = 0, hc_w = 0; // the closest neighbour's
+    for (int seq = 1;; ++seq) {
+        while (__hip_atomic_load(&mail->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);
+        MW_PH(0);
+        const int node = __builtin_amdgcn_readfirstlane(mail->req_node);
+        if (node < 0) { MW_FLUSH(); return; }
+        const int layer = __builtin_amdgcn_readfirstlane(mail->req_layer);
+        int n, nb = 0;
+        if ((node == ha_node && layer == ha_layer) || (node == hc_node && layer == hc_layer)) {
+            const bool a = node == ha_node && layer == ha_layer;
+            const int v = a ? ha_v : hc_v, w = a ? ha_w : hc_w;
+            n = __builtin_amdgcn_readlane(v, 0);
+            nb = __shfl(v, (lane + 1) & 63, 64);
+            if (lane == 63) nb = __builtin_amdgcn_readlane(w, 0);
+        } else {
+            const int *l = G.list(node, layer);
+            n = __builtin_amdgcn_readfirstlane(l[0]);
+            if (lane < n && lane < 64) nb = l[1 + lane];
+        }
+        if (n > 64) { // (the host never launches this variant on such a graph)
+            if (lane == 0) { mail->n = n; mail->fresh = 0ull; mail->pass = 0ull; __hip_atomic_store(&mail->rsp_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            continue;
+        }
+        const bool in = lane < n;
+        if (in) mail->ids[lane] = nb;
+        wave_lds_sync();
+        MW_PH(1);
+        {   // the hint's list, in flight with the marks and the rows
+            const int hint = __builtin_amdgcn_readfirstlane(mail->hint_node);
+            if (hint >= 0 && !(hint == ha_node && layer == ha_layer)) {
+                const int *pl = G.list(hint, layer);
+                const int lstride = layer == 0 ? G.stride0 : G.strideU;
+                ha_node = hint; ha_layer = layer;
+                ha_v = lane < lstride ? pl[lane] : 0;
+                ha_w = 64 < lstride ? pl[64] : 0;
+            }
+        }
+        // visited marks (GraphNavigator.cs:181), in flight with the row loads
+        unsigned old = 0u;
+        const unsigned bit = 1u << (nb & 31);
+        unsigned hpos = 0u;
+        if constexpr (HASHED) {
+            hpos = ((unsigned)nb * 2654435761u) & V.tab_mask;
+            if (in) old = (unsigned)atomicCAS(&V.tab[hpos], -1, nb);
+        } else if (in) old = atomicOr(&V.bits[nb >> 5], bit);
+        if (n > 0) measure_all<METRIC, true>(rows, row_sn, dim, qs, mail->sb, mail->ids, mail->dist, n, lane); // :163 (and the visited ones)
+        bool have;
+        if constexpr (HASHED) {
+            have = in && (int)old == -1;
+            if (in && (int)old != -1 && (int)old != nb) { // slot taken by another id: probe on (VisitedSet::first_visit)
+                for (unsigned probes = 0; probes <= V.tab_mask; ++probes) {
+                    hpos = (hpos + 1) & V.tab_mask;
+                    const int o2 = atomicCAS(&V.tab[hpos], -1, nb);
+                    if (o2 == -1) { have = true; break; }
+                    if (o2 == nb) break;
+                }
+            }
+        } else have = in && (old & bit) == 0u;
+        const unsigned long long mask = __ballot(have);
+        MW_PH(2);
+        // what the logic wave would compute first of all, done here (this wave has the slack): keys, the push test against
+        // the bound that came with the request, the closest neighbour passing it
+        wave_lds_sync();
+        const float d = in ? mail->dist[lane] : 0.0f;
+        const unsigned key = f2key(d);
+        const unsigned far = (unsigned)__builtin_amdgcn_readfirstlane((int)mail->req_far);
+        const unsigned long long odd = __ballot(have && key_unsafe(d));
+        const unsigned long long pass = __ballot(key < far) & mask;
+        const unsigned bk = wave_min_u32(((pass >> lane) & 1ull) != 0ull ? key : 0xffffffffu);
+        const unsigned long long bm = __ballot(key == bk) & pass;
+        wave_lds_sync();
+        if (in) mail->dist[lane] = __uint_as_float(key);
+        if (lane == 0) {
+            mail->n = n | (odd != 0ull ? 0x10000 : 0); mail->fresh = mask; mail->pass = pass;
+            mail->best_key = bk;
+            mail->best_lane = bm ? ((int)__builtin_ctzll(bm) | ((bm & (bm - 1)) ? (int)0x80000000 : 0)) : 0;
+        }
+        wave_lds_sync();
+        if (lane == 0) __hip_atomic_store(&mail->rsp_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (bm) { // the closest neighbour's list: under way while the logic wave reads the answer and decides
+            const int cn = __builtin_amdgcn_readlane(nb, (int)__builtin_ctzll(bm));
+            const int *pl = G.list(cn, layer);
+            const int lstride = layer == 0 ? G.stride0 : G.strideU;
+            hc_node = cn; hc_layer = layer;
+            hc_v = lane < lstride ? pl[lane] : 0;
+            hc_w = 64 < lstride ? pl[64] : 0;
+        }
+        MW_PH(3);
+    }
+}
+
+template <int METRIC, int NS, bool HASHED>
 __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                                 const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet<HASHED> &V,
                                                 const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals,
@@ -1253,7 +1464,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     PH_DECL();
     int best;
     float cur;
-    descend<METRIC, LAT>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals, RL);
+    descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals, RL);
     // ---- SearchLayer (GraphNavigator.cs:123-189) ----
     const int layer = jb.search_layer;
     RL.layer(layer, lane);
@@ -1307,14 +1518,13 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         PH_COUNT(6, c.id == pre_id);
         PH_COUNT(7, 1);
         int m = 0;
-        __syncthreads();
+        wave_sync();
         PH(2);
         // candidate distances and ids of this expansion, one per lane, in adjacency order
         bool have = false;     // this lane holds an unvisited neighbour
         float lane_d = 0.0f;
         int lane_id = 0;
-        if constexpr (LAT) { if (n > 64) { hash_full = true; break; } } // (the host never launches this variant on such a graph: handed back)
-        const bool overlapped = LAT || ((oflags & 1) != 0 && n <= 64); // oflags bit 0: rows requested with the visited atomics
+        const bool overlapped = (oflags & 1) != 0 && n <= 64; // oflags bit 0: rows requested with the visited atomics
         if (overlapped) {
             // Latency-bound launch (fewer jobs than resident waves): the rows of ALL listed neighbours
             // are fetched together with the visited atomics instead of after them -- one dependent
@@ -1322,7 +1532,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             // bandwidth, of which such a launch has plenty.  Evaluations counted: the unvisited ones.
             const bool in = lane < n;
             if (in) nbuf[lane] = nb_a;
-            __syncthreads();
+            wave_sync();
             unsigned old = 0u;
             const unsigned bit = 1u << (nb_a & 31);
             unsigned hpos = 0u;
@@ -1347,10 +1557,8 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                     pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
                 }
             }
-            PHX(0);
-            if (n > 0) measure_all<METRIC, LAT>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
-            PHX(1);
-            __syncthreads();
+            if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
+            wave_sync();
             if constexpr (HASHED) {
                 have = in && (int)old == -1;
                 if (in && (int)old != -1 && (int)old != nb_a) { // slot taken by another id: probe on (VisitedSet::first_visit)
@@ -1368,10 +1576,10 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             if (V.crowded()) { hash_full = true; break; }
             lane_d = in ? dbuf[lane] : 0.0f;
             lane_id = nb_a;
-            PHX(2);
+            PH(4);
             if (m == 0) continue;
             evals += (unsigned long long)m;
-        } else if constexpr (!LAT) {
+        } else {
         for (int base = 0; base < n; base += 64) { // :158-161 keep only unvisited, in list order
             const int i = base + lane;
             bool fresh = false;
@@ -1400,12 +1608,12 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
             }
         }
-        __syncthreads();
+        wave_sync();
         if (m == 0) continue;
         V.seen += m;
         if (V.crowded()) { hash_full = true; break; } // the id table is filling up: host traversal
         measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
-        __syncthreads();
+        wave_sync();
         PH(4);
         evals += (unsigned long long)m;
         }
@@ -1421,7 +1629,6 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             if (__ballot(valid && key_unsafe(my_d))) { unsafe = true; break; }
             if (grp_cnt > 0 && __ballot(valid && (my_key == grp_key || (top_n >= k && my_key == far_key)))) { tie = true; break; } // (a), (b)
             unsigned long long maybe = __ballot(valid && (top_n < k || my_key < far_key));
-            PHY(8);
             if (rounds == 1 && maybe) {
                 // What the next pop returns is known before the insertions: the closest open entry, or a neighbour of this
                 // expansion that is closer.  In the second case the list prefetched above is the wrong one: request the
@@ -1441,10 +1648,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 }
             }
 #ifndef HNSW_NO_BATCH_MERGE
-            PHY(9);
-            PHX_COUNT(5, __popcll(maybe));
             if (maybe & (maybe - 1)) { // two or more: one counting merge instead of as many list shifts
-                PHX_COUNT(3, 1);
                 unsigned last = 0u;
                 bool boundary_tie = false, dropped_expanded = false;
                 T.merge(maybe, my_key, my_id, top_n, k, lane, reinterpret_cast<uint2 *>(L.top), last, boundary_tie, dropped_expanded);
@@ -1460,11 +1664,9 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 maybe = 0ull;
             }
 #endif
-            PHY(10);
             while (maybe) {
                 const int src = __builtin_ctzll(maybe);
                 maybe &= maybe - 1;
-                PHX_COUNT(4, 1);
                 const unsigned dk = (unsigned)__builtin_amdgcn_readlane((int)my_key, src);
                 if (top_n < k || dk < far_key) { // :165
                     const bool evicts = top_n == k;
@@ -1482,7 +1684,6 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                     }
                 } else if (grp_cnt > 0 && dk == far_key) tie = true; // (b): turned away by equality
             }
-            PHY(11);
         }
         PH(5);
     }
@@ -1493,19 +1694,344 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     }
     // ToArray() for the callers: with distinct distances any order-insensitive consumer (OrderBy,
     // Span.Sort) sees the same thing; ascending order is also what they would produce
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
         const int p = lane + 64 * t;
         if (p < top_n) { L.top[p].id = T.id[t] & kIdMask; L.top[p].dist = key2f(T.key[t]); }
     }
-    __syncthreads();
+    wave_sync();
     top_n_out = top_n;
     if (T.any_flagged(top_n, lane, kDoubt) && (doubt_hard || T.first_flagged(top_n, lane, kDoubt) < min(top_n, ordered_prefix)))
         tie = true;                                                      // (i) left unresolved
     // (iii): the SET is the reference's, only its order among equal distances is open.  A caller that can tell
     // whether that order shows in what it makes of the list asks for this case separately (insert_job).
     const bool order_tie = T.adjacent_equal(min(top_n, ordered_prefix), lane);
+    if (order_tie_out) *order_tie_out = order_tie && !tie;
+    else if (order_tie) tie = true;
+    tie_out = tie;
+    return !unsafe && !hash_full;
+}
+
+// ---- SearchLayer on an UNSORTED pool in registers (the latency variants' logic wave) -----------------------------
+// traverse_sorted keeps the beam as one ascending list, and every insertion ranks the newcomers against all of it: a few
+// hundred instructions per expansion, which a full chip hides behind other waves' memory traffic and a lone wave pays in
+// full (phase clocks of B = 1 inserts, two-wave form: 7 500 of an expansion's 8 500 clocks were the list's upkeep).  But
+// nothing SearchLayer does needs an order: it removes the closest open candidate (:146), replaces the farthest result
+// when a closer one arrives (:165-178) and asks for the farthest distance -- a minimum and a maximum.  So the logic wave
+// of the latency variants keeps the k results in register slots in no particular order (slot s in lane s mod 64 of
+// register set s / 64; bit 31 of the id = expanded, bit 30 = doubtful, as in SortedTop) and runs the reference's own
+// loop on them: pop = wave-wide minimum over the open slots (four DPP steps inside the rows of 16 lanes, four readlanes),
+// push = the slot of the farthest entry takes the newcomer, then a wave-wide maximum; the list is sorted ONCE, when the
+// search is over (ranks by counting through LDS), and handed on ascending like the sorted list's.
+// Equal distances: the rules of traverse_sorted, stated on keys instead of positions.  (i) the farthest result leaves
+// while another entry has its distance (the maximum does not change): the survivors of that distance become doubtful
+// (hard unless the one that left and all of them were expanded); (ii) the closest open candidate has an open twin: a
+// group window opens (members counted by key; closes at the first pop beyond the key with all members still present);
+// (a), (b), (d) inside a window and (c) at its end as there; (iii) is read off the sorted output.  Which of several
+// equal entries a minimum or maximum picks differs from the sorted list (lowest slot here, first position there) -- in
+// exactly the situations these rules either prove immaterial or hand to the exact two-heap traversal.
+// v_writelane_b32: a uniform value into ONE lane of a register.  (No builtin reaches it.  One scalar register per VALU
+// instruction on this ISA: the lane select goes through M0, as the compiler's own lowering of the intrinsic does.)
+__device__ __forceinline__ int lane_write(int value, int lane_sel, int old)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(value), "s"(lane_sel) : "m0");
+    return old;
+}
+template <int NS>
+struct PoolTop {
+    unsigned key[NS];  // unused slots: 0 (no distance has that key, and it never is the maximum)
+    unsigned okey[NS]; // the key while the entry is open, 0xffffffff once it is expanded (and in unused slots): what pops look at
+    int id[NS];        // unused slots: expanded bit set
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) { key[t] = 0u; okey[t] = 0xffffffffu; id[t] = (int)0x80000000; }
+    }
+    // slot = 64 t + lane, uniform: one v_readlane / v_writelane per register touched
+    __device__ __forceinline__ int id_at(int slot) const
+    {
+        const int l = slot & 63;
+        int v = 0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            if ((slot >> 6) == t) v = __builtin_amdgcn_readlane(id[t], l);
+        return v;
+    }
+    __device__ __forceinline__ void put(int slot, unsigned k0, int i0) // a new, open entry
+    {
+        const int l = slot & 63;
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            if ((slot >> 6) == t) {
+                key[t] = (unsigned)lane_write((int)k0, l, (int)key[t]);
+                okey[t] = (unsigned)lane_write((int)k0, l, (int)okey[t]);
+                id[t] = lane_write(i0, l, id[t]);
+            }
+    }
+    __device__ __forceinline__ void mark_expanded(int slot, int idword) // idword: the entry's id word as it reads now
+    {
+        const int l = slot & 63;
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            if ((slot >> 6) == t) {
+                okey[t] = (unsigned)lane_write(-1, l, (int)okey[t]);
+                id[t] = lane_write(idword | (int)0x80000000, l, id[t]);
+            }
+    }
+    // where a key sits: the lowest slot holding it (-1: nowhere) and how many slots do
+    template <bool OPEN>
+    __device__ __forceinline__ void locate(unsigned k0, int &slot, int &count) const
+    {
+        slot = -1; count = 0;
+#pragma unroll
+        for (int t = NS - 1; t >= 0; --t) {
+            const unsigned long long bm = __ballot((OPEN ? okey[t] : key[t]) == k0);
+            count += (int)__popcll(bm);
+            if (bm) slot = 64 * t + (int)__builtin_ctzll(bm);
+        }
+    }
+    // the closest open entry: its key (0xffffffff: none), slot (-1), id word, and how many open entries share the key
+    __device__ __forceinline__ void min_open(unsigned &mk, int &slot, int &eid, int &nsame) const
+    {
+        unsigned v = okey[0];
+#pragma unroll
+        for (int t = 1; t < NS; ++t) v = min(v, okey[t]);
+        mk = wave_min_u32(v);
+        slot = -1; eid = 0; nsame = 0;
+        if (mk == 0xffffffffu) return;
+        locate<true>(mk, slot, nsame);
+        eid = id_at(slot);
+    }
+    __device__ __forceinline__ unsigned max_key() const // the farthest entry's key
+    {
+        unsigned v = key[0];
+#pragma unroll
+        for (int t = 1; t < NS; ++t) v = max(v, key[t]);
+        return wave_max_u32(v);
+    }
+    __device__ __forceinline__ int count_key(unsigned k0) const // entries of that key (uniform)
+    {
+        int c = 0;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) c += (int)__popcll(__ballot(key[t] == k0));
+        return c;
+    }
+    __device__ __forceinline__ void mark_key(unsigned k0, int bit)
+    {
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            if (key[t] == k0) id[t] |= bit;
+    }
+    __device__ __forceinline__ bool any_open_key(unsigned k0) const
+    {
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) m |= __ballot(okey[t] == k0);
+        return m != 0ull;
+    }
+};
+
+// The contract of traverse_sorted (same arguments, same results: L.top[0..top_n) ascending, tie / order_tie / window,
+// read log, evaluation count), for the logic wave of a latency variant: expansions are served by the memory wave
+// through `port` (TeamMail).
+template <int METRIC, int NS, bool HASHED>
+__device__ __forceinline__ bool traverse_pool(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
+                                              const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet<HASHED> &V,
+                                              const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals,
+                                              ReadLog &RL, bool *order_tie_out, bool *window_out, TeamPort *port)
+{
+    PH_DECL();
+    int best;
+    float cur;
+    descend<METRIC, true>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals, RL);
+    // ---- SearchLayer (GraphNavigator.cs:123-189) ----
+    const int layer = jb.search_layer;
+    RL.layer(layer, lane);
+    constexpr int kDoubt = 0x40000000, kIdMask = 0x3fffffff;
+    PoolTop<NS> T;
+    T.init();
+    int top_n = 0;
+    bool unsafe = key_unsafe(cur); // NaN / -0 (see f2key)
+    bool tie = false, hash_full = false;
+    T.put(0, f2key(cur), best);                                         // :134, :138
+    top_n = 1;
+    if (lane == 0) (void)V.first_visit(best);                           // :140
+    __builtin_amdgcn_s_waitcnt(0); // (the memory wave's marks follow: this one has landed)
+    V.seen += 1;
+    unsigned far_key = f2key(cur);                                      // farthestResultDist :135
+    const bool ids_matter_everywhere = order_tie_out != nullptr; // an insert's heuristic reads the whole list; a search its first entries
+    bool doubt_hard = false;
+    unsigned grp_key = 0u; // the group window of (ii): its distance and its members (0: no window open)
+    int grp_cnt = 0;
+    int early_id = -1;     // the node whose expansion was requested before its pop (-1: none) ...
+    int early_pos = 0, early_nsame = 0; // ... the slot it sits in, and how many open entries share its key
+    unsigned early_key = 0u;
+    PH(0);
+    while (!unsafe && !tie) {
+        unsigned ck;
+        int pos, cid, nsame;
+        if (early_id >= 0) {
+            // the pop was foreseen (below): its slot, key and twins are known, its id word is re-read (a doubt may have been
+            // marked since), and the memory wave has been on its expansion since before the last insertions
+            pos = early_pos; ck = early_key; nsame = early_nsame;
+            cid = T.id_at(pos);
+            if ((cid & kIdMask) != early_id || cid < 0) { tie = true; break; } // (cannot happen: the exact traversal decides)
+            early_id = -1;
+        } else {
+            T.min_open(ck, pos, cid, nsame);                             // :146 closest candidate; none left <=> :147-150 / empty
+            if (pos < 0) break;
+            port->post(cid & kIdMask, layer, lane, top_n >= k ? far_key : 0xffffffffu);
+        }
+        if (cid & kDoubt) { tie = true; break; } // the reference may be expanding its twin instead
+        if (grp_cnt > 0 && ck > grp_key) { // the group window closes: (c) every member still listed?
+            if (T.count_key(grp_key) != grp_cnt) { tie = true; break; }
+            grp_cnt = 0;
+            if (window_out) *window_out = true;
+        }
+        T.mark_expanded(pos, cid);
+        RL.put(cid & kIdMask, lane, top_n >= k && grp_cnt == 0 ? far_key : 0xffffffffu);
+        // what would be popped next if this expansion brought nothing closer; (ii): an open twin of the popped candidate
+        unsigned nxt_key;
+        int npos, nid, nn;
+        T.min_open(nxt_key, npos, nid, nn);
+        const int nxt_id = npos >= 0 ? (nid & kIdMask) : -1;
+        if (nsame > 1) {
+            if (grp_cnt == 0) { grp_key = ck; grp_cnt = T.count_key(ck); }
+            else if (ck != grp_key) tie = true; // (d)
+        }
+        if (lane == 0) port->m->hint_node = nxt_id; // (a list for the memory wave to prefetch: stale or missing, nothing breaks)
+        PH(1);
+        port->wait(); // ids, keys and masks of this node's neighbours
+        PH(4);
+        const TeamMail *mail = port->m;
+        // the answer: its header in two 16-byte reads, ids and keys one per lane -- all four requested before anything is looked at
+        const int4 h0 = *reinterpret_cast<const int4 *>(&mail->rsp_seq);
+        const uint4 h1 = *reinterpret_cast<const uint4 *>(&mail->fresh);
+        const int my_id = mail->ids[lane];
+        const unsigned my_key = __float_as_uint(mail->dist[lane]);
+        const int nw = __builtin_amdgcn_readfirstlane(h0.y);
+        const unsigned bk0 = (unsigned)__builtin_amdgcn_readfirstlane(h0.z);
+        const int bl0 = __builtin_amdgcn_readfirstlane(h0.w);
+        const unsigned long long fresh = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h1.y) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)h1.x);
+        const unsigned long long passm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h1.w) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)h1.z);
+        if ((nw & 0xffff) > 64) { hash_full = true; break; }
+        const int m = (int)__popcll(fresh);
+        PH_COUNT(7, 1);
+        V.seen += m;
+        if (V.crowded()) { hash_full = true; break; }
+        if (m == 0) {
+            if (grp_cnt == 0 && !tie && nxt_id >= 0) {
+                early_id = nxt_id; early_pos = npos; early_key = nxt_key; early_nsame = nn;
+                port->post(nxt_id, layer, lane, top_n >= k ? far_key : 0xffffffffu);
+            }
+            continue;
+        }
+        evals += (unsigned long long)m;
+        if (nw & 0x10000) { unsafe = true; break; }
+        if (grp_cnt > 0) { // (a), (b)
+            const bool valid = ((fresh >> lane) & 1ull) != 0ull;
+            if (__ballot(valid && my_key == grp_key) || (top_n >= k && __ballot(valid && my_key == far_key))) { tie = true; break; }
+        }
+        // the push loop (:165-178) in adjacency order.  `pass` was tested against the bound sent with the request, which the
+        // farthest key has not exceeded since: every neighbour the test lets through is in it, and the test is made again,
+        // against the key as it stands, when its turn comes
+        unsigned long long maybe = top_n < k ? fresh : passm;
+        PHX_COUNT(5, __popcll(maybe));
+        // What the next pop returns is known before the insertions: the closest open entry, or a neighbour of this expansion
+        // that is closer.  The memory wave is asked for it NOW, and the insertions run under its round trip.  Not foreseen
+        // (the request then follows the pop): anything among equal keys -- a group window, the best neighbour tied with
+        // another one or with the closest open entry.
+        int want_lane = -1; // the lane of the neighbour foreseen as the next pop: its slot is noted when it goes in
+        if (grp_cnt == 0 && !tie) {
+            const bool cand = maybe != 0ull && (top_n < k || bk0 < far_key); // the closest neighbour passes the test as it stands (then it is the closest of those that do)
+            if (cand && bk0 < nxt_key) {
+                if (bl0 >= 0) { want_lane = bl0; early_id = __builtin_amdgcn_readlane(my_id, bl0); early_key = bk0; early_nsame = 1; }
+            } else if (nxt_id >= 0 && (!cand || bk0 > nxt_key)) { early_id = nxt_id; early_pos = npos; early_key = nxt_key; early_nsame = nn; }
+            if (early_id >= 0) port->post(early_id, layer, lane, top_n >= k ? far_key : 0xffffffffu);
+        }
+        PHY(9);
+        while (maybe) {
+            const int src = (int)__builtin_ctzll(maybe);
+            maybe &= maybe - 1;
+            const unsigned dk = (unsigned)__builtin_amdgcn_readlane((int)my_key, src);
+            const int did = __builtin_amdgcn_readlane(my_id, src);
+            if (top_n < k) {                                             // :165, :168-174
+                T.put(top_n, dk, did);
+                if (src == want_lane) early_pos = top_n;
+                ++top_n;
+                if (top_n == k) far_key = T.max_key();                   // :176-177
+            } else if (dk < far_key) {
+                int slot, twins;
+                T.template locate<false>(far_key, slot, twins);          // the farthest result leaves (:171-174)
+                if (twins == 1) {
+                    T.put(slot, dk, did);
+                    far_key = T.max_key();                               // :176-177: a farthest key of its own
+                } else { // (i): one of several equally far results is dropped -- the key stays; (b)
+                    const int evicted = T.id_at(slot);
+                    T.put(slot, dk, did);
+                    const bool hard = ids_matter_everywhere || evicted >= 0 || T.any_open_key(far_key);
+                    doubt_hard |= hard;
+                    T.mark_key(far_key, kDoubt);
+                    if (grp_cnt > 0 && hard) tie = true;
+                }
+                if (src == want_lane) early_pos = slot;
+            } else if (grp_cnt > 0 && dk == far_key) tie = true; // (b): turned away by equality
+        }
+        PHY(11);
+        PH(5);
+    }
+    PH_FLUSH();
+    if (port->pending()) port->wait(); // a request posted ahead of a pop that never came: let it finish (its marks die with the visited set)
+    if (grp_cnt > 0 && !tie && !unsafe && !hash_full) { // (c) at the end of the search
+        if (T.count_key(grp_key) != grp_cnt) tie = true;
+        else if (window_out) *window_out = true;
+    }
+    // ToArray() for the callers, ascending: rank every entry by counting -- (key, doubtful first, slot) -- through LDS
+    uint2 *raw = reinterpret_cast<uint2 *>(L.top);
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int sl = lane + 64 * t;
+        if (sl < top_n) raw[sl] = make_uint2((unsigned)T.id[t], T.key[t]);
+    }
+    wave_sync();
+    int rank[NS];
+    unsigned long long mine[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        rank[t] = 0;
+        mine[t] = ((unsigned long long)T.key[t] << 32) | ((T.id[t] & kDoubt) ? 0ull : 0x10000ull) | (unsigned long long)(lane + 64 * t);
+    }
+    for (int j = 0; j < top_n; ++j) {
+        const uint2 e = raw[j];
+        const unsigned long long other = ((unsigned long long)e.y << 32) | (((int)e.x & kDoubt) ? 0ull : 0x10000ull) | (unsigned long long)j;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) rank[t] += other < mine[t] ? 1 : 0;
+    }
+    wave_sync();
+    unsigned first_doubt = 0xffffffffu;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int sl = lane + 64 * t;
+        if (sl < top_n) {
+            L.top[rank[t]].id = T.id[t] & kIdMask;
+            L.top[rank[t]].dist = key2f(T.key[t]);
+            if (T.id[t] & kDoubt) first_doubt = min(first_doubt, (unsigned)rank[t]);
+        }
+    }
+    wave_sync();
+    top_n_out = top_n;
+    first_doubt = wave_min_u32(first_doubt);
+    if (first_doubt != 0xffffffffu && (doubt_hard || (int)first_doubt < min(top_n, ordered_prefix))) tie = true; // (i) left unresolved
+    // (iii): equal distances next to each other in what the caller consumes in order
+    bool eq = false;
+    const int upto = min(top_n, ordered_prefix);
+    for (int p0 = 0; p0 < upto; p0 += 64) {
+        const int pp = p0 + lane;
+        if (pp >= 1 && pp < upto) eq = eq || __float_as_uint(L.top[pp].dist) == __float_as_uint(L.top[pp - 1].dist);
+    }
+    const bool order_tie = __ballot(eq) != 0ull;
     if (order_tie_out) *order_tie_out = order_tie && !tie;
     else if (order_tie) tie = true;
     tie_out = tie;
@@ -1528,11 +2054,11 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
     const float *qs = L.qs;
     // ---- FindEntryPoint / FindEntryAtLayer (GraphNavigator.cs:27-82) ----
     int best = jb.entry;
-    __syncthreads();
+    wave_sync();
     if (lane == 0) nbuf[0] = best;
-    __syncthreads();
+    wave_sync();
     measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, 1, lane);
-    __syncthreads();
+    wave_sync();
     float cur = dbuf[0]; // :57
     evals += 1;
     for (int layer = jb.entry_layer; layer > jb.search_layer; --layer) {
@@ -1543,11 +2069,11 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
             const int *l = G.list(best, layer);
             const int n = l[0];
             RL.put(best, lane);
-            __syncthreads();
+            wave_sync();
             for (int i = lane; i < n; i += 64) nbuf[i] = l[1 + i]; // :65 span taken once per pass
-            __syncthreads();
+            wave_sync();
             if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane);
-            __syncthreads();
+            wave_sync();
             evals += (unsigned long long)n;
             for (int i = 0; i < n; ++i) { // :67-78
                 float d = dbuf[i];
@@ -1605,7 +2131,7 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
             if (lane + 64 < n) nb_b = l[65 + lane];
         }
         int m = 0;
-        __syncthreads();
+        wave_sync();
         bool have = false; // overlapped form: this lane holds an unvisited neighbour, its distance and id
         float lane_d = 0.0f;
         int lane_id = 0;
@@ -1616,7 +2142,7 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
             // shadow) or in launches that do not fill the chip; the rows of visited neighbours are bandwidth nobody misses.
             const bool in = lane < n;
             if (in) nbuf[lane] = nb_a;
-            __syncthreads();
+            wave_sync();
             unsigned old = 0u;
             const unsigned bit = 1u << (nb_a & 31);
             unsigned hpos = 0u;
@@ -1632,7 +2158,7 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
                 pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
             }
             if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
-            __syncthreads();
+            wave_sync();
             if constexpr (HASHED) {
                 have = in && (int)old == -1;
                 if (in && (int)old != -1 && (int)old != nb_a) { // slot taken by another id: probe on (VisitedSet::first_visit)
@@ -1669,12 +2195,12 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
             pre_a = lane < lstride ? pl[lane] : 0;
             pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
         }
-        __syncthreads();
+        wave_sync();
         if (m == 0) continue;
         V.seen += m;
         if (V.crowded()) { hash_full = true; break; } // the id table is filling up: host traversal
         measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, m, lane); // :163
-        __syncthreads();
+        wave_sync();
         evals += (unsigned long long)m;
         }
         // Replay of the push loop (:165-178) in adjacency order.  farthest never grows once the
@@ -1705,9 +2231,9 @@ __device__ __forceinline__ bool traverse(const float *__restrict__ rows, const d
         }
     }
     // back to float distances for the callers (ToArray(): heap order, BinaryHeap.cs:41-44)
-    __syncthreads();
+    wave_sync();
     for (int i = lane; i < top_n; i += 64) L.top[i].dist = key2f(__float_as_uint(L.top[i].dist));
-    __syncthreads();
+    wave_sync();
     top_n_out = top_n;
     return !overflow && !hash_full;
 }
@@ -1859,10 +2385,10 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                                                          float *gscratch = nullptr, size_t gscratch_bytes = 0, bool mfma_ok = false)
 {
     int *acc = L.acc;
-    __syncthreads();
+    wave_sync();
     if (n < max_edges) { // :13-18 input (heap) order, unsorted
         for (int i = lane; i < n; i += 64) acc[i] = cands[i].id;
-        __syncthreads();
+        wave_sync();
         return n;
     }
     if (!presorted) { // :22 (a sorted-list traversal hands them over in order)
@@ -1880,14 +2406,14 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                 odd |= lane < n && t != lane && kt == my_key;
             }
             if (__ballot(odd) == 0ull) {
-                __syncthreads();
+                wave_sync();
                 if (lane < n) cands[rank] = mine;
                 ranked = true;
             }
         }
         if (!ranked) dev_dotnet_sort(cands, n, L.stk); // equal / NaN / -0 distances: the BCL introsort decides
     }
-    __syncthreads();
+    wave_sync();
     int rc = 0;
     constexpr int kPre = 4; // floats per lane: rows up to 256 floats; longer rows (bandwidth-bound anyway) are staged on demand
     const bool prefetch = dim <= 64 * kPre;
@@ -1915,21 +2441,21 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
             // the exact test of one candidate against everything accepted so far (Heuristic.cs:31-35)
             auto exact_rejects = [&](const ND c) -> bool {
                 const float *crow = rows + (size_t)c.id * dim;
-                __syncthreads();
+                wave_sync();
                 for (int e = lane; e < dim; e += 64) qbuf[e] = crow[e];
                 double sbc = 0.0;
                 if (METRIC == M_COS) sbc = row_sn[c.id];
-                __syncthreads();
+                wave_sync();
                 bool ok = true;
                 const int chunk = dim >= 512 ? 16 : 32;
                 for (int a0 = 0; a0 < rc && ok; a0 += chunk) {
                     const int an = min(chunk, rc - a0);
                     measure_all<METRIC>(rows, row_sn, dim, qbuf, sbc, acc + a0, L.dbuf, an, lane);
-                    __syncthreads();
+                    wave_sync();
                     evals += (unsigned long long)an;
                     const float dj = lane < an ? L.dbuf[lane] : 0.0f;
                     ok = __ballot(lane < an && dj < c.dist) == 0ull;
-                    __syncthreads();
+                    wave_sync();
                 }
                 return !ok;
             };
@@ -1970,7 +2496,7 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                     for (int j = 0; j < bsz && rc < max_edges; ++j) {
                         const ND c = cands[b0 + j];
                         if (rc == 0 || !exact_rejects(c)) { if (lane == 0) acc[rc] = c.id; rc++; }
-                        __syncthreads();
+                        wave_sync();
                     }
                     continue;
                 }
@@ -2020,7 +2546,7 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                     }
                 }
                 evals += (unsigned long long)(rc0 + bsz); // rows streamed by the tiles of this block (each once per tile)
-                __syncthreads(); // acc / snacc written by lane 0 are read by the next block's tiles
+                wave_sync(); // acc / snacc written by lane 0 are read by the next block's tiles
             }
             return rc;
         }
@@ -2048,7 +2574,7 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                     for (int e = lane; e < dim; e += 64) dst[e] = crow[e];
                     if (METRIC == M_COS && lane == 0) sbq[t] = row_sn[cands[t].id];
                 }
-                __syncthreads();
+                wave_sync();
             }
             for (int g0 = 0; g0 < n && rc < max_edges; g0 += 4) { // :23, four at a time
                 const int gsz = min(4, n - g0);
@@ -2084,7 +2610,7 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                     const float v = group_metric<METRIC>(gq(live ? pu : 0), gq(live ? pt : 0), dim, j, sa, sb);
                     if (live && j == 0) P[pu * 4 + pt] = v;
                 }
-                __syncthreads();
+                wave_sync();
                 unsigned in_group = 0u; // bit u: member u accepted
                 for (int t = 0; t < gsz && rc < max_edges; ++t) {
                     const ND c = cands[g0 + t];
@@ -2098,7 +2624,7 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                         if ((in_group >> u) & 1u) rej = rej || P[u * 4 + t] < c.dist;
                     if (!rej) { if (lane == 0) acc[rc] = c.id; rc++; in_group |= 1u << t; }
                 }
-                __syncthreads();
+                wave_sync();
 #define HNSW_PRE_STORE(T, PRE)                                                                         \
                 if (T < nsz) {                                                                         \
                     float *dst = gq(T);                                                                \
@@ -2108,7 +2634,7 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                 }
                 HNSW_PRE_STORE(0, pre0) HNSW_PRE_STORE(1, pre1) HNSW_PRE_STORE(2, pre2) HNSW_PRE_STORE(3, pre3)
 #undef HNSW_PRE_STORE
-                __syncthreads();
+                wave_sync();
             }
             return rc;
         }
@@ -2136,7 +2662,7 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
                 const float *crow = rows + (size_t)c.id * dim;
                 for (int t = lane; t < dim; t += 64) buf[cur][t] = crow[t];
                 if (METRIC == M_COS) sbc = row_sn[c.id];
-                __syncthreads();
+                wave_sync();
             }
             // accepted ids are measured in chunks, in acceptance order, stopping at the first chunk
             // that rejects (the reference breaks at the first hit, :34; later pairs cannot change the
@@ -2145,11 +2671,11 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
             for (int a0 = 0; a0 < rc && ok; a0 += chunk) {
                 const int an = min(chunk, rc - a0);
                 measure_all<METRIC>(rows, row_sn, dim, buf[cur], sbc, acc + a0, L.dbuf, an, lane); // distanceFnc(s.Id, candidateId) :34
-                __syncthreads();
+                wave_sync();
                 evals += (unsigned long long)an;
                 const float dj = lane < an ? L.dbuf[lane] : 0.0f;
                 ok = __ballot(lane < an && dj < c.dist) == 0ull;
-                __syncthreads();
+                wave_sync();
             }
         }
         if (ok) { if (lane == 0) acc[rc] = c.id; rc++; }
@@ -2160,7 +2686,7 @@ __device__ __forceinline__ int relative_neighbor_pruning(const float *__restrict
             cur ^= 1;
             sbc = sbn;
         }
-        __syncthreads();
+        wave_sync();
     }
     return rc;
 }
@@ -2182,10 +2708,10 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
                     int spill_cap, VisitedSet<HASHED> &V, int k_out, int *__restrict__ out_ids,
                     float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
                     unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap,
-                    int *__restrict__ job_word = nullptr, bool shadow = false)
+                    int *__restrict__ job_word = nullptr, bool shadow = false, TeamPort *port = nullptr)
 {
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const SearchJob jb = jobs[job];
     const GraphView G{adj0, stride0, upper, pool, strideU};
 
@@ -2199,6 +2725,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         if (METRIC == M_COS) sb = row_sn[~jb.qref];
     }
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+    if constexpr (LAT) { if (lane == 0) port->m->sb = sb; } // (the memory wave reads both after the first request's release)
     unsigned long long evals = 0;
     int top_n = 0;
     bool repeated = shadow;
@@ -2215,7 +2742,9 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         bool tie = false;
         // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
         bool window = false;
-        const bool ok1 = traverse_sorted<METRIC, NS, HASHED, LAT>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL, nullptr, &window);
+        bool ok1;
+        if constexpr (LAT) ok1 = traverse_pool<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, RL, nullptr, &window, port);
+        else ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL, nullptr, &window);
         if (!(ok1 && tie)) {
             if (!claim_answer()) return;
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
@@ -2250,7 +2779,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
                                              shadow ? job_word : nullptr, &aborted, LAT || (overlap & 1) != 0 || repeated);
     if (aborted || !claim_answer()) return;
     if (jb.aux == -2) { // SearchLayer's own return value: topCandidates.ToArray(), the heap's array (BinaryHeap.cs:41-44)
-        __syncthreads();
+        wave_sync();
         for (int r = lane; r < k_out; r += 64) {
             const bool have = ok && r < top_n;
             out_ids[(size_t)job * k_out + r] = have ? L.top[r].id : -1;
@@ -2267,7 +2796,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
     // array (ToArray(), BinaryHeap.cs:41-44) and only the first k_out survive -- so select the
     // k_out smallest (float.CompareTo order: NaN first, -0 == +0) with ties broken by array index:
     // exactly the stable sort's prefix.  Key = (order-preserving bits << 32) | index, wave min.
-    __syncthreads();
+    wave_sync();
     unsigned long long used = 0; // bit t: entry lane + 64*t already emitted
     for (int r = 0; r < k_out; ++r) {
         unsigned long long best = ~0ull;
@@ -2313,7 +2842,7 @@ template <int METRIC, int NS, bool HASHED, bool LAT = false>
 // float rows: 168 VGPRs, three waves per SIMD; int8 records keep 16 registers of rows in flight, not 64: five waves.
 // LAT (launches that do not fill the chip): no occupancy to buy -- every spilled register is a memory round trip a lone wave
 // waits out in full -- so two waves per SIMD at most (256 VGPRs), one with eight register sets
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(LAT ? (NS <= 4 ? 2 : 1) : METRIC == M_I8 ? (NS <= 2 ? 5 : 4) : (NS <= 4 ? 3 : 2)))))
+__global__ void __launch_bounds__(LAT ? 128 : 64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(LAT ? (NS <= 4 ? 2 : 1) : METRIC == M_I8 ? (NS <= 2 ? 5 : 4) : (NS <= 4 ? 3 : 2)))))
 graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
@@ -2324,10 +2853,26 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
                     const int *__restrict__ ready)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
                  vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, (unsigned)(vis_tab_cap - 1), 0, vis_tab_cap / 4 * 3};
     ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
+
+    TeamPort port{nullptr, 0, 0};
+    if constexpr (LAT) {
+        // two waves per block (see TeamMail): wave 1 serves the expansions, wave 0 is the traversal.  The mailbox follows
+        // the traversal's LDS; its sequence words are zeroed before the roles part (the one barrier both waves meet at).
+        TeamMail *mail = reinterpret_cast<TeamMail *>(smem + ((search_lds_bytes(k, cand_cap, dim, false, nbcap) + 15) & ~(size_t)15));
+        if (threadIdx.x == 0) { mail->req_seq = 0; mail->rsp_seq = 0; mail->hint_node = -1; }
+        __syncthreads();
+        if (threadIdx.x >= 64) {
+            const GraphView G{adj0, stride0, upper, pool, strideU};
+            const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
+            memory_wave<METRIC, HASHED>(rows, row_sn, dim, G, V, L.qs, mail, lane);
+            return;
+        }
+        port.m = mail;
+    }
     // `ready` (hnsw_knn_query on host buffers): the launch started when the first rows of the query set had landed; the
     // rest is still arriving on the copy engine, and *ready (a word in host memory the uploading thread advances) says how
     // many rows are there.  Jobs are taken in order, so a wave almost never has to wait; when it does it sleeps and
@@ -2405,9 +2950,11 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
         }
         search_job<METRIC, NS, HASHED, LAT>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
                                V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job, overlap, shadows ? job_words + job : nullptr,
-                               shadow);
+                               shadow, &port);
         V.clear(lane);
     }
+
+    if constexpr (LAT) port.post(-1, 0, lane); // the memory wave leaves
 }
 
 #ifdef HNSW_HOST_TU // few variants and launched from one place: defined only in the unit that launches it
@@ -2455,7 +3002,7 @@ graph_range_kernel(const float *__restrict__ rows, const double *__restrict__ ro
         const float *q = queries + (size_t)jb.qref * dim;
         double sb = 0.0;
         if (METRIC == M_COS) sb = q_sn[jb.qref];
-        __syncthreads();
+        wave_sync();
         for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
         unsigned long long evals = 0;
         int best;
@@ -2498,7 +3045,7 @@ graph_range_kernel(const float *__restrict__ rows, const double *__restrict__ ro
 #pragma unroll
             for (int w = 0; w < kRangeFan; ++w) fr[w] = lane < n[w] && V.first_visit(nb[w]); // :297 / :318 (a node two lists share is fresh once)
             int m = 0;
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int w = 0; w < kRangeFan; ++w) {
                 const unsigned long long mask = __ballot(fr[w]);
@@ -2516,12 +3063,12 @@ graph_range_kernel(const float *__restrict__ rows, const double *__restrict__ ro
                     m += __popcll(mk);
                 }
             }
-            __syncthreads();
+            wave_sync();
             if (m == 0) continue;
             V.seen += m;
             if (V.crowded()) { ok = false; break; }
             measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, nbuf, dbuf, m, lane); // :299
-            __syncthreads();
+            wave_sync();
             evals += (unsigned long long)m;
             for (int base = 0; base < m && ok; base += 64) {
                 const int i = base + lane;
@@ -2576,10 +3123,10 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                            int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
                            unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap_and_flags,
-                           int *__restrict__ read_log, int read_log_cap)
+                           int *__restrict__ read_log, int read_log_cap, TeamPort *port = nullptr)
 {
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int overlap = overlap_and_flags & 1; // bit 0: overlapped form (bit 1: the MFMA-prefiltered heuristic is allowed)
     SearchJob jb = jobs[job];
     const GraphView G{adj0, stride0, upper, pool, strideU};
@@ -2588,6 +3135,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     double sb = 0.0;
     if (METRIC == M_COS) sb = row_sn[item];
     for (int i = lane; i < dim; i += 64) L.qs[i] = q[i];
+    if constexpr (LAT) { if (lane == 0) port->m->sb = sb; }
     unsigned long long evals = 0;
     bool ok = true, repeat = false;
     // exact-window Add: record [n, entries...] of this job's read log (n beyond the capacity = overflow)
@@ -2605,7 +3153,8 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         const unsigned long long ev0 = evals;
         if constexpr (NS > 0) {
             bool tie = false;
-            ok = traverse_sorted<METRIC, NS, HASHED, LAT>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap, RL, &order_tie); // Span.Sort consumes all
+            if constexpr (LAT) ok = traverse_pool<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, RL, &order_tie, nullptr, port);
+            else ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap, RL, &order_tie); // Span.Sort consumes all
             if (!ok) break;
             // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
             // then returns them in HEAP order, Heuristic.cs:13-18): this layer again, exact traversal
@@ -2647,7 +3196,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
             // distance -- in any order.  So when every member but the last of each group was rejected, the outcome is
             // the reference's whatever its order was (one candidate in seven is accepted on uniform data: most groups
             // are harmless -- 2.1 % of the inserts at C2 used to start over, a third of a percent still do).
-            __syncthreads();
+            wave_sync();
             bool shows = false;
             for (int p0 = 0; p0 < top_n; p0 += 64) {
                 const int pp = p0 + lane;
@@ -2667,7 +3216,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         jb.entry = next_entry;
         jb.entry_layer = layer - 1;
         jb.search_layer = layer - 1;
-        __syncthreads();
+        wave_sync();
     }
     if (lane == 0) {
         out_flag[job] = ok ? (repeat ? 2 : 0) : 1; // 2: informational (a layer was answered by the exact traversal)
@@ -2680,7 +3229,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
 }
 
 template <int METRIC, int NS, bool HASHED, bool LAT = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(LAT ? (NS <= 4 ? 2 : 1) : NS <= 4 ? 3 : 2)))) // up to 256 candidates: 168 VGPRs, three waves per SIMD (LAT: see graph_search_kernel)
+__global__ void __launch_bounds__(LAT ? 128 : 64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(LAT ? (NS <= 4 ? 2 : 1) : NS <= 4 ? 3 : 2)))) // up to 256 candidates: 168 VGPRs, three waves per SIMD (LAT: see graph_search_kernel)
 graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
@@ -2691,10 +3240,26 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
                            const int *__restrict__ order, int *__restrict__ read_log, int read_log_cap)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
                  vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, (unsigned)(vis_tab_cap - 1), 0, vis_tab_cap / 4 * 3};
     ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
+
+    TeamPort port{nullptr, 0, 0};
+    if constexpr (LAT) {
+        // two waves per block (see TeamMail): wave 1 serves the expansions, wave 0 is the traversal.  The mailbox follows
+        // the traversal's LDS; its sequence words are zeroed before the roles part (the one barrier both waves meet at).
+        TeamMail *mail = reinterpret_cast<TeamMail *>(smem + ((search_lds_bytes(k, cand_cap, dim, true, nbcap) + 15) & ~(size_t)15));
+        if (threadIdx.x == 0) { mail->req_seq = 0; mail->rsp_seq = 0; mail->hint_node = -1; }
+        __syncthreads();
+        if (threadIdx.x >= 64) {
+            const GraphView G{adj0, stride0, upper, pool, strideU};
+            const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
+            memory_wave<METRIC, HASHED>(rows, row_sn, dim, G, V, L.qs, mail, lane);
+            return;
+        }
+        port.m = mail;
+    }
     for (;;) { // persistent, see graph_search_kernel
         int job = 0;
         if (lane == 0) job = atomicAdd(job_counter, 1);
@@ -2705,9 +3270,11 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         // order of processing changes nothing else.
         if (order) job = __builtin_amdgcn_readfirstlane(order[job]);
         insert_job<METRIC, NS, HASHED, LAT>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
-                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap, read_log, read_log_cap);
+                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap, read_log, read_log_cap, &port);
         V.clear(lane);
     }
+
+    if constexpr (LAT) port.post(-1, 0, lane); // the memory wave leaves
 }
 
 // Insert, link half, on the HBM mirror.  (a) new nodes' own lists.
@@ -2753,7 +3320,7 @@ graph_relink_kernel(const float *__restrict__ rows, const double *__restrict__ r
     const int last = cnt - 1;
     if (pos >= 0) --cnt;
     for (int i = lane; i < cnt; i += 64) L.nbuf[i] = (i == pos) ? l[1 + last] : l[1 + i]; // :110-120 the existing neighbours
-    __syncthreads();
+    wave_sync();
     int n = cnt;
     bool bad = false;
     for (int base = 0; base < ncand; base += 64) { // :123-129
@@ -2767,7 +3334,7 @@ graph_relink_kernel(const float *__restrict__ rows, const double *__restrict__ r
         if (keep) L.nbuf[n + posn] = c;
         n += (int)__popcll(mask);
     }
-    __syncthreads();
+    wave_sync();
     unsigned long long evals = 0;
     int rc = 0;
     // heap_order: `cands` are SearchLayer's heap array itself (the exact two-heap search), so the candidate array is
@@ -2776,12 +3343,12 @@ graph_relink_kernel(const float *__restrict__ rows, const double *__restrict__ r
     if (!bad && n == 0) rc = 0;
     if (!bad && n > 0) {
         measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, L.nbuf, L.dbuf, n, lane); // Distance(id, affectedNodeId) :118, :128
-        __syncthreads();
+        wave_sync();
         evals += (unsigned long long)n;
         for (int i = lane; i < n; i += 64) L.top[i] = ND{L.nbuf[i], L.dbuf[i]};
-        __syncthreads();
+        wave_sync();
         rc = relative_neighbor_pruning<METRIC>(rows, row_sn, dim, L.top, n, max_edges, L, lane, evals); // sorts L.top
-        __syncthreads();
+        wave_sync();
         bool odd = false; // equal, NaN or -0 distances: Span.Sort's answer depends on the input order
         for (int i = lane; i < n; i += 64) {
             const float d = L.top[i].dist;
@@ -2849,18 +3416,18 @@ __device__ __forceinline__ void link_group(const float *__restrict__ rows, const
     for (int i = lane; i < cnt; i += 64) L.nbuf[i] = l[1 + i];
     int *tested_p = layer == 0 ? tested0 + node : testedU + (upper[node] / strideU + (layer - 1));
     int tested = min(max(*tested_p, 0), cnt); // leading entries that are an ordered, mutually tested heuristic output
-    __syncthreads();
+    wave_sync();
     unsigned long long evals = 0;
     PH_DECL();
     PH(0);
     for (int item = next_item(); item >= 0; item = next_item()) {
         if (lane == 0) L.nbuf[cnt] = item; // :207
         cnt++;
-        __syncthreads();
+        wave_sync();
         PH_COUNT(6, 1);
         if (cnt > max_edges) { // :209
             measure_all<METRIC>(rows, row_sn, dim, L.qs, sb, L.nbuf, L.dbuf, cnt, lane); // Distance(cand, node.Id) :233
-            __syncthreads();
+            wave_sync();
             evals += (unsigned long long)cnt;
             int rc = -1;
             // Shortcut.  The first `tested` entries are the output of an earlier greedy pass over this
@@ -2893,17 +3460,17 @@ __device__ __forceinline__ void link_group(const float *__restrict__ rows, const
                     for (int jn = 0; jn < u; ++jn) {
                         const int xid = L.nbuf[tested + jn];
                         const float *xrow = rows + (size_t)xid * dim;
-                        __syncthreads();
+                        wave_sync();
                         for (int t2 = lane; t2 < dim; t2 += 64) L.qs2[t2] = xrow[t2];
                         double sbx = 0.0;
                         if (METRIC == M_COS) sbx = row_sn[xid];
-                        __syncthreads();
+                        wave_sync();
                         // a single new entry only meets the old ones (one pass of <= 32 rows instead of two)
                         const int mrows = u == 1 ? tested : n;
                         measure_all<METRIC>(rows, row_sn, dim, L.qs2, sbx, L.nbuf, Dm + jn * nbcap, mrows, lane);
                         evals += (unsigned long long)(u == 1 ? mrows : n - 1);
                     }
-                    __syncthreads();
+                    wave_sync();
                     // greedy pass :23-40 in sorted order, on the distances at hand
                     bool acc0 = false, acc1 = false; // entries lane / lane + 64 accepted
                     unsigned new_acc = 0u;           // bit j: new entry j accepted
@@ -2929,7 +3496,7 @@ __device__ __forceinline__ void link_group(const float *__restrict__ rows, const
                             rc++;
                         }
                     }
-                    __syncthreads();
+                    wave_sync();
                 }
             }
             if (rc < 0) {
@@ -2939,7 +3506,7 @@ __device__ __forceinline__ void link_group(const float *__restrict__ rows, const
             for (int i = lane; i < rc; i += 64) L.nbuf[i] = L.acc[i]; // node.OutEdges[layer] = newOut :236
             cnt = rc;
             tested = rc; // the whole list is a greedy output now
-            __syncthreads();
+            wave_sync();
         }
     }
     if (dry_changed) { // dry run (exact-window Add): nothing is written; would the list read differently afterwards?
@@ -2975,13 +3542,13 @@ __device__ __forceinline__ void link_group(const float *__restrict__ rows, const
             code |= (nd > 3 ? 255 : nd) << 8;
         }
         if (lane == 0) { *dry_changed = code; atomicAdd(eval_counter, evals); }
-        __syncthreads();
+        wave_sync();
         return;
     }
     if (lane == 0) { l[0] = cnt; *tested_p = tested; if (out_list) out_list[0] = cnt; }
     for (int i = lane; i < cnt; i += 64) { l[1 + i] = L.nbuf[i]; if (out_list) out_list[1 + i] = L.nbuf[i]; }
     if (lane == 0) atomicAdd(eval_counter, evals);
-    __syncthreads();
+    wave_sync();
 }
 
 // groups prepared by the host: one block per group, items in CSR order
