@@ -39,7 +39,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-PROFILE_ROUND = "r3"
+PROFILE_ROUND = "r4"
+PROFILE_FALLBACK = "r3"  # traffic / ceilings measured last round stay quoted until this round's passes are committed
 
 
 def parse():
@@ -346,8 +347,14 @@ def main():
     # cannot be combined with tracing) and committed under profiles/: quoted only for the very workload they were measured on
     traffic, traffic_add, gather = None, {}, None
     fetched_row_bytes = 128 if a.metric == "sq_euclid_i8" and a.dim <= 120 else st["row_bytes"]
+    def profile_file(stem):
+        for r in (PROFILE_ROUND, PROFILE_FALLBACK):
+            f = ROOT / "profiles" / f"{r}_{stem}"
+            if f.exists():
+                return f
+        return ROOT / "profiles" / f"{PROFILE_ROUND}_{stem}"
     try:
-        pm = json.loads((ROOT / "profiles" / f"{PROFILE_ROUND}_pmc_traffic.json").read_text())
+        pm = json.loads(profile_file("pmc_traffic.json").read_text())
         for c in pm["configs"].values():
             w = c["workload"]
             if a.traversal == "device" and a.data == "uniform" and (w["n"], w["dim"], w["queries_per_gpu_per_step"], w["ef_search"], w["k"], w["max_edges"]) == \
@@ -357,7 +364,7 @@ def main():
     except Exception:
         pass
     try:
-        gc = json.loads((ROOT / "profiles" / f"{PROFILE_ROUND}_gather_ceilings.json").read_text())["rows"]
+        gc = json.loads(profile_file("gather_ceilings.json").read_text())["rows"]
         gather = gc.get(str(fetched_row_bytes))
     except Exception:
         pass
@@ -372,7 +379,7 @@ def main():
     if gather:  # what RANDOM gathers of rows this size reach on this chip (tools/gather_bench, table >> Infinity Cache), in rows fetched
         rows_per_s = t_evals / kernel_s if kernel_s > 0 else 0.0
         roofline["measured_gather_ceiling"] = {"row_bytes_fetched": fetched_row_bytes, "GBps": gather["best_GBps"], "rows_per_s": round(gather["rows_per_s"]),
-                                               "source": f"profiles/{PROFILE_ROUND}_gather_ceilings.json"}
+                                               "source": "profiles/" + profile_file("gather_ceilings.json").name}
         roofline["frac_of_measured_gather"] = round(rows_per_s / gather["rows_per_s"], 4)
     # the Add half: graph_insert_search_kernel (search half + heuristic) and the link half, HIP events during the build
     bs = build_stats
@@ -594,9 +601,14 @@ def main():
                        "recall_on_clustered_data is the same build and query on data that has structure",
         "recall_on_clustered_data": clustered,
         "add_per_sec": round(a.n / build_s, 1), "build_seconds": round(build_s, 3),
-        "add_note": "hnsw_add of the whole set in one call: the deterministic snapshot-batched schedule (DESIGN.md 4) -- one legal outcome "
-                    "of the reference's Parallel.For Add(List), checked bit for bit against the CPU restatement of the same schedule; "
-                    "the reference-exact graph (sequential, and through exact windows) and a bounded-concurrency mode are in add_modes",
+        "add_schedule_reference_defined": False,
+        "add_per_sec_reference_graph": (add_modes or {}).get("exact_window", {}).get("adds_per_sec"),
+        "add_note": "add_per_sec: hnsw_add of the whole set in one call with snapshot batches of up to tens of thousands of items (DESIGN.md 4). "
+                    "That schedule is THIS BUILD'S OWN: a snapshot that large is not an interleaving a T-thread Parallel.For can produce "
+                    "(HNSWIndex.cs:70-78); it is checked bit for bit against the builder's CPU restatement of the same schedule, and tied to the "
+                    "reference only through recall. add_per_sec_reference_graph: the graph the reference DEFINES -- HNSWIndex.Add(item) one item after "
+                    "the other (HNSWIndex.cs:55-65) -- built through exact windows on the same index (add_modes.exact_window; graph hash equal to the "
+                    "CPU restatement's sequential Add); add_modes.sequential is the same graph one call per item, add_modes.bounded a B = host-cores schedule",
         "build_evals": build_stats["evals"] + build_stats["search_evals"],
         "build_launches": build_stats["launches"] + build_stats["search_launches"],
         "replicas_identical": replicas_identical,

@@ -125,6 +125,8 @@ lib.hnsw_mi355x_device_count.restype = ct.c_int
 lib.hnsw_mi355x_device_count.argtypes = [ct.c_void_p]
 lib.hnsw_mi355x_get_stats_at.restype = ct.c_int
 lib.hnsw_mi355x_get_stats_at.argtypes = [ct.c_void_p, ct.c_int, ct.POINTER(Stats)]
+lib.hnsw_mi355x_build_id.restype = ct.c_char_p
+lib.hnsw_mi355x_build_id.argtypes = []
 lib.hnsw_mi355x_exact_window_stats.restype = ct.c_int
 lib.hnsw_mi355x_exact_window_stats.argtypes = [ct.c_void_p, ct.POINTER(ct.c_uint64)]
 

@@ -27,12 +27,36 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+BUILD_ID_TAG = b"HNSW_MI355X_BUILD_ID="
+
+
+def source_id() -> str:
+    """sha256 over everything the library is compiled from: csrc/* and include/*, by name and content, plus the
+    compiler flags.  The same string is compiled into the library (hnsw_mi355x_build_id()), so a binary says which
+    sources it came from -- file times say nothing once a tree has been copied."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(list(CSRC.glob("*")) + list((PKG.parent / "include").glob("*.h")), key=lambda f: f.name)
+    for f in files:
+        if f.is_file():
+            h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def embedded_id(lib: Path = None) -> str:
+    """The build id inside a built library (read from the file: nothing is loaded), '' when it carries none."""
+    lib = lib or LIB
+    try:
+        blob = lib.read_bytes()
+    except OSError:
+        return ""
+    i = blob.find(BUILD_ID_TAG)
+    return blob[i + len(BUILD_ID_TAG):i + len(BUILD_ID_TAG) + 64].decode("ascii", "replace") if i >= 0 else ""
+
+
 def needs_build() -> bool:
-    if not LIB.exists():
-        return True
-    t = LIB.stat().st_mtime
-    deps = list(CSRC.glob("*")) + [PKG.parent / "include" / "hnsw_mi355x.h"]
-    return any(p.stat().st_mtime > t for p in deps)
+    return not LIB.exists() or embedded_id() != source_id()
 
 
 def build(force: bool = False, verbose: bool = False, out: Path = None) -> Path:
@@ -52,9 +76,12 @@ def build(force: bool = False, verbose: bool = False, out: Path = None) -> Path:
         extra = sorted(set(extra) | {"-DHNSW_SINGLE_TU"})
         sources = [s for s in sources if not s.startswith("traverse_")]
 
+    sid = source_id() if out is None and not extra else source_id() + "+variant"
+
     def compile_one(src):
         obj = OBJ / (Path(src).stem + ".o")
-        cmd = [hipcc(), *FLAGS, *extra, "-c", str(CSRC / src), "-o", str(obj)]
+        ident = [f'-DHNSW_MI355X_BUILD_ID_STR="{sid}"'] if src == "exports.cpp" else []  # one unit carries the id
+        cmd = [hipcc(), *FLAGS, *extra, *ident, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -203,6 +203,15 @@ API int hnsw_set_distribution_rate(float dist_rate) // :247 -- crosses the ABI a
 }
 
 // ---- introspection / counters ----
+// Which sources this binary was compiled from: sha256 over csrc/* and include/* (build.py: source_id()), also findable
+// in the file itself behind the tag.  __graft_entry__.build() rebuilds when it differs from the tree's, and the test
+// tier asserts that the library that got loaded is the tree's.
+#ifndef HNSW_MI355X_BUILD_ID_STR
+#define HNSW_MI355X_BUILD_ID_STR "unidentified"
+#endif
+extern "C" __attribute__((visibility("default"), used)) const char hnsw_mi355x_build_id_tag[] = "HNSW_MI355X_BUILD_ID=" HNSW_MI355X_BUILD_ID_STR;
+API const char *hnsw_mi355x_build_id(void) { return hnsw_mi355x_build_id_tag + sizeof("HNSW_MI355X_BUILD_ID=") - 1; }
+
 API int hnsw_mi355x_count(void *h)
 {
     if (!h) return 0;

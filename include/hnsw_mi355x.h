@@ -135,6 +135,9 @@ int hnsw_mi355x_set_device_traversal(int enabled);
  * changed, answers queries [g nq / n, (g + 1) nq / n) and writes that slice of the caller's out arrays.  Same ids and
  * distance bits as one device.  Add / Remove / RangeQuery run on the first context. */
 int hnsw_mi355x_set_devices(int n);
+/* The sha256 (hex) of the sources this binary was compiled from -- csrc and include, by name and content, plus the compiler
+ * flags -- or that string with "+variant" for a diagnostic build.  hnswindex.net_amd/build.py: source_id(). */
+const char *hnsw_mi355x_build_id(void);
 int hnsw_mi355x_device_count(void *handle);
 /* hnswdev_stats of context `context` (0 = the primary). */
 struct hnswdev_stats;

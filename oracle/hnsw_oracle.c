@@ -1305,6 +1305,7 @@ static void retire_item(index_t *ix, int id) /* GraphData.RemoveItem :124-128, A
  *     batch; then the members are unlinked in order with those search results.
  * Disjoint regions make the unlinking steps independent of each other (no step reads a list another one writes),
  * so the outcome is one the reference's locking admits. */
+ORC_API int orc_remove(void *h, const int *ids, int n);
 ORC_API int orc_remove_batched(void *h, const int *ids_in, int n, int bmax)
 {
     index_t *ix = (index_t *)h;

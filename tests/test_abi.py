@@ -42,6 +42,22 @@ def test_library_is_at_the_reference_loader_path(net):
     assert net.LIB_PATH.parts[-4:] == ("artifacts", "native", "linux-x64", "HNSWIndex.Native.so")
 
 
+def test_loaded_library_was_built_from_this_tree(net):
+    """A stale binary (it is git-ignored and travels with the tree) must not pass for the sources beside it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hnsw_build", ROOT / "hnswindex.net_amd" / "build.py")
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    want = b.source_id()
+    assert len(want) == 64
+    got = net.lib.hnsw_mi355x_build_id().decode()
+    if net.LIB_PATH == b.LIB:          # (HNSW_MI355X_LIB may point the bindings at a diagnostic variant)
+        assert got == want, "the loaded library was compiled from other sources than the tree's: run __graft_entry__.build()"
+        assert b.embedded_id() == want and not b.needs_build()
+    else:
+        assert got.endswith("+variant") or got == want
+
+
 def _has_gpu(net):
     return net.lib.hnswdev_device_count() > 0
 
