@@ -236,6 +236,12 @@ def main():
         dist.all_gather_into_tensor(hs, h63)
         replicas_identical = bool((hs == hs[0]).all().item())
 
+    ranks_seen = 1
+    if world > 1:  # every rank must be reachable through the collective backend the step uses (RCCL when backend == "nccl")
+        ones = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, f"{ranks_seen} ranks answered the all-reduce, WORLD_SIZE is {world}"
     nshards = world * ndev_native
     nq_total = a.nq * nshards if a.scaling == "weak" else a.nq
     # R distinct query sets (all distinct from the base vectors): every timed step hands the export fresh host buffers
@@ -244,6 +250,8 @@ def main():
     q_all = q_sets[0]
     lo, hi = dmod.shard_bounds(nq_total, world, rank)
     per_gpu = (hi - lo) // ndev_native
+    if a.scaling == "weak":  # weak scaling keeps the N = 1 (BENCH) workload on every GPU: same index, same queries per GPU and step
+        assert per_gpu == a.nq, f"rank {rank}: {per_gpu} queries per GPU and step, the N = 1 configuration has {a.nq}" 
 
     # THE STEP: the reference's export hnsw_knn_query (HNSWIndexExports.cs:119-149) on host buffers; with several ranks one
     # all-gather of the packed top-k leaves the full result on every GPU and rank 0 copies it to its host -- SURVEY.md 8e
@@ -592,6 +600,8 @@ def main():
                             f"query-shard x{world}, index replicated ({a.build if world > 1 else 'one build'})"),
         },
         "entry_point": "hnsw_knn_query",
+        "collective_backend": (("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None), "rccl_ranks_seen": ranks_seen,
+        "per_gpu_workload_equals_n1": bool(a.scaling == "weak"),
         "resident_queries_per_sec": round(nq_total / dt_resident, 1),
         "resident_note": "the same step with the query set uploaded once before the timed region (hnsw_mi355x_knn_query_resident); "
                          "`value` is the reference's export, PCIe-inclusive",

@@ -39,6 +39,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -646,12 +647,42 @@ bool Device::upload_tail()
     return true;
 }
 
+// Peer access between two devices, asked for once per ordered pair.  hipMemcpyPeerAsync works either way -- without peer
+// access the runtime stages the copy through host memory -- so a refusal is not an error; it is COUNTED, because "replicas
+// are copied device to device over xGMI" is a claim about the machine, not about this code (hnswdev_stats.peer_direct_copies
+// / .peer_staged_copies).  Same device on both sides: a plain device-to-device copy, counted as direct.
+static bool peer_direct(int dst, int src)
+{
+    if (dst == src) return true;
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, bool> known;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = known.find({dst, src});
+    if (it != known.end()) return it->second;
+    int can = 0;
+    bool ok = hipDeviceCanAccessPeer(&can, dst, src) == hipSuccess && can != 0;
+    if (ok) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        ok = hipSetDevice(dst) == hipSuccess;
+        if (ok) {
+            const hipError_t e = hipDeviceEnablePeerAccess(src, 0);
+            ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+            (void)hipGetLastError(); // (already enabled is not an error to keep)
+        }
+        (void)hipSetDevice(cur);
+    }
+    known[{dst, src}] = ok;
+    return ok;
+}
+
 bool Device::clone_from(Device *src, long long pool_len)
 {
     if (!src || src == this || src->dim_ != dim_ || src->metric_ != metric_ || src->pitch_ != pitch_) { set_dev_error("clone_from: contexts differ in shape"); return false; }
     if (pool_len < 0 || pool_len > src->g_pool_cap_) { set_dev_error("clone_from: bad pool length"); return false; }
     if (!src->sync()) return false; // what is copied must have landed
     if (!reserve(src->capacity_)) return false;
+    const bool direct = peer_direct(device_, src->device_);
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     const long long have = std::min(n_rows_hw_, src->n_rows_hw_); // rows never change once uploaded (slot reuse re-clones: see HnswIndex)
@@ -693,6 +724,7 @@ bool Device::clone_from(Device *src, long long pool_len)
     HIP_OK(hipStreamSynchronize(st));
     n_rows_hw_ = src->n_rows_hw_;
     stats_.replica_bytes += (uint64_t)more * pitch_ * sizeof(float) + sizeof(int) * ((uint64_t)n * g_stride0_ + (uint64_t)n * 3 + (uint64_t)pool_len);
+    (direct ? stats_.peer_direct_copies : stats_.peer_staged_copies) += 1;
     return true;
 }
 
@@ -703,6 +735,7 @@ bool Device::adopt_queries(Device *src, long long first, long long n, long long 
         return false;
     }
     if (!src->sync()) return false;
+    (peer_direct(device_, src->device_) ? stats_.peer_direct_copies : stats_.peer_staged_copies) += 1;
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     if (total > q_capacity_) { // grow, keeping what is resident

@@ -63,6 +63,20 @@ def test_sharded_query_equals_single_rank(tmp_path, nq):
     assert sum(sizes) == nq and max(sizes) - min(sizes) <= 1
 
 
+def test_eight_ranks_like_config_4(tmp_path):
+    # BASELINE config 4's partitioning: the query set over EIGHT ranks, one all-gather of the per-shard top-k (gloo stands in
+    # for RCCL here; the 8-GPU run is the driver's)
+    import torch.multiprocessing as mp
+    world, port, nq = 8, _free_port(), 1003
+    mp.spawn(_worker, args=(world, port, nq, 10, str(tmp_path)), nprocs=world, join=True)
+    sizes = []
+    for r in range(world):
+        ok, m = np.load(tmp_path / f"ok_{r}.npy")
+        assert ok == 1
+        sizes.append(int(m))
+    assert sum(sizes) == nq and max(sizes) - min(sizes) <= 1
+
+
 def test_single_destination_rank(tmp_path):
     # the all-gather leaves the result on every rank, rank 0 copies it out
     import torch.multiprocessing as mp

@@ -92,3 +92,24 @@ def test_resident_set_is_sharded_too(Index):
     for k in (10, 3):
         a, b = one.knn_query_resident(k), two.knn_query_resident(k)
         assert a[0].shape == (2048, k) and (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
+
+
+def test_eight_contexts_and_how_the_replicas_travelled(Index):
+    """BASELINE config 4's shape inside one process: eight device contexts (on a one-GPU box they share the device), 100 000 / 8-like
+    unequal shards, and the copy statistics that say whether replicas went device to device: with peer access between the
+    contexts' devices -- or one device -- every copy counts as direct, none as staged through the host."""
+    n, dim = 8000, 64
+    x, q = uniform(n, dim, 23), uniform(4003, dim, 24)
+    one, eight = _index(Index, x, "sq_euclid", 1, collection=n + 500), _index(Index, x, "sq_euclid", 8, collection=n + 500)
+    a, b = one.knn_query(q, 10), eight.knn_query(q, 10)
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
+    direct = sum(eight.stats_at(g)["peer_direct_copies"] for g in range(1, 8))
+    staged = sum(eight.stats_at(g)["peer_staged_copies"] for g in range(1, 8))
+    assert direct >= 7 and staged == 0, (direct, staged)
+    for g in range(1, 8):
+        st = eight.stats_at(g)
+        assert st["replica_bytes"] > 0 and st["search_launches"] >= 1
+    eight.add(uniform(500, dim, 25))                          # the replicas go stale together and are refreshed together
+    one.add(uniform(500, dim, 25))
+    a, b = one.knn_query(q, 10), eight.knn_query(q, 10)
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
