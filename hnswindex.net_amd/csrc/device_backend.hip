@@ -1001,6 +1001,13 @@ static int overlap_mode()
 // The latency variants of the traversal kernels (device_kernels.h, LAT) for launches that do not fill the chip -- B = 1
 // Add, the exact window's rounds, small query calls: 0 never, 1 (default) when the jobs fit the variant's resident waves,
 // 2 whenever the graph allows it (adjacency lists of at most 64 entries; tests).
+// KnnQuery launches on graphs whose visited sets are hash tables run WITHOUT a visited set (traverse_sorted, oflags bit 3):
+// HNSW_MI355X_NOVIS=0 keeps the tables (A/B runs; same answers).
+static bool novis_mode()
+{
+    const char *e = std::getenv("HNSW_MI355X_NOVIS");
+    return !e || std::atoi(e) != 0;
+}
 static constexpr size_t kTeamLds = ((sizeof(TeamMail) + 15) & ~(size_t)15) + 16; // the latency variants' mailbox, behind the traversal's LDS
 static int lat_mode()
 {
@@ -1724,7 +1731,7 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_, LAT_>), dim3(std::min<int>(GRID, SLOTS)), \
                        dim3(LAT_ ? 128 : 64), (LDS) + (LAT_ ? kTeamLds : 0), st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (vis_tab != nullptr && overlap_mode() != 0 && g_stride0_ - 2 <= 64 && novis_mode() ? 8 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
                        gate)
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \

@@ -1206,6 +1206,16 @@ struct SortedTop {
         dropped_expanded = boundary_tie && (int)lds[k].x < 0; // the twin that left had been expanded (bit 31 of its id word)
         wave_lds_sync();
     }
+    __device__ __forceinline__ bool contains_id(int node, int count, int lane) const // is that node listed? (uniform)
+    {
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            if (64 * t >= count) break;
+            m |= __ballot(lane + 64 * t < count && (id[t] & 0x3fffffff) == node);
+        }
+        return m != 0ull;
+    }
     __device__ __forceinline__ bool any_open_key(unsigned k0, int count, int lane) const // an entry of that key not yet expanded? (uniform)
     {
         bool o = false;
@@ -1475,8 +1485,16 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     bool unsafe = key_unsafe(cur); // NaN / -0 (see f2key)
     bool tie = false, hash_full = false;
     T.insert(f2key(cur), best, top_n, k, lane);                      // :134, :138
-    if (lane == 0) (void)V.first_visit(best);                           // :140
-    V.seen += 1;
+    // oflags bit 3 (KnnQuery launches on graphs whose visited sets are hash tables): NO visited set at all.  Such launches fetch
+    // the rows of every listed neighbour anyway (overlapped form), and what the set is for follows from the list itself: a
+    // neighbour seen before is either still listed -- found by its id -- or it was turned away or pushed out at a farthest key
+    // that has only shrunk since, and the push test (:165) turns it away again.  One CAS per evaluation was as much HBM traffic
+    // as a 128-byte int8 record, and the 64-KB table was cleared after every job.
+    const bool novis = HASHED && (oflags & 8) != 0;
+    if (!novis) {
+        if (lane == 0) (void)V.first_visit(best);                       // :140
+        V.seen += 1;
+    }
     unsigned far_key = f2key(cur);                                   // farthestResultDist :135
     int pre_id = -1, pre_a = 0, pre_b = 0; // speculative prefetch of the next expansion's list (see traverse)
     const int lstride = layer == 0 ? G.stride0 : G.strideU;
@@ -1538,7 +1556,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             unsigned hpos = 0u;
             if constexpr (HASHED) { // first probe of the id table; a collision is followed up after the rows
                 hpos = ((unsigned)nb_a * 2654435761u) & V.tab_mask;
-                if (in) old = (unsigned)atomicCAS(&V.tab[hpos], -1, nb_a);
+                if (in && !novis) old = (unsigned)atomicCAS(&V.tab[hpos], -1, nb_a);
             } else if (in) old = atomicOr(&V.bits[nb_a >> 5], bit); // :181, in flight with the row loads below
             pre_id = -1;
             {
@@ -1559,7 +1577,22 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             }
             if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
             wave_sync();
+            lane_d = in ? dbuf[lane] : 0.0f;
+            lane_id = nb_a;
             if constexpr (HASHED) {
+                if (novis) {
+                    // every listed neighbour counts as new -- except the ones that are in the list: only a key that could pass
+                    // the push test or meet the farthest key matters to anything below, so only those are looked up
+                    have = in;
+                    const unsigned kq = f2key(lane_d);
+                    unsigned long long look = __ballot(in && (top_n < k || kq <= far_key));
+                    unsigned long long listed = 0ull;
+                    for (unsigned long long mm = look; mm; mm &= mm - 1) {
+                        const int sl = (int)__builtin_ctzll(mm);
+                        if (T.contains_id(__builtin_amdgcn_readlane(nb_a, sl), top_n, lane)) listed |= 1ull << sl;
+                    }
+                    if ((listed >> lane) & 1ull) have = false;
+                } else {
                 have = in && (int)old == -1;
                 if (in && (int)old != -1 && (int)old != nb_a) { // slot taken by another id: probe on (VisitedSet::first_visit)
                     for (unsigned probes = 0; probes <= V.tab_mask; ++probes) {
@@ -1569,17 +1602,19 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                         if (o2 == nb_a) break;
                     }
                 }
+                }
             } else have = in && (old & bit) == 0u;
             const unsigned long long mask = __ballot(have);
             m = __popcll(mask);
-            V.seen += m;
-            if (V.crowded()) { hash_full = true; break; }
-            lane_d = in ? dbuf[lane] : 0.0f;
-            lane_id = nb_a;
+            if (!novis) {
+                V.seen += m;
+                if (V.crowded()) { hash_full = true; break; }
+            }
             PH(4);
             if (m == 0) continue;
             evals += (unsigned long long)m;
         } else {
+        if (novis) { hash_full = true; break; } // (a list of more than 64 entries: the host does not ask for this mode on such a graph)
         for (int base = 0; base < n; base += 64) { // :158-161 keep only unvisited, in list order
             const int i = base + lane;
             bool fresh = false;
@@ -2708,10 +2743,11 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
                     int spill_cap, VisitedSet<HASHED> &V, int k_out, int *__restrict__ out_ids,
                     float *__restrict__ out_d, int *__restrict__ out_cnt, int *__restrict__ out_flag,
                     unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap,
-                    int *__restrict__ job_word = nullptr, bool shadow = false, TeamPort *port = nullptr)
+                    int *__restrict__ job_word = nullptr, bool shadow = false, TeamPort *port = nullptr, bool *v_untouched = nullptr)
 {
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x & 63;
+    if (v_untouched) *v_untouched = false;
     const SearchJob jb = jobs[job];
     const GraphView G{adj0, stride0, upper, pool, strideU};
 
@@ -2746,6 +2782,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         if constexpr (LAT) ok1 = traverse_pool<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, RL, nullptr, &window, port);
         else ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL, nullptr, &window);
         if (!(ok1 && tie)) {
+            if (v_untouched) *v_untouched = !LAT && HASHED && (overlap & 8) != 0; // the sorted traversal ran without a visited set: nothing to clear
             if (!claim_answer()) return;
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
             // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
@@ -2889,6 +2926,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     const bool shadows = (overlap & 0x100) != 0 && NS > 0;
     int *job_words = job_counter + 4;
     int known_ready = 0;
+    bool v_clean = false;
     for (;;) {
         int job = 0;
         bool shadow = false;
@@ -2950,8 +2988,8 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
         }
         search_job<METRIC, NS, HASHED, LAT>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
                                V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job, overlap, shadows ? job_words + job : nullptr,
-                               shadow, &port);
-        V.clear(lane);
+                               shadow, &port, &v_clean);
+        if (!v_clean) V.clear(lane);
     }
 
     if constexpr (LAT) port.post(-1, 0, lane); // the memory wave leaves

@@ -1,6 +1,8 @@
 """GPU tier: randomized shapes and TIE-HEAVY data against the oracle.  Small-integer coordinates
 produce many exactly equal distances and duplicate vectors, which is where heap tie order,
 the unstable introsort and the device's integer-key heaps could diverge from the host path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -202,8 +204,13 @@ def test_row_loads_overlapped_with_visited_atomics(Index, monkeypatch, overlap):
     ix.set_profiling(True); ix.reset_stats()
     ref.reset_n_eval()
     ix.knn_query(q[:2000], 7); ref.knn_query(q[:2000], 7)
-    # evaluations are counted for the unvisited neighbours only, overlapped or not
-    assert abs(ix.stats()["search_evals"] - ref.n_eval) <= 2000 * (1 + ref.levels().max())
+    # evaluations are counted for the unvisited neighbours only, overlapped or not -- unless the launch ran without a visited set
+    # (hash-table graphs, forced from outside by HNSW_MI355X_VIS_HASH=1): then every row measured counts
+    st = ix.stats()
+    if st["visited_hash_launches"] and os.environ.get("HNSW_MI355X_NOVIS", "1") != "0":
+        assert st["search_evals"] >= ref.n_eval - 2000 * (1 + ref.levels().max())
+    else:
+        assert abs(st["search_evals"] - ref.n_eval) <= 2000 * (1 + ref.levels().max())
 
 
 @pytest.mark.parametrize("cap,expect_handback", [("16384", False), ("512", True)])
