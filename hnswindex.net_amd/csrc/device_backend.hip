@@ -1001,12 +1001,16 @@ static int overlap_mode()
 // The latency variants of the traversal kernels (device_kernels.h, LAT) for launches that do not fill the chip -- B = 1
 // Add, the exact window's rounds, small query calls: 0 never, 1 (default) when the jobs fit the variant's resident waves,
 // 2 whenever the graph allows it (adjacency lists of at most 64 entries; tests).
-// KnnQuery launches on graphs whose visited sets are hash tables run WITHOUT a visited set (traverse_sorted, oflags bit 3):
-// HNSW_MI355X_NOVIS=0 keeps the tables (A/B runs; same answers).
-static bool novis_mode()
+// KnnQuery launches run WITHOUT a visited set (traverse_sorted, oflags bit 3): every listed neighbour's row is requested as
+// soon as the list is known, and a neighbour seen before is recognised by what the set was standing in for -- it is still in
+// the result list, or the push test turns it away again.  HNSW_MI355X_NOVIS=0 keeps the sets, =1 drops them only on the
+// graphs whose sets are hash tables (A/B runs; same answers either way).  Measured, same box: C2 (1M x 128, bitsets) 2.46-2.56
+// -> 3.07 M queries/s (25-26 -> 20.7 ms per 65 536-query launch, +2.5 % rows measured), 12 500-query calls 2.0 -> 2.39 M; C4-size
+// 1.68 -> 2.03 M, C5-size 2.26 -> 2.70 M.
+static int novis_mode() // 0 never, 1 hash-table graphs only, 2 (default) every graph
 {
     const char *e = std::getenv("HNSW_MI355X_NOVIS");
-    return !e || std::atoi(e) != 0;
+    return e ? std::atoi(e) : 2;
 }
 static constexpr size_t kTeamLds = ((sizeof(TeamMail) + 15) & ~(size_t)15) + 16; // the latency variants' mailbox, behind the traversal's LDS
 static int lat_mode()
@@ -1706,6 +1710,7 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
     int *h_flag = reinterpret_cast<int *>(hs + 16 + b_jobs + 2 * b_res);
     int *d_ids = reinterpret_cast<int *>(s_hits_);
     float *d_d = reinterpret_cast<float *>(s_hits_) + (size_t)chunk * k_out;
+    const bool novis_ = g_stride0_ - 2 <= 64 && overlap_mode() != 0 && (novis_mode() == 2 || (novis_mode() == 1 && vis_tab != nullptr));
     // a query set whose tail is still on the host (set_queries_streamed): the launch is gated on the rows' arrival
     const int *gate = tail_.n > 0 ? d_ready_ : nullptr;
     // whatever happens below, nothing stays pending -- and a tail that never went up (an error between the launch and
@@ -1731,7 +1736,7 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_, LAT_>), dim3(std::min<int>(GRID, SLOTS)), \
                        dim3(LAT_ ? 128 : 64), (LDS) + (LAT_ ? kTeamLds : 0), st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (vis_tab != nullptr && overlap_mode() != 0 && g_stride0_ - 2 <= 64 && novis_mode() ? 8 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, (novis_ ? 9 : (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
                        gate)
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \

@@ -1490,7 +1490,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     // neighbour seen before is either still listed -- found by its id -- or it was turned away or pushed out at a farthest key
     // that has only shrunk since, and the push test (:165) turns it away again.  One CAS per evaluation was as much HBM traffic
     // as a 128-byte int8 record, and the 64-KB table was cleared after every job.
-    const bool novis = HASHED && (oflags & 8) != 0;
+    const bool novis = (oflags & 8) != 0;
     if (!novis) {
         if (lane == 0) (void)V.first_visit(best);                       // :140
         V.seen += 1;
@@ -1557,7 +1557,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             if constexpr (HASHED) { // first probe of the id table; a collision is followed up after the rows
                 hpos = ((unsigned)nb_a * 2654435761u) & V.tab_mask;
                 if (in && !novis) old = (unsigned)atomicCAS(&V.tab[hpos], -1, nb_a);
-            } else if (in) old = atomicOr(&V.bits[nb_a >> 5], bit); // :181, in flight with the row loads below
+            } else if (in && !novis) old = atomicOr(&V.bits[nb_a >> 5], bit); // :181, in flight with the row loads below
             pre_id = -1;
             {
                 const int nxt = T.first_open(top_n, lane);
@@ -1579,8 +1579,8 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             wave_sync();
             lane_d = in ? dbuf[lane] : 0.0f;
             lane_id = nb_a;
-            if constexpr (HASHED) {
-                if (novis) {
+            if (novis) {
+                {
                     // every listed neighbour counts as new -- except the ones that are in the list: only a key that could pass
                     // the push test or meet the farthest key matters to anything below, so only those are looked up
                     have = in;
@@ -1592,7 +1592,9 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                         if (T.contains_id(__builtin_amdgcn_readlane(nb_a, sl), top_n, lane)) listed |= 1ull << sl;
                     }
                     if ((listed >> lane) & 1ull) have = false;
-                } else {
+                }
+            } else if constexpr (HASHED) {
+                {
                 have = in && (int)old == -1;
                 if (in && (int)old != -1 && (int)old != nb_a) { // slot taken by another id: probe on (VisitedSet::first_visit)
                     for (unsigned probes = 0; probes <= V.tab_mask; ++probes) {
@@ -2782,7 +2784,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         if constexpr (LAT) ok1 = traverse_pool<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, RL, nullptr, &window, port);
         else ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL, nullptr, &window);
         if (!(ok1 && tie)) {
-            if (v_untouched) *v_untouched = !LAT && HASHED && (overlap & 8) != 0; // the sorted traversal ran without a visited set: nothing to clear
+            if (v_untouched) *v_untouched = !LAT && (overlap & 8) != 0; // the sorted traversal ran without a visited set: nothing to clear
             if (!claim_answer()) return;
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
             // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)

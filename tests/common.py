@@ -34,3 +34,12 @@ def self_recall_at_1(index, x, ids, **kw):
     """Utils.Recall with k=1 on the inserted vectors (Utils.cs:54-70)."""
     res, _ = index.knn_query(x, 1, **kw)
     return float((res[:, 0] == ids).mean())
+
+
+def novis_active(stats):
+    """True when the search launches behind `stats` ran without a visited set (the default; HNSW_MI355X_NOVIS=0 keeps the
+    sets, =1 drops them on hash-table graphs only): the kernel then counts every row it measures, which includes the
+    neighbours the reference had already seen and skips."""
+    import os
+    mode = os.environ.get("HNSW_MI355X_NOVIS", "2")
+    return mode == "2" or (mode == "1" and stats.get("visited_hash_launches", 0) > 0)

@@ -207,7 +207,8 @@ def test_row_loads_overlapped_with_visited_atomics(Index, monkeypatch, overlap):
     # evaluations are counted for the unvisited neighbours only, overlapped or not -- unless the launch ran without a visited set
     # (hash-table graphs, forced from outside by HNSW_MI355X_VIS_HASH=1): then every row measured counts
     st = ix.stats()
-    if st["visited_hash_launches"] and os.environ.get("HNSW_MI355X_NOVIS", "1") != "0":
+    from common import novis_active
+    if novis_active(st):
         assert st["search_evals"] >= ref.n_eval - 2000 * (1 + ref.levels().max())
     else:
         assert abs(st["search_evals"] - ref.n_eval) <= 2000 * (1 + ref.levels().max())

@@ -225,7 +225,8 @@ def test_search_stats_count_device_evaluations(Index):
     ref = oracle.OracleIndex(64, collection_size=3000); ref.add_batched(x, 4096); ref.reset_n_eval(); ref.knn_query(q, 10)
     # same traversal => same evaluations, except that the oracle re-measures the layer-0 entry
     # point once per query (GraphNavigator.cs:200) and re-measures the start node on each upper layer
-    if s["visited_hash_launches"] and os.environ.get("HNSW_MI355X_NOVIS", "1") != "0":
+    from common import novis_active
+    if novis_active(s):
         # hash-table graphs (forced here by HNSW_MI355X_VIS_HASH=1) are searched WITHOUT a visited set: the kernel counts the rows it
         # measures, which includes neighbours the reference had already seen and skips
         assert s["search_evals"] >= ref.n_eval - 500 * (1 + ref.levels().max())
