@@ -1195,6 +1195,9 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
                 d_order = s_order_;
             }
         }
+        // (Add's searches without a visited set as well -- see novis_mode(); HNSW_MI355X_NOVIS_INSERT=0 keeps the sets there)
+        static const bool novis_ins_on = [] { const char *e = std::getenv("HNSW_MI355X_NOVIS_INSERT"); return !e || std::atoi(e) != 0; }();
+        const bool novis_ins_ = novis_ins_on && g_stride0_ - 2 <= 64 && overlap_mode() != 0 && (novis_mode() == 2 || (novis_mode() == 1 && vis_tab != nullptr));
         HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int), st));
         HIP_OK(hipMemsetAsync(p_evals, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
@@ -1204,7 +1207,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
                        dim3(LAT_ ? 128 : 64), (LDS) + (LAT_ ? kTeamLds : 0), st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, p_sel0 + (size_t)off * sel_stride, p_cnt0 + off, p_selU, p_cntU,        \
-                       sel_stride, p_flag + off, p_evals, nbcap(), GRID, s_jobctr_, ((overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
+                       sel_stride, p_flag + off, p_evals, nbcap(), GRID, s_jobctr_, (novis_ins_ ? 9 : (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
                        windowed ? p_log : (int *)nullptr, read_log_cap)
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \

@@ -3163,8 +3163,10 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                            int *__restrict__ out_sel0, int *__restrict__ out_cnt0, int *__restrict__ out_selU,
                            int *__restrict__ out_cntU, int sel_stride, int *__restrict__ out_flag,
                            unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap_and_flags,
-                           int *__restrict__ read_log, int read_log_cap, TeamPort *port = nullptr)
+                           int *__restrict__ read_log, int read_log_cap, TeamPort *port = nullptr, bool *v_dirty_out = nullptr)
 {
+    bool v_dirty = false; // the visited set has marks in it (the sorted traversal without a visited set -- oflags bit 3 -- leaves none)
+    const bool novis = !LAT && (overlap_and_flags & 8) != 0;
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x & 63;
     const int overlap = overlap_and_flags & 1; // bit 0: overlapped form (bit 1: the MFMA-prefiltered heuristic is allowed)
@@ -3185,7 +3187,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
 #endif
     const int first_layer = jb.search_layer, last_layer = jb.stop_layer;
     for (int layer = first_layer; layer >= last_layer && ok; --layer) {
-        if (layer != first_layer) V.clear(lane); // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
+        if (layer != first_layer && v_dirty) { V.clear(lane); v_dirty = false; } // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
         int top_n = 0;
         const int rl_n0 = RL.n;
         const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
@@ -3194,7 +3196,8 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         if constexpr (NS > 0) {
             bool tie = false;
             if constexpr (LAT) ok = traverse_pool<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, RL, &order_tie, nullptr, port);
-            else ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap, RL, &order_tie); // Span.Sort consumes all
+            else ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap_and_flags & 9, RL, &order_tie); // Span.Sort consumes all
+            v_dirty = v_dirty || !novis;
             if (!ok) break;
             // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
             // then returns them in HEAP order, Heuristic.cs:13-18): this layer again, exact traversal
@@ -3208,10 +3211,11 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                     evals = ev0;
                     top_n = 0;
                     RL.n = rl_n0; // the same lists are read again
-                    V.clear(lane);
+                    if (v_dirty) V.clear(lane);
                 }
                 ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL, nullptr, nullptr,
                                               LAT || overlap != 0);
+                v_dirty = true;
                 if (!ok) break;
             }
 #ifdef EXP_PHASE_CLOCKS
@@ -3258,6 +3262,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         jb.search_layer = layer - 1;
         wave_sync();
     }
+    if (v_dirty_out) *v_dirty_out = v_dirty || LAT; // (the latency variants' memory wave marks as it goes)
     if (lane == 0) {
         out_flag[job] = ok ? (repeat ? 2 : 0) : 1; // 2: informational (a layer was answered by the exact traversal)
         if (read_log) read_log[(size_t)job * read_log_cap] = RL.n;
@@ -3300,6 +3305,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         }
         port.m = mail;
     }
+    bool v_dirty = true;
     for (;;) { // persistent, see graph_search_kernel
         int job = 0;
         if (lane == 0) job = atomicAdd(job_counter, 1);
@@ -3310,8 +3316,8 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         // order of processing changes nothing else.
         if (order) job = __builtin_amdgcn_readfirstlane(order[job]);
         insert_job<METRIC, NS, HASHED, LAT>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
-                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap, read_log, read_log_cap, &port);
-        V.clear(lane);
+                               out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap, read_log, read_log_cap, &port, &v_dirty);
+        if (v_dirty) V.clear(lane);
     }
 
     if constexpr (LAT) port.post(-1, 0, lane); // the memory wave leaves
