@@ -466,6 +466,21 @@ def main():
             cpu["single_thread_adds_per_s"] = round(cpu_add["sequential"][0], 1)
         del ref
 
+    # The traversal kernels run without a visited set: they count every row they MEASURE, a few per cent more than
+    # the reference's evaluations (it skips neighbours it has seen).  The roofline's numerator is the ALGORITHMIC work -- the
+    # reference's evaluations, counted by the CPU restatement on the sample it answered -- whenever that count is at hand.
+    roofline["rows_measured_per_launch"] = roofline["evals_per_launch"]
+    roofline["algorithmic_evals_source"] = "device counter (rows measured)"
+    if cpu is not None and kernel_s > 0 and a.traversal == "device":
+        alg = min(t_evals, cpu["evals_per_query"] * per_gpu * ndev_native * max(1, t_launches) / max(1, ndev_native))
+        achieved = alg * st["row_bytes"] / kernel_s / 1e9
+        roofline.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "algorithmic_bytes_per_launch": round(alg / max(1, t_launches) * st["row_bytes"]),
+                         "evals_per_launch": round(alg / max(1, t_launches), 1),
+                         "algorithmic_evals_source": "reference evaluations per query (CPU restatement, cpu_baseline.evals_per_query) x queries per launch"})
+        if gather:
+            roofline["frac_of_measured_gather"] = round(alg / kernel_s / gather["rows_per_s"], 4)
+
     add_modes = None
     if not a.no_add_modes and world == 1:
         def leg(name, vecs, call, note):
