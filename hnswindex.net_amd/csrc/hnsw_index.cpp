@@ -601,6 +601,7 @@ constexpr int kBatchGrowthDiv = 16, kEarlyGrowthDiv = 4, kEarlyLinked = 65536;
 struct PhaseTimers {
     double sync_graph = 0, search_half = 0, collect = 0, link_host = 0, link_dev = 0, post = 0, query_dev = 0, set_queries = 0;
     double add_nodes = 0, add_upload = 0, add_total = 0;
+    double xw_total = 0, xw_todo = 0, xw_launch = 0, xw_parse = 0, xw_pairs = 0, xw_valid = 0, xw_link = 0; // the exact window's rounds
     long rounds = 0, batches = 0, prune_jobs = 0;
     bool on = std::getenv("HNSW_MI355X_TRACE") != nullptr;
 };
@@ -662,6 +663,9 @@ HnswIndex::~HnswIndex()
         fprintf(stderr, "[hnsw trace] add: total=%.3fs nodes=%.3fs upload=%.3fs\n", g_pt.add_total, g_pt.add_nodes, g_pt.add_upload),
         fprintf(stderr, "[hnsw trace] batches=%ld sync_graph=%.3fs search_half=%.3fs collect=%.3fs link_host=%.3fs link_dev=%.3fs (rounds=%ld prune_jobs=%ld) | query: set_queries=%.3fs dev=%.3fs post=%.3fs\n",
                 g_pt.batches, g_pt.sync_graph, g_pt.search_half, g_pt.collect, g_pt.link_host, g_pt.link_dev, g_pt.rounds, g_pt.prune_jobs, g_pt.set_queries, g_pt.query_dev, g_pt.post);
+    if (g_pt.on && g_pt.xw_total > 0)
+        fprintf(stderr, "[hnsw trace] exact window: total=%.3fs | what to search %.3fs, search launch + wait %.3fs, results -> specs %.3fs, pair distances %.3fs, validation %.3fs, prefix link %.3fs\n",
+                g_pt.xw_total, g_pt.xw_todo, g_pt.xw_launch, g_pt.xw_parse, g_pt.xw_pairs, g_pt.xw_valid, g_pt.xw_link);
     engine_.reset(); // before the device it allocates from
     for (auto &l : lanes_) l.reset();
     replicas_.clear();
@@ -1036,9 +1040,12 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         return true;
     };
     struct Drain { std::function<void()> f; ~Drain() { f(); } } drain{[&] { std::string e2; for (int s2 = 0; s2 < 2; ++s2) if (pend[s2]) { pend[s2] = false; (void)dev_->link_batch_finish(s2, nullptr); } }};
+    Tick t_xw(g_pt.xw_total);
     while (p < m) {
         if (graph_.entry < 0) { graph_.entry = fresh[(size_t)p++]; continue; } // GraphConnector.cs:28-33
         const int top = graph_.top_layer();
+        double t_ph = g_pt.on ? now_s() : 0;
+        auto phase = [&](double &acc) { if (g_pt.on) { const double n = now_s(); acc += n - t_ph; t_ph = n; } };
         {
             Spec &sf = spec[(size_t)(p % ring)];
             if (graph_.level[(size_t)fresh[(size_t)p]] > top || (sf.t == p && sf.handback)) { // alone: entry-point lock (:36-41) / exact host path
@@ -1079,6 +1086,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
             if (!uv) { s.lo.has = false; todo.push_back(Todo{t, t == p ? kFull : kUpper}); continue; } // layer 0 enters where the upper layers end
             if (t < hi && !lo_valid(s, R)) todo.push_back(Todo{t, kLower});
         }
+        phase(g_pt.xw_todo);
         if (!todo.empty()) {
             int max_t = 0;
             for (const Todo &d : todo) max_t = std::max(max_t, d.t);
@@ -1100,6 +1108,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
             Device::InsertResults res{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
             Device::WindowExtras win{log_cap, upper_owner.data(), nullptr, nullptr, nullptr};
             if (!dev_->insert_search_batch(jobs.data(), n, p_.max_candidates, M2, n_upper, &res, &win)) { err = get_dev_error(); return false; }
+            phase(g_pt.xw_launch);
             xw_searches_ += (uint64_t)n;
             for (int i = 0; i < n; ++i) {
                 Spec &s = spec[(size_t)(todo[(size_t)i].t % ring)];
@@ -1151,6 +1160,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         // reader row against gained / lost row, are one batch of id<->id distances on the device (the kernels' own arithmetic, so
         // the keys compare exactly as they would have inside the search).  Per layer-0 list only the FIRST change of a round is
         // known this way (the dry run saw the list as it was); a second one, or a change whose lost ids are unknown, blocks.
+        phase(g_pt.xw_parse);
         int hi_link = p;
         for (; hi_link < hi; ++hi_link) {
             const Spec &s = spec[(size_t)(hi_link % ring)];
@@ -1194,7 +1204,9 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
             }
             if (!pa_.empty()) {
                 pd_.resize(pa_.size());
+                phase(g_pt.xw_valid);
                 if (!dev_->dist_pair_batch(pa_.data(), pb_.data(), (int)pa_.size(), pd_.data())) { err = get_dev_error(); return false; }
+                phase(g_pt.xw_pairs);
                 xw_pairs_ += (uint64_t)pa_.size();
                 for (size_t q = 0; q < pa_.size(); ++q) {
                     uint32_t u;
@@ -1238,6 +1250,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
             s.t = -1;
         }
         ++xw_rounds_;
+        phase(g_pt.xw_valid);
         if (bid.empty()) continue; // the frontier item was handed back: the next iteration takes it alone
         sel.n = (int)bid.size();
         if (!finish(next_set)) return false;
@@ -1248,6 +1261,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         xw_prefix_ema_ = 0.75 * xw_prefix_ema_ + 0.25 * (double)bid.size();
         seq_ = cur;
         p = t;
+        phase(g_pt.xw_link);
     }
     return finish(0) && finish(1);
 }
