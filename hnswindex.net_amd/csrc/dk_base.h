@@ -1,0 +1,44 @@
+// dk_base.h -- device code, part of device_kernels.h: includes, launch-shape macros, wave-level synchronisation, metric ids.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "device_backend.h"
+
+#ifdef EXP_LAT_REGS // experiment: no occupancy target for the traversal kernels (every register the wave can have: no spills)
+#define HNSW_WAVES(x) 1
+#else
+#define HNSW_WAVES(x) (x)
+#endif
+
+namespace hnsw {
+
+// Every block of the kernels below that stage data through LDS is ONE wavefront working on its own job (the latency
+// variants add a second wave with a role of its own, which never meets the first at a barrier): what the phases of
+// such a wave need between a write and the reads of other lanes is that its own memory operations have completed and
+// that the compiler keeps the order -- what __syncthreads() does in front of its s_barrier, without the barrier.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+// LDS ordering inside ONE wave (every traversal block is one wave): the wave's LDS instructions execute in order, so
+// all a write-then-read by other lanes needs is that the compiler keeps them in order -- not wave_sync(), whose
+// s_waitcnt also drains the vector-memory counter and with it every load still in flight.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// ------------------------------------------------------------------------------------
+// device code
+// ------------------------------------------------------------------------------------
+enum { M_SQ = HNSWDEV_SQ_EUCLID, M_COS = HNSWDEV_COSINE, M_UCOS = HNSWDEV_UCOSINE, M_I8 = HNSWDEV_SQ_EUCLID_I8 };
+
+} // namespace hnsw
