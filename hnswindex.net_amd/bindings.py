@@ -54,7 +54,7 @@ class Stats(ct.Structure):
                 ("range_launches", ct.c_uint64), ("range_evals", ct.c_uint64), ("range_timed_launches", ct.c_uint64),
                 ("range_timed_evals", ct.c_uint64), ("range_kernel_ms", ct.c_double), ("range_handbacks", ct.c_uint64),
                 ("replica_bytes", ct.c_uint64),
-                ("tie_windows", ct.c_uint64), ("peer_direct_copies", ct.c_uint64), ("peer_staged_copies", ct.c_uint64), ("lat_launches", ct.c_uint64)]
+                ("tie_windows", ct.c_uint64), ("peer_direct_copies", ct.c_uint64), ("peer_staged_copies", ct.c_uint64), ("entry_block_launches", ct.c_uint64), ("lat_launches", ct.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

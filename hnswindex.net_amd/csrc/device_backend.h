@@ -371,6 +371,7 @@ private:
     hnswdev_stats stats_{};
     bool shadows_allowed_ = true;
     int uj_len_ = 0, uj_entry_ = -1, uj_layer_ = -1; // s_jobs_ holds search_queries' jobs 0 .. uj_len_-1 for that entry point
+    bool uj_hinted_ = false;                          // ... with entry_block_kernel's hints of the LAST query set in them
     bool search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag,
                            bool two_heap, int u_entry, int u_layer);
 };

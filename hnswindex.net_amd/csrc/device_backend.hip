@@ -1197,7 +1197,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         }
         // (Add's searches without a visited set as well -- see novis_mode(); HNSW_MI355X_NOVIS_INSERT=0 keeps the sets there)
         static const bool novis_ins_on = [] { const char *e = std::getenv("HNSW_MI355X_NOVIS_INSERT"); return !e || std::atoi(e) != 0; }();
-        const bool novis_ins_ = novis_ins_on && g_stride0_ - 2 <= 64 && overlap_mode() != 0 && (novis_mode() == 2 || (novis_mode() == 1 && vis_tab != nullptr));
+        const bool novis_ins_ = novis_ins_on && g_stride0_ - 2 <= 64 && overlap_mode() != 0 && (size_t)pitch_ * sizeof(float) <= 1024 && (novis_mode() == 2 || (novis_mode() == 1 && vis_tab != nullptr));
         HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int), st));
         HIP_OK(hipMemsetAsync(p_evals, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
@@ -1713,7 +1713,9 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
     int *h_flag = reinterpret_cast<int *>(hs + 16 + b_jobs + 2 * b_res);
     int *d_ids = reinterpret_cast<int *>(s_hits_);
     float *d_d = reinterpret_cast<float *>(s_hits_) + (size_t)chunk * k_out;
-    const bool novis_ = g_stride0_ - 2 <= 64 && overlap_mode() != 0 && (novis_mode() == 2 || (novis_mode() == 1 && vis_tab != nullptr));
+    // (rows of more than 1 KB: the set's traffic is small beside the rows', and the rows of re-seen neighbours are what costs --
+    //  C3's 3-KB rows: 282.7 k queries/s with the sets against 273.6 k without, build 69.5 k against 61.3 k adds/s)
+    const bool novis_ = g_stride0_ - 2 <= 64 && overlap_mode() != 0 && (size_t)pitch_ * sizeof(float) <= 1024 && (novis_mode() == 2 || (novis_mode() == 1 && vis_tab != nullptr));
     // a query set whose tail is still on the host (set_queries_streamed): the launch is gated on the rows' arrival
     const int *gate = tail_.n > 0 ? d_ready_ : nullptr;
     // whatever happens below, nothing stays pending -- and a tail that never went up (an error between the launch and
@@ -1722,14 +1724,33 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
     struct TailGuard { Device *d; ~TailGuard() { if (d->tail_.n > 0) d->n_queries_ = 0; d->tail_.n = 0; } } tail_guard{this};
     for (long long off = 0; off < njobs; off += chunk) {
         const int nj = (int)std::min<long long>(chunk, njobs - off);
+        // the queries' shared first hop as one dense MFMA block (entry_block_kernel): float metrics, rows of a multiple of 8
+        // floats, a top layer to descend from, every query row resident (not the streamed upload); HNSW_MI355X_MFMA_ENTRY=0: off
+        // (a launch of its own, 10-20 microseconds: not for calls of a few queries, which are all latency)
+        const char *entry_env = std::getenv("HNSW_MI355X_MFMA_ENTRY");
+        const bool entry_on = !entry_env || std::atoi(entry_env) != 0;
+        const bool entry_block = !jobs && entry_on && nj >= 256 && metric_ != M_I8 && (pitch_ & 7) == 0 && u_layer >= 1 && gate == nullptr && ns > 0 && g_strideU_ - 2 <= 31;
         if (jobs) {
             memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
+            for (int i = 0; i < nj; ++i) h_jobs[i].stop_layer = 0; // (a search job's stop_layer is the entry block's hint: none)
             HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
             uj_len_ = 0;
-        } else if (!(uj_len_ >= nj && uj_entry_ == u_entry && uj_layer_ == u_layer)) {
+        } else if (!(uj_len_ >= nj && uj_entry_ == u_entry && uj_layer_ == u_layer) || (uj_hinted_ && !entry_block)) {
             for (int i = 0; i < nj; ++i) h_jobs[i] = SearchJob{i, u_entry, u_layer, 0, -1, 0};
             HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
-            uj_len_ = nj; uj_entry_ = u_entry; uj_layer_ = u_layer;
+            uj_len_ = nj; uj_entry_ = u_entry; uj_layer_ = u_layer; uj_hinted_ = false;
+        }
+        if (entry_block) { // every job of this launch gets its hint (or 0) rewritten: the resident query set may be a new one
+            const int tiles = (nj + 31) / 32;
+#define LAUNCH_EB(M) hipLaunchKernelGGL(entry_block_kernel<M>, dim3(tiles), dim3(64), 0, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, g_upper_, g_pool_, \
+                                        g_strideU_, u_entry, u_layer, s_jobs_, nj, (unsigned long long *)nullptr)
+            if (metric_ == M_SQ) LAUNCH_EB(M_SQ);
+            else if (metric_ == M_COS) LAUNCH_EB(M_COS);
+            else LAUNCH_EB(M_UCOS);
+#undef LAUNCH_EB
+            HIP_OK(hipGetLastError());
+            uj_hinted_ = true;
+            stats_.entry_block_launches++;
         }
         HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int) * (4 + (size_t)nj), st));
         HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));

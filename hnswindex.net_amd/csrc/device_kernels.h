@@ -10,7 +10,8 @@
 //   dk_team.h            the latency variants' memory wave and its mailbox
 //   dk_pool_top.h        SearchLayer on an unsorted register pool (the latency variants' logic wave)
 //   dk_traverse_exact.h  the exact two-heap traversal
-//   dk_heuristic.h       RelativeNeighborPruning
+//   dk_heuristic.h       RelativeNeighborPruning (with its MFMA Gram-block prefilter)
+//   dk_entry_block.h     the queries' shared first hop as one dense MFMA block (prefilter)
 //   dk_search_kernels.h  graph_search_kernel, graph_range_kernel
 //   dk_insert_kernels.h  graph_insert_search_kernel
 //   dk_link.h            the link half of Add, Remove's re-link
@@ -27,6 +28,7 @@
 #include "dk_pool_top.h"
 #include "dk_traverse_exact.h"
 #include "dk_heuristic.h"
+#include "dk_entry_block.h"
 #include "dk_search_kernels.h"
 #include "dk_insert_kernels.h"
 #include "dk_link.h"

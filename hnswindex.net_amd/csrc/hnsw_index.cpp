@@ -602,6 +602,8 @@ struct PhaseTimers {
     double sync_graph = 0, search_half = 0, collect = 0, link_host = 0, link_dev = 0, post = 0, query_dev = 0, set_queries = 0;
     double add_nodes = 0, add_upload = 0, add_total = 0;
     double xw_total = 0, xw_todo = 0, xw_launch = 0, xw_parse = 0, xw_pairs = 0, xw_valid = 0, xw_link = 0; // the exact window's rounds
+    long xw_end[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // what ended a round's prefix: 0 window exhausted, 1 stale result (searched on an older graph, list written since), 2 second change of a list,
+                                               // 3 change with unknown lost ids, 4 reader answered by the exact traversal, 5 expansion without a bound, 6 the change shows (pair distance), 7 upper layers / overflow
     long rounds = 0, batches = 0, prune_jobs = 0;
     bool on = std::getenv("HNSW_MI355X_TRACE") != nullptr;
 };
@@ -664,8 +666,11 @@ HnswIndex::~HnswIndex()
         fprintf(stderr, "[hnsw trace] batches=%ld sync_graph=%.3fs search_half=%.3fs collect=%.3fs link_host=%.3fs link_dev=%.3fs (rounds=%ld prune_jobs=%ld) | query: set_queries=%.3fs dev=%.3fs post=%.3fs\n",
                 g_pt.batches, g_pt.sync_graph, g_pt.search_half, g_pt.collect, g_pt.link_host, g_pt.link_dev, g_pt.rounds, g_pt.prune_jobs, g_pt.set_queries, g_pt.query_dev, g_pt.post);
     if (g_pt.on && g_pt.xw_total > 0)
-        fprintf(stderr, "[hnsw trace] exact window: total=%.3fs | what to search %.3fs, search launch + wait %.3fs, results -> specs %.3fs, pair distances %.3fs, validation %.3fs, prefix link %.3fs\n",
-                g_pt.xw_total, g_pt.xw_todo, g_pt.xw_launch, g_pt.xw_parse, g_pt.xw_pairs, g_pt.xw_valid, g_pt.xw_link);
+        fprintf(stderr, "[hnsw trace] exact window: total=%.3fs | what to search %.3fs, search launch + wait %.3fs, results -> specs %.3fs, pair distances %.3fs, validation %.3fs, prefix link %.3fs\n"
+                        "[hnsw trace] exact window, what ended the rounds' prefixes: window exhausted %ld, stale result %ld, second change of a list %ld, change with unknown lost ids %ld, "
+                        "reader took the exact traversal %ld, expansion without a bound %ld, the change shows %ld, upper layers / no read log %ld\n",
+                g_pt.xw_total, g_pt.xw_todo, g_pt.xw_launch, g_pt.xw_parse, g_pt.xw_pairs, g_pt.xw_valid, g_pt.xw_link,
+                g_pt.xw_end[0], g_pt.xw_end[1], g_pt.xw_end[2], g_pt.xw_end[3], g_pt.xw_end[4], g_pt.xw_end[5], g_pt.xw_end[6], g_pt.xw_end[7]);
     engine_.reset(); // before the device it allocates from
     for (auto &l : lanes_) l.reset();
     replicas_.clear();
@@ -999,6 +1004,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         std::vector<uint64_t> rU; // upper-layer lists read: layer << 32 | node
         bool repeated = false;    // a layer was answered by the exact two-heap traversal (equal distances): order-sensitive
         int blocker = -1;         // this round: the first item of the window whose linking invalidates this result (-1: none)
+        int why = 0;              // (trace) what set the blocker: see PhaseTimers::xw_end
     };
     std::vector<Spec> spec((size_t)ring);
     // Write stamps are compared with snapshots taken inside THIS call only, and every stamp an earlier call left is at most
@@ -1186,16 +1192,16 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
             pa_.clear(); pb_.clear(); pfar_.clear(); powner_.clear();
             for (int t = p + 1; t < hi_link; ++t) {
                 Spec &s = spec[(size_t)(t % ring)];
-                auto block = [&](int by) { if (by < t && (s.blocker < 0 || by < s.blocker)) s.blocker = by; };
+                auto block = [&](int by, int why) { if (by < t && (s.blocker < 0 || by < s.blocker)) { s.blocker = by; s.why = why; } };
                 const int jid = fresh[(size_t)t];
                 for (size_t r = 0; r < s.r0.size(); ++r) {
                     auto it = xw_first_.find(s.r0[r]);
                     if (it == xw_first_.end() || it->second.t >= t) continue;
                     const XwChange &c1 = it->second;
                     auto i2 = xw_second_.find(s.r0[r]);
-                    if (i2 != xw_second_.end()) block(i2->second);
+                    if (i2 != xw_second_.end()) block(i2->second, 2);
                     const uint32_t far = s.f0[r];
-                    if (!c1.known || s.repeated || far == 0xffffffffu) { block(c1.t); continue; }
+                    if (!c1.known || s.repeated || far == 0xffffffffu) { block(c1.t, !c1.known ? 3 : s.repeated ? 4 : 5); continue; }
                     const Spec &w = spec[(size_t)(c1.t % ring)];
                     const int code = w.code[0][(size_t)c1.e], nd = (code >> 8) & 0xff;
                     if (code & 2) { pa_.push_back(jid); pb_.push_back(fresh[(size_t)c1.t]); pfar_.push_back(far); powner_.push_back(std::make_pair(t, c1.t)); }
@@ -1215,7 +1221,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
                     const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u); // the kernels' f2key
                     if (odd || key < pfar_[q]) {                                     // it would have been pushed: the change shows
                         Spec &s = spec[(size_t)(powner_[q].first % ring)];
-                        if (s.blocker < 0 || powner_[q].second < s.blocker) s.blocker = powner_[q].second;
+                        if (s.blocker < 0 || powner_[q].second < s.blocker) { s.blocker = powner_[q].second; s.why = 6; }
                     }
                 }
             }
@@ -1227,8 +1233,9 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         Selection sel;
         for (; t < hi_link; ++t) {
             Spec &s = spec[(size_t)(t % ring)];
-            if (s.blocker >= 0 || !up_valid(s, cur)) break;                       // (upper layers: any write since the snapshot counts)
-            if (s.lo.overflow && !(s.lo.snap == cur)) break;                      // no read log: only good on the very graph it searched
+            if (s.blocker >= 0) { g_pt.xw_end[s.why]++; break; }
+            if (!up_valid(s, cur)) { g_pt.xw_end[7]++; break; }                   // (upper layers: any write since the snapshot counts)
+            if (s.lo.overflow && !(s.lo.snap == cur)) { g_pt.xw_end[7]++; break; } // no read log: only good on the very graph it searched
             ++cur;
             for (size_t layer = 0; layer < s.sel.size(); ++layer) {
                 const uint32_t snap = layer == 0 ? s.lo.snap : s.up.snap; // the dry run saw the graph of that snapshot
@@ -1250,6 +1257,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
             s.t = -1;
         }
         ++xw_rounds_;
+        if (t == hi_link) g_pt.xw_end[hi_link < hi ? 1 : 0]++;
         phase(g_pt.xw_valid);
         if (bid.empty()) continue; // the frontier item was handed back: the next iteration takes it alone
         sel.n = (int)bid.size();
@@ -1596,7 +1604,7 @@ void HnswIndex::collect_stats(hnswdev_stats *out)
         out->search_launches += s.search_launches; out->search_evals += s.search_evals; out->search_timed_launches += s.search_timed_launches;
         out->search_timed_evals += s.search_timed_evals; out->search_kernel_ms += s.search_kernel_ms; out->search_overflows += s.search_overflows;
         out->search_repeats += s.search_repeats; out->visited_hash_launches += s.visited_hash_launches;
-        out->tie_windows += s.tie_windows; out->lat_launches += s.lat_launches; out->peer_direct_copies += s.peer_direct_copies; out->peer_staged_copies += s.peer_staged_copies;
+        out->tie_windows += s.tie_windows; out->lat_launches += s.lat_launches; out->peer_direct_copies += s.peer_direct_copies; out->peer_staged_copies += s.peer_staged_copies; out->entry_block_launches += s.entry_block_launches;
     }
 }
 

@@ -240,6 +240,7 @@ typedef struct hnswdev_stats {
     uint64_t tie_windows;           /* searches that met open candidates of equal distance and were shown to be order-free (no exact re-run) */
     uint64_t peer_direct_copies;    /* replica / query-set copies between contexts whose devices have peer access enabled (one device: counted here) */
     uint64_t peer_staged_copies;    /* ... and those the runtime had to stage through host memory (no peer access between the two devices) */
+    uint64_t entry_block_launches;  /* search launches preceded by the MFMA block of the queries' shared first hop (entry_block_kernel) */
     uint64_t lat_launches;          /* traversal launches that ran the latency variant of their kernel (fewer jobs than its resident waves) */
 } hnswdev_stats;
 

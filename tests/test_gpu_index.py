@@ -526,3 +526,30 @@ def test_batched_removal_matches_its_cpu_restatement(Index, metric, batch):
         more = normalize_f32(more)
     c, d = ix.add(more), ref.add_batched(more, 1024)      # vacated slots reused (LIFO), same Add schedule on both
     assert (c == d).all() and ix.graph_hash() == ref.graph_hash()
+
+
+@pytest.mark.parametrize("metric", ["sq_euclid", "cosine", "ucosine"])
+def test_mfma_entry_block_decides_first_passes_like_the_exact_pass(Index, metric, monkeypatch):
+    """The queries' shared first hop -- entry point + its top-layer edges against the whole batch -- as one dense MFMA block
+    (entry_block_kernel, csrc/dk_entry_block.h): a prefilter whose verdicts must be the exact pass's.  Same ids and distance
+    bits with it on and off and from the oracle; fewer rows measured with it on."""
+    n, dim = 40000, 64
+    x, q = uniform(n, dim, 301), uniform(3000, dim, 302)
+    if metric == "ucosine":
+        x, q = normalize_f32(x), normalize_f32(q)
+    ix = Index(dim, metric); ix.set_collection_size(n); ix.set_min_nn(32)
+    ix.add(x)
+    top = int(ix.levels().max())
+    assert top >= 1 and len(ix.edges(ix.entry_point, top)) >= 2, "the data must give the entry point neighbours on its top layer"
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HNSW_MI355X_MFMA_ENTRY", mode)
+        ix.reset_stats()
+        out[mode] = ix.knn_query(q, 10) + (ix.stats(),)
+    assert out["0"][2]["entry_block_launches"] == 0 and out["1"][2]["entry_block_launches"] >= 1
+    assert (out["0"][0] == out["1"][0]).all() and out["0"][1].tobytes() == out["1"][1].tobytes()
+    assert out["1"][2]["search_evals"] < out["0"][2]["search_evals"]          # first passes were decided without their rows
+    ref = oracle.OracleIndex(dim, metric, min_nn=32, collection_size=n)
+    ref.import_graph(x, ix.levels(), ix.entry_point, [ix.export_edges(l, 34 if l == 0 else 18) for l in range(top + 1)])
+    rids, rd = ref.knn_query(q, 10)
+    assert (out["1"][0] == rids).all() and out["1"][1].tobytes() == rd.tobytes()
