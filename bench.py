@@ -586,7 +586,7 @@ def main():
                         return b
                     b0, r0 = sizes[i - 1], rates[i - 1]  # log-linear between the two measured call sizes
                     f = (np.log(level) - np.log(r0)) / max(1e-9, np.log(r_) - np.log(r0))
-                    return int(round(float(np.exp(np.log(b0) + f * (np.log(b) - np.log(b0))))))
+                    return int(np.ceil(float(np.exp(np.log(b0) + f * (np.log(b) - np.log(b0))) - 1e-9)))  # the smallest call that wins
             return None
         crossover = {"queries_per_call": sizes, "gpu_queries_per_sec": rates,
                      "cpu_one_thread_queries_per_sec": cpu["single_thread_queries_per_s"], f"cpu_{cores}_threads_queries_per_sec": cpu["value"],

@@ -109,8 +109,9 @@ mj, bl = src / "c3_mfma.json", src / "bench_c3_mfma.log"
 if mj.exists() and bl.exists() and bench(bl):
     b = bench(bl)
     cs = json.load(open(mj))["counters"]
-    k = [x for x in cs if "graph_insert_search_kernel" in x][0]
-    mops, busy, gui = cs[k]["SQ_INSTS_VALU_MFMA_MOPS_F32"]["sum"], cs[k]["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"], cs[k]["GRBM_GUI_ACTIVE"]["sum"]
+    ks = [x for x in cs if "graph_insert_search_kernel" in x]  # the loaded form and the latency variant: summed (seconds are both's)
+    k = " + ".join(sorted(ks))
+    mops, busy, gui = (sum(cs[x][c]["sum"] for x in ks) for c in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))
     secs = b["roofline_add"]["insert_search"]["seconds"]
     flops = mops * 512.0                      # the counter's unit: 512 floating-point operations
     out = {"kernel": k, "config": "C3 build (1M x 768 ucosine, M=32, efConstruction=400): gram_tile inside RelativeNeighborPruning, v_mfma_f32_32x32x2_f32",
