@@ -215,14 +215,18 @@ def test_row_loads_overlapped_with_visited_atomics(Index, monkeypatch, overlap):
 
 
 @pytest.mark.parametrize("cap,expect_handback", [("16384", False), ("512", True)])
-@pytest.mark.parametrize("sorted_top", ["1", "0"])
-def test_visited_id_hash_table(Index, monkeypatch, sorted_top, cap, expect_handback):
+@pytest.mark.parametrize("sorted_top,novis", [("1", "0"), ("0", "0"), ("1", "2")])
+def test_visited_id_hash_table(Index, monkeypatch, sorted_top, novis, cap, expect_handback):
     # large graphs keep the visited ids of a traversal in a per-wave hash table instead of a bitset
-    # (forced here on a small graph); a table that fills up hands the job to the host traversal
+    # (forced here on a small graph); a table that fills up hands the job to the host traversal.
+    # novis = "2" is the default of the search launches: the sorted traversal keeps no set at all, only its exact re-runs and
+    # the shadow traversals of a draining launch do -- whether one of those fills a 512-entry table is a matter of timing,
+    # so that leg checks the answers only
     from common import uniform
     monkeypatch.setenv("HNSW_MI355X_VIS_HASH", "1")
     monkeypatch.setenv("HNSW_MI355X_VIS_HASH_CAP", cap)
     monkeypatch.setenv("HNSW_MI355X_SORTED_TOP", sorted_top)
+    monkeypatch.setenv("HNSW_MI355X_NOVIS", novis)
     x, q = uniform(6000, 24, 701), uniform(6000, 24, 702)
     ref = oracle.OracleIndex(24, max_edges=8, max_candidates=50, min_nn=96, collection_size=6000)
     ref.add_batched(x, 16384)
@@ -231,7 +235,8 @@ def test_visited_id_hash_table(Index, monkeypatch, sorted_top, cap, expect_handb
     ix.reset_stats()
     got, want = ix.knn_query(q, 5), ref.knn_query(q, 5, threads=8)
     assert (got[0] == want[0]).all() and got[1].tobytes() == want[1].tobytes()
-    assert (ix.stats()["search_overflows"] > 0) == expect_handback
+    if novis == "0" or not expect_handback:
+        assert (ix.stats()["search_overflows"] > 0) == expect_handback
 
 
 @pytest.mark.parametrize("case_seed", range(4))
