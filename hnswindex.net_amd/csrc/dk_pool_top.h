@@ -200,6 +200,9 @@ __device__ __forceinline__ bool traverse_pool(const float *__restrict__ rows, co
     // loop below ran out of those: two dozen spill moves per accepted neighbour)
     enum : unsigned { kTie = 1u, kUnsafe = 2u, kHashFull = 4u, kFarDoubt = 8u, kDoubtHard = 16u };
     unsigned st = key_unsafe(cur) ? kUnsafe : 0u; // NaN / -0 (see f2key)
+    // (the hint left by the previous traversal names a node of ITS layer: the last job's layer-0 search, say, while this one
+    //  starts on an upper layer where that node has no list -- the memory wave would prefetch from in front of the pool)
+    if (lane == 0) port->m->hint_node = -1;
     T.put(0, f2key(cur), best);                                         // :134, :138
     top_n = 1;
     if (lane == 0) (void)V.first_visit(best);                           // :140
@@ -246,7 +249,7 @@ __device__ __forceinline__ bool traverse_pool(const float *__restrict__ rows, co
             if (grp_cnt == 0) { grp_key = ck; grp_cnt = T.count_key(ck); }
             else if (ck != grp_key) st |= kTie; // (d)
         }
-        if (lane == 0) port->m->hint_node = nxt_id; // (a list for the memory wave to prefetch: stale or missing, nothing breaks)
+        if (lane == 0) port->m->hint_node = nxt_id; // (a list for the memory wave to prefetch: a node of THIS layer; late or missing, nothing breaks)
         PH(1);
         port->wait(); // ids, keys and masks of this node's neighbours
         PH(4);
