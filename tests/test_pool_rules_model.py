@@ -10,6 +10,8 @@ shown, the verdict is raised and the exact two-heap traversal answers instead.  
 the reference side is the oracle's own SearchLayer (orc_search_layer: the restated heaps, on the oracle-built graph, queries
 that are stored vectors so that both sides read the same float32 distances), and every search that ends without the verdict
 must equal it: as a set for an insert's candidate list, and entry by entry over the prefix a KnnQuery consumes in order.
+(traverse_sorted -- the loaded launches' one sorted list, dk_sorted_top.h -- states the same rules on positions; its way of
+taking a twin, by position, is one of the choices the random model makes.)
 
 What the data shows of the rules themselves (each switched off in turn, same searches): without (i)'s doubts at an eviction,
 without (ii)'s windows, or without the closing check on doubtful entries the comparison fails within a few hundred searches;
