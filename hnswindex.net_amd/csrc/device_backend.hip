@@ -1086,7 +1086,7 @@ bool Device::ensure_search_scratch(long long chunk, long long slots, int k, size
         HIP_OK(hipMalloc(&s_cnt_, sizeof(int) * s_jobs_cap_));
         HIP_OK(hipMalloc(&s_flag_, sizeof(int) * s_jobs_cap_));
     }
-    if (k > 0 && !grow_dev(&s_hits_, &s_hits_cap_, (size_t)chunk * k)) return false;
+    if (k > 0 && !grow_dev(&s_hits_, &s_hits_cap_, (size_t)chunk * k + ((size_t)chunk + 1) / 2)) return false; // ids, distances, and (single-launch calls) the flags behind them
     if (!grow_dev(&s_spill_, &s_spill_cap_, (size_t)slots * kSpillCap + 8)) return false; // +8: get2 may read one entry past a heap
     if (!s_evals_) HIP_OK(hipMalloc(&s_evals_, sizeof(unsigned long long)));
     if (!ev0_) { hipEvent_t a, b; HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); ev0_ = a; ev1_ = b; }
@@ -1713,6 +1713,14 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
     int *h_flag = reinterpret_cast<int *>(hs + 16 + b_jobs + 2 * b_res);
     int *d_ids = reinterpret_cast<int *>(s_hits_);
     float *d_d = reinterpret_cast<float *>(s_hits_) + (size_t)chunk * k_out;
+    // A call answered by ONE launch of modest size is mostly API calls around a latency-bound kernel (a single query: 0.37 ms
+    // of kernel in a 0.45-ms call, eleven HIP calls): ids, distances and flags then sit in one device slab and come back in
+    // one copy into the pinned staging (laid out alike), the evaluation counter lives in the job counter's spare words and
+    // is zeroed with it -- five HIP calls.  (A large call keeps the separate copies: its ids are handed to the caller while
+    // the distances are still crossing the link.)
+    const bool compact = njobs == chunk && 2 * b_res + 4u * (size_t)chunk <= (size_t)1 << 20;
+    int *d_flag = compact ? reinterpret_cast<int *>(d_d + (size_t)chunk * k_out) : s_flag_;
+    unsigned long long *d_ev = compact ? reinterpret_cast<unsigned long long *>(s_jobctr_ + 2) : s_evals_;
     // (rows of more than 1 KB: the set's traffic is small beside the rows', and the rows of re-seen neighbours are what costs --
     //  C3's 3-KB rows: 282.7 k queries/s with the sets against 273.6 k without, build 69.5 k against 61.3 k adds/s)
     const bool novis_ = g_stride0_ - 2 <= 64 && overlap_mode() != 0 && (size_t)pitch_ * sizeof(float) <= 1024 && (novis_mode() == 2 || (novis_mode() == 1 && vis_tab != nullptr));
@@ -1753,14 +1761,14 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
             stats_.entry_block_launches++;
         }
         HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int) * (4 + (size_t)nj), st));
-        HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
+        if (!compact) HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
         const bool timed = profiling_;
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
 #define LAUNCH2L(M, NS_, H_, LAT_, SLOTS, GRID, LDS, CAP) \
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_, LAT_>), dim3(std::min<int>(GRID, SLOTS)), \
                        dim3(LAT_ ? 128 : 64), (LDS) + (LAT_ ? kTeamLds : 0), st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, s_flag_, s_evals_, nbcap(), GRID, s_jobctr_, (novis_ ? 9 : (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, d_flag, d_ev, nbcap(), GRID, s_jobctr_, (novis_ ? 9 : (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
                        gate)
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \
@@ -1797,6 +1805,12 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
 #undef LAUNCH2L
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         if (tail_.n > 0 && !upload_tail()) return false; // the rest of the query set, while the launch above is running
+        if (compact) { // [ids | distances | flags] in one piece (nj == chunk: the device slab and the staging are laid out alike)
+            HIP_OK(hipMemcpyAsync(h_ids, d_ids, 2 * b_res + sizeof(int) * (size_t)nj, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(h_ev, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            memcpy(out_ids + (size_t)off * k_out, h_ids, 4u * (size_t)nj * k_out);
+        } else {
         // the ids are copied out to the caller's array while the distances are still crossing the link
         HIP_OK(hipMemcpyAsync(h_ids, d_ids, 4u * (size_t)nj * k_out, hipMemcpyDeviceToHost, st));
         HIP_OK(hipEventRecord((hipEvent_t)ev2_, st));
@@ -1806,6 +1820,7 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
         HIP_OK(hipEventSynchronize((hipEvent_t)ev2_));
         memcpy(out_ids + (size_t)off * k_out, h_ids, 4u * (size_t)nj * k_out);
         HIP_OK(hipStreamSynchronize(st));
+        }
         memcpy(out_d + (size_t)off * k_out, h_d, 4u * (size_t)nj * k_out);
         for (int i = 0; i < nj; ++i) {
             if (h_flag[i] == 2) { stats_.search_repeats++; if (!keep_repeat_flag) h_flag[i] = 0; }
