@@ -11,19 +11,23 @@ namespace hnsw {
 // nothing SearchLayer does needs an order: it removes the closest open candidate (:146), replaces the farthest result
 // when a closer one arrives (:165-178) and asks for the farthest distance -- a minimum and a maximum.  So the logic wave
 // of the latency variants keeps the k results in register slots in no particular order (slot s in lane s mod 64 of
-// register set s / 64; bit 31 of the id = expanded, bit 30 = doubtful, as in SortedTop) and runs the reference's own
-// loop on them: pop = wave-wide minimum over the open slots (four DPP steps inside the rows of 16 lanes, four readlanes),
-// push = the slot of the farthest entry takes the newcomer, then a wave-wide maximum; the list is sorted ONCE, when the
-// search is over (ranks by counting through LDS), and handed on ascending like the sorted list's.
+// register set s / 64; bit 31 of the id = expanded; bit 30 = doubtful, set only when the list is handed on) and runs the
+// reference's own loop on them: pop = wave-wide minimum over the open slots (six fused DPP steps, one readlane), push = the
+// farthest entry rewrites itself under the mask of the compare that found it, then a wave-wide maximum; the list is
+// sorted ONCE, when the search is over (ranks by counting through LDS), and handed on ascending like the sorted list's.
 // Equal distances: the rules of traverse_sorted, stated on keys instead of positions.  (i) the farthest result leaves
 // while another entry has its distance (the maximum does not change): the survivors of that distance become doubtful
-// (hard unless the one that left and all of them were expanded); (ii) the closest open candidate has an open twin: a
-// group window opens (members counted by key; closes at the first pop beyond the key with all members still present);
+// (hard unless the one that left and all of them were expanded) -- ONE bit of state: they are the entries of key far_key
+// until that key changes; (ii) the popped candidate has an open twin -- read off the next lookup: the closest open key
+// still equals the popped one -- a group window opens (members counted by key; closes at the first pop beyond the key
+// with all members still present);
 // (a), (b), (d) inside a window and (c) at its end as there; (iii) is read off the sorted output.  Which of several
-// equal entries a minimum or maximum picks differs from the sorted list (lowest slot here, first position there) -- in
-// exactly the situations these rules either prove immaterial or hand to the exact two-heap traversal.
+// equal entries a minimum or maximum picks differs from the sorted list (lowest lane here, first position there) -- in
+// exactly the situations these rules either prove immaterial or hand to the exact two-heap traversal
+// (tests/test_pool_rules_model.py: the rules in Python with twins taken at random, against the oracle's SearchLayer).
 // v_writelane_b32: a uniform value into ONE lane of a register.  (No builtin reaches it.  One scalar register per VALU
-// instruction on this ISA: the lane select goes through M0, as the compiler's own lowering of the intrinsic does.)
+// instruction on this ISA: the lane select goes through M0, as the compiler's own lowering of the intrinsic does.)  The pool
+// no longer writes through it -- see lanes_set below -- tools/pool_probe.hip keeps the forms that did, for comparison.
 __device__ __forceinline__ int lane_write(int value, int lane_sel, int old)
 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(value), "s"(lane_sel) : "m0");
