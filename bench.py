@@ -11,13 +11,15 @@ a drop-in caller sees).  The same step with the query set already resident in HB
 (`resident_queries_per_sec`).  Timed: exactly K steps between (barrier + cuda.synchronize) pairs, max over ranks.
 One JSON line on rank 0.  `--sharding native`: ONE process, the library itself shards the call over N GPUs.
 
-The Add half of the metric is reported five ways (all on the same 1M index):
-  add_per_sec            the build: hnsw_add of the whole set, default schedule (snapshot batches)
+The Add half of the metric (all on the same 1M index):
+  add_per_sec            the build: hnsw_add of the whole set under the library's DEFAULT schedule -- snapshot batches capped at the
+                         host's hardware threads T, an interleaving the reference's Parallel.For (HNSWIndex.cs:70-78) can produce on
+                         a host with >= T threads
   add_modes.sequential   B = 1: the reference's HNSWIndex.Add(item), one call per item
   add_modes.exact_window the SAME graph as B = 1 (the only Add whose graph the reference defines) through
                          speculative windows with read-set validation, one call for the whole sample
-  add_modes.bounded      B = host-core count: what a Parallel.For on that host can hold in flight
-  add_modes.batched      one large batch on the built index
+  add_modes.bounded      the ladder B = 16 / 64 / 256 / 1024: each rung legal for a Parallel.For host with >= B threads
+  add_modes.batched      one snapshot of 32 768 items on the built index (opt-in: this build's own schedule, rounds 1-4's default)
 each beside the CPU restatement running the SAME schedule on the same vectors (graph hashes compared),
 plus `roofline_add` for the two build kernels.
 
@@ -39,8 +41,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-PROFILE_ROUND = "r4"
-PROFILE_FALLBACK = "r3"  # traffic / ceilings measured last round stay quoted until this round's passes are committed
+PROFILE_ROUND = "r5"
+PROFILE_FALLBACK = "r4"  # ceilings measured last round stay quoted until this round's passes are committed (traffic: only from a profile of THIS build, see below)
 
 
 def parse():
@@ -59,7 +61,8 @@ def parse():
     p.add_argument("--max-edges", type=int, default=16)
     p.add_argument("--ef-construction", type=int, default=200)
     p.add_argument("--ef-search", type=int, default=128)
-    p.add_argument("--insert-batch", type=int, default=65536, help="cap of a snapshot batch (a batch is also <= linked/16)")
+    p.add_argument("--insert-batch", type=int, default=0, help="cap of Add's snapshot batches for the build (a batch is also <= linked/16): 0 = the library's default, "
+                   "the host's hardware threads -- the items a Parallel.For on this host holds in flight; 65536 = the opt-in large snapshots of rounds 1-4")
     p.add_argument("--slots", type=int, default=0, help="lock-step search slots (0 = library default)")
     p.add_argument("--threads", type=int, default=0, help="host threads of the driver (0 = library default)")
     p.add_argument("--recall-queries", type=int, default=1000)
@@ -71,7 +74,9 @@ def parse():
     p.add_argument("--sharding", choices=["ranks", "native"], default="ranks",
                    help="N > 1: ranks = one process per GPU, torch.distributed over RCCL (what the driver launches); native = ONE process, "
                         "hnsw_knn_query shards over N device contexts inside the library (hnsw_mi355x_set_devices)")
-    p.add_argument("--bounded-adds", type=int, default=4096, help="sample inserted in calls of B = host cores, GPU and CPU")
+    p.add_argument("--bounded-ladder", default="16,64,256,1024", help="caps B of the bounded-concurrency Add ladder (a snapshot batch of B items is legal for a "
+                   "Parallel.For host with >= B threads); '' = skip")
+    p.add_argument("--bounded-adds", type=int, default=2048, help="sample per rung of the ladder: max(this, 16 batches' worth), GPU and CPU")
     p.add_argument("--batched-adds", type=int, default=32768, help="sample inserted as one batch, GPU and CPU (all cores)")
     p.add_argument("--recall-study-n", type=int, default=32768, help="index size of the bounded-concurrency recall comparison (0 = skip)")
     p.add_argument("--data", choices=["uniform", "clustered"], default="uniform",
@@ -128,6 +133,15 @@ def recall_of(x, q, k, metric, got_ids):
     gt = brute_force_topk(x_t, q, k, metric)
     del x_t
     return float(np.mean([len(set(gt[i]) & set(got_ids[i])) / k for i in range(q.shape[0])]))
+
+
+def cgroup_quota():
+    """CPUs this process's cgroup may use (cpu.max quota / period), or None: what .NET clamps Environment.ProcessorCount to."""
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:
+        return None
 
 
 def new_index(a, dev_index, capacity, insert_batch, devices=1):
@@ -200,7 +214,9 @@ def main():
 
     # ---------------- setup (untimed): data, index build, resident queries ----------------
     x = make_data(a.n, a.dim, 65537, a.metric, a.data)
-    extra_total = a.seq_adds + a.window_adds + a.bounded_adds + a.batched_adds
+    ladder = [int(b) for b in a.bounded_ladder.split(",") if b.strip()] if not a.no_add_modes else []
+    ladder_items = [max(a.bounded_adds, 16 * b) for b in ladder]   # per rung: at least 16 batches
+    extra_total = a.seq_adds + a.window_adds + sum(ladder_items) + a.batched_adds
     # process warm-up (untimed): a throw-away index loads the library's code objects and creates the HIP
     # context once -- 0.15 s on the first launch of every kernel family, which is not Add throughput
     if not a.no_process_warmup:
@@ -361,34 +377,59 @@ def main():
             if f.exists():
                 return f
         return ROOT / "profiles" / f"{PROFILE_ROUND}_{stem}"
+    build_id = hnswindex.net_amd.lib.hnsw_mi355x_build_id().decode()
+    traffic_note = "no PMC profile of this workload under profiles/"
     try:
         pm = json.loads(profile_file("pmc_traffic.json").read_text())
+        if pm.get("build_id") != build_id:   # counters of another build say nothing about this one's kernels: not quoted
+            traffic_note = (f"profiles/{profile_file('pmc_traffic.json').name} was measured on build {str(pm.get('build_id'))[:16]}, this library is build {build_id[:16]}: "
+                            "not quoted (tools/run_profiles_r5.sh re-measures)")
+            pm = {"configs": {}}
         for c in pm["configs"].values():
             w = c["workload"]
             if a.traversal == "device" and a.data == "uniform" and (w["n"], w["dim"], w["queries_per_gpu_per_step"], w["ef_search"], w["k"], w["max_edges"]) == \
                     (a.n, a.dim, per_gpu, a.ef_search, a.k, a.max_edges) and c["row_bytes_fetched"] == fetched_row_bytes:
                 traffic = round(c["graph_search_kernel"]["traffic_bytes_per_launch"])
                 traffic_add = {k: c[k] for k in ("insert_search", "link_half") if k in c}
+                traffic_note = f"FETCH_SIZE x calibration + WRITE_SIZE, separate --pmc passes on this build (profiles/{profile_file('pmc_traffic.json').name})"
     except Exception:
         pass
+    gather_same_table = None
     try:
-        gc = json.loads(profile_file("gather_ceilings.json").read_text())["rows"]
-        gather = gc.get(str(fetched_row_bytes))
+        gj = json.loads(profile_file("gather_ceilings.json").read_text())
+        gather = gj["rows"].get(str(fetched_row_bytes))          # table >> Infinity Cache (4 GiB)
+        table_bytes = a.n * fetched_row_bytes
+        for e in gj.get("by_table", []):                          # uniform random rows of a table of THIS configuration's size
+            if e["row_bytes"] == fetched_row_bytes and abs(e["table_bytes"] - table_bytes) <= 0.15 * table_bytes:
+                gather_same_table = e
     except Exception:
         pass
     roofline = {
         "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
         "algorithmic_bytes_per_launch": round(t_evals / max(1, t_launches) * st["row_bytes"]),
         "bytes_per_eval": st["row_bytes"], "evals_per_launch": round(t_evals / max(1, t_launches), 1),
         "launches": t_launches, "avg_launch_us": round(1e3 * k_ms / max(1, t_launches), 2),
         "kernel_time_share_of_step": round(kernel_s / dt, 4),
     }
-    if gather:  # what RANDOM gathers of rows this size reach on this chip (tools/gather_bench, table >> Infinity Cache), in rows fetched
-        rows_per_s = t_evals / kernel_s if kernel_s > 0 else 0.0
-        roofline["measured_gather_ceiling"] = {"row_bytes_fetched": fetched_row_bytes, "GBps": gather["best_GBps"], "rows_per_s": round(gather["rows_per_s"]),
-                                               "source": "profiles/" + profile_file("gather_ceilings.json").name}
-        roofline["frac_of_measured_gather"] = round(rows_per_s / gather["rows_per_s"], 4)
+    # What RANDOM gathers of rows this size reach on this chip (tools/gather_bench): the honest ceiling is the one measured on a table of the
+    # configuration's OWN size -- a 512-MB matrix half-lives in the 256-MiB Infinity Cache, and the counters and the kernel both see that.
+    src_g = "profiles/" + profile_file("gather_ceilings.json").name
+    rows_per_s = t_evals / kernel_s if kernel_s > 0 else 0.0
+    gref = gather_same_table or gather
+    if gref:
+        roofline["measured_gather_ceiling"] = {"row_bytes_fetched": fetched_row_bytes, "GBps": gref["best_GBps"], "rows_per_s": round(gref["rows_per_s"]),
+                                               "table": (f"{gref['table_bytes'] / 1e9:.2f} GB: this configuration's own matrix size" if gather_same_table else "4 GiB (16x the Infinity Cache)"),
+                                               "source": src_g}
+        roofline["frac_of_measured_gather"] = round(rows_per_s / gref["rows_per_s"], 4)
+    if gather and gather_same_table:
+        roofline["measured_gather_ceiling_beyond_cache"] = {"GBps": gather["best_GBps"], "rows_per_s": round(gather["rows_per_s"]), "table": "4 GiB (16x the Infinity Cache)"}
+    roofline["peak_note"] = ("`frac` divides by the 8 TB/s HBM peak (the contract's denominator). " +
+                             ("This matrix (%.2f GB) is small enough for the 256-MiB Infinity Cache to serve part of the rows, so `achieved` is cache-ASSISTED and can exceed what "
+                              "HBM alone gives a gather; frac_of_measured_gather prices the kernel against uniform random gathers from a table of the same size. " % (a.n * fetched_row_bytes / 1e9)
+                              if a.n * fetched_row_bytes < 2.0e9 else
+                              "This matrix (%.2f GB) is far beyond the Infinity Cache: frac_of_measured_gather is against what random gathers of such rows reach on this chip. " % (a.n * fetched_row_bytes / 1e9)) +
+                             "The figure that transfers to large indices is the C4-size one (profiles/).")
     # the Add half: graph_insert_search_kernel (search half + heuristic) and the link half, HIP events during the build
     bs = build_stats
     rb = bs["row_bytes"]
@@ -410,14 +451,21 @@ def main():
             "end_to_end_frac": round(add_evals * rb / build_s / 1e9 / HBM_PEAK_GBPS, 4),
         }
 
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    # threads of the CPU legs: this process's CPU share -- the cgroup quota where there is one (the GPU box: 16 of the host's 256
+    # hardware threads), else the affinity mask -- capped at 32; both host figures are printed beside it (cpu_baseline.host)
+    import math
+    quota = cgroup_quota()
+    cores = max(1, min(len(os.sched_getaffinity(0)), math.ceil(quota) if quota else 1 << 30, 32))
     rng_x = np.random.default_rng(65539)
     extra = rng_x.random((max(extra_total, 1), a.dim), dtype=np.float32)
     if a.metric == "ucosine":
         extra = (extra / np.sqrt((extra * extra).sum(axis=1, dtype=np.float32, keepdims=True))).astype(np.float32)
-    o1 = a.seq_adds; o2 = o1 + a.window_adds; o3 = o2 + a.bounded_adds
-    e_seq, e_win, e_bnd, e_bat = extra[:o1], extra[o1:o2], extra[o2:o3], extra[o3:extra_total]
-    B = cores  # bounded concurrency: what a Parallel.For over T = cores items holds in flight (HNSWIndex.cs:70-78)
+    o1 = a.seq_adds; o2 = o1 + a.window_adds; o3 = o2 + sum(ladder_items)
+    e_seq, e_win, e_bat = extra[:o1], extra[o1:o2], extra[o3:extra_total]
+    e_rung, _o = {}, o2   # bounded concurrency: a snapshot batch of B items = what a Parallel.For over T >= B threads can hold in flight (HNSWIndex.cs:70-78)
+    for b_, m_ in zip(ladder, ladder_items):
+        e_rung[b_] = extra[_o:_o + m_]; _o += m_
+    host_threads = hnswindex.net_amd.host_parallelism()
 
     cpu = None
     cpu_add = {}
@@ -443,6 +491,7 @@ def main():
         parity_d = bool(c_d.tobytes() == np.ascontiguousarray(res_d[:nm]).tobytes())
         cpu = {
             "value": round(nm / tm, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+            "host": {"hardware_threads_visible": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota, "threads_used": cores},
             "sample": f"{nm} of the step's queries on the product-built {a.n}-node graph imported into the C restatement "
                       f"(oracle/, AVX2+FMA, {cores} threads = Parallel.For over queries); ids/distances compared bit for bit with the GPU run",
             "single_thread_queries_per_s": round(n1 / t1, 1),
@@ -455,10 +504,9 @@ def main():
             t0 = time.perf_counter(); ref.add(e_seq); cpu_add["sequential"] = (a.seq_adds / (time.perf_counter() - t0), 1, ref.graph_hash())
             if a.window_adds:  # the exact window builds the SEQUENTIAL graph: the CPU's same schedule is one item after the other
                 t0 = time.perf_counter(); ref.add(e_win); cpu_add["exact_window"] = (a.window_adds / (time.perf_counter() - t0), 1, ref.graph_hash())
-            t0 = time.perf_counter()
-            for i in range(0, a.bounded_adds, B):
-                ref.add_batched(e_bnd[i:i + B], B, threads=cores)
-            cpu_add["bounded"] = (a.bounded_adds / (time.perf_counter() - t0), cores, ref.graph_hash())
+            for b_ in ladder:  # one add_batched call = the library's own batch loop under cap B (batches of exactly B on a graph this size)
+                t0 = time.perf_counter(); ref.add_batched(e_rung[b_], b_, threads=cores)
+                cpu_add[f"B{b_}"] = (e_rung[b_].shape[0] / (time.perf_counter() - t0), cores, ref.graph_hash())
             ref.reset_n_eval()
             t0 = time.perf_counter(); ref.add_batched(e_bat, 1 << 20, threads=cores)
             cpu_add["batched"] = (a.batched_adds / (time.perf_counter() - t0), cores, ref.graph_hash())
@@ -469,17 +517,23 @@ def main():
     # The traversal kernels run without a visited set: they count every row they MEASURE, a few per cent more than
     # the reference's evaluations (it skips neighbours it has seen).  The roofline's numerator is the ALGORITHMIC work -- the
     # reference's evaluations, counted by the CPU restatement on the sample it answered -- whenever that count is at hand.
+    # Two numerators, each under keys that mean the same thing in every run: *_rows_measured = what the device counted (always at hand),
+    # *_algorithmic = the reference's evaluations (None without the CPU leg).  `achieved` / `frac` / `evals_per_launch` are the
+    # ALGORITHMIC figures whenever they are known and say so in `achieved_basis`.
     roofline["rows_measured_per_launch"] = roofline["evals_per_launch"]
-    roofline["algorithmic_evals_source"] = "device counter (rows measured)"
+    roofline["achieved_rows_measured"], roofline["frac_rows_measured"] = roofline["achieved"], roofline["frac"]
+    roofline["achieved_algorithmic"] = roofline["frac_algorithmic"] = roofline["algorithmic_evals_per_launch"] = None
+    roofline["achieved_basis"] = "rows measured (device counter): no CPU leg in this run"
     if cpu is not None and kernel_s > 0 and a.traversal == "device":
         alg = min(t_evals, cpu["evals_per_query"] * per_gpu * ndev_native * max(1, t_launches) / max(1, ndev_native))
         achieved = alg * st["row_bytes"] / kernel_s / 1e9
         roofline.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "achieved_algorithmic": round(achieved, 1), "frac_algorithmic": round(achieved / HBM_PEAK_GBPS, 4),
                          "algorithmic_bytes_per_launch": round(alg / max(1, t_launches) * st["row_bytes"]),
-                         "evals_per_launch": round(alg / max(1, t_launches), 1),
-                         "algorithmic_evals_source": "reference evaluations per query (CPU restatement, cpu_baseline.evals_per_query) x queries per launch"})
-        if gather:
-            roofline["frac_of_measured_gather"] = round(alg / kernel_s / gather["rows_per_s"], 4)
+                         "evals_per_launch": round(alg / max(1, t_launches), 1), "algorithmic_evals_per_launch": round(alg / max(1, t_launches), 1),
+                         "achieved_basis": "reference evaluations per query (CPU restatement, cpu_baseline.evals_per_query) x queries per launch"})
+        if gref:
+            roofline["frac_of_measured_gather"] = round(alg / kernel_s / gref["rows_per_s"], 4)
 
     add_modes = None
     if not a.no_add_modes and world == 1:
@@ -519,27 +573,48 @@ def main():
             if "cpu_adds_per_sec" in d:
                 d["speedup_vs_one_cpu_core_same_graph"] = round(d["adds_per_sec"] / d["cpu_adds_per_sec"], 2)
             return d
+        def batched_leg():
+            ix.set_insert_batch_live(65536)
+            d = leg("batched", e_bat, max(1, a.batched_adds), f"one snapshot batch of {a.batched_adds} into the built index (opt-in cap 65536: this build's own schedule, "
+                    "not an interleaving any real host's Parallel.For produces; checked against its CPU restatement only)")
+            ix.set_insert_batch_live(a.insert_batch)
+            return d
+        def bounded_ladder():
+            # one hnsw_add call per rung under cap B: consecutive snapshot batches of B items (the library's own loop), CPU restatement
+            # of the same schedule beside it.  A rung is an interleaving HNSWIndex.Add(List)'s Parallel.For can produce iff B <= its threads.
+            out_l = {"host_hardware_threads": host_threads, "cgroup_cpu_quota": cgroup_quota(), "default_cap": host_threads,
+                     "note": "B items search one snapshot, then link in id order: legal for a Parallel.For host with >= B threads (HNSWIndex.cs:70-78). The library's "
+                             "default cap is this host's hardware threads; .NET additionally clamps its thread count to a cgroup CPU quota where one is set"}
+            for b_ in ladder:
+                ix.set_insert_batch_live(b_)
+                d = leg(f"B{b_}", e_rung[b_], e_rung[b_].shape[0], f"B={b_}: snapshot batches of {b_}; legal for a Parallel.For host with >= {b_} threads")
+                d["ms_per_batch"] = round(1e3 * e_rung[b_].shape[0] / d["adds_per_sec"] / max(1, e_rung[b_].shape[0] // b_), 3)
+                d["legal_on_this_host"] = bool(b_ <= host_threads)
+                d.pop("ms_per_call", None)
+                out_l[f"B{b_}"] = d
+            ix.set_insert_batch_live(a.insert_batch)
+            return out_l
         add_modes = {
             "sequential": leg("sequential", e_seq, 1, "B=1: HNSWIndex.Add(item) one at a time (HNSWIndex.cs:55-65), the reference-exact mode"),
             **({"exact_window": window_leg()} if a.window_adds and a.traversal == "device" else {}),
-            "bounded": leg("bounded", e_bnd, B, f"B={B} (= host cores): batches a Parallel.For over {B} threads can hold in flight (HNSWIndex.cs:70-78)"),
-            "batched": leg("batched", e_bat, max(1, a.batched_adds), f"one snapshot batch of {a.batched_adds} into the built index"),
+            "bounded": bounded_ladder(),
+            "batched": batched_leg(),
         }
         if a.recall_study_n and a.traversal == "device":
-            # does bounding the batch change the graph's quality?  Two full builds of a smaller index, same data
+            # does the cap change the graph's quality?  Full builds of a smaller index under every rung, beside the SEQUENTIAL graph
+            # (the only Add whose graph the reference defines, built here through exact windows) and the opt-in large snapshots
             ns = min(a.recall_study_n, a.n)
             xs, qs = x[:ns], q_all[:min(1000, nq_total)]
             rec = {}
-            for label, call in (("default_schedule", ns), (f"B{B}", B)):
-                sub = new_index(a, dev_index, ns, 65536)
+            for label, cap in [("sequential_graph", -256)] + [(f"B{b_}", b_) for b_ in ladder] + [("snapshot_65536", 65536)]:
+                sub = new_index(a, dev_index, ns, cap)
                 t0 = time.perf_counter()
-                for i in range(0, ns, call):
-                    sub.add(xs[i:i + call])
+                sub.add(xs)
                 tb = time.perf_counter() - t0
                 got, _ = sub.knn_query(qs, a.k)
                 rec[label] = {"recall_at_10": round(recall_of(xs, qs, a.k, a.metric, got), 4), "adds_per_sec": round(ns / tb, 1)}
                 del sub
-            add_modes["bounded"]["recall_study"] = {"n": ns, **rec}
+            add_modes["bounded"]["recall_study"] = {"n": ns, "queries": int(qs.shape[0]), **rec}
 
     # The headline data (i.i.d. uniform, the reference's own test distribution) has no neighbourhood structure at
     # this dimension, so recall@10 is low on CPU and GPU alike.  The same build and query on data that has some:
@@ -610,11 +685,11 @@ def main():
                         + ("(one process, the library shards the call over its device contexts)" if native else "(query set sharded over ranks, one all-gather of top-k)"),
             "n": a.n, "dim": a.dim, "queries_per_gpu_per_step": per_gpu, "queries_per_step": nq_total, "k": a.k, "max_edges": a.max_edges,
             "ef_construction": a.ef_construction, "ef_search": a.ef_search, "query_sets": R,
-            "add_mode": f"snapshot-batched, cap {a.insert_batch}",
+            "add_mode": f"snapshot-batched, cap {ix.insert_batch_cap}" + (" (the library default: this host's hardware threads)" if a.insert_batch == 0 else " (set by --insert-batch)"),
             "parallelism": (f"native: one process, query-shard x{ndev_native} device contexts, replicas copied device to device" if native else
                             f"query-shard x{world}, index replicated ({a.build if world > 1 else 'one build'})"),
         },
-        "entry_point": "hnsw_knn_query",
+        "entry_point": "hnsw_knn_query", "build_id": build_id,
         "collective_backend": (("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None), "rccl_ranks_seen": ranks_seen,
         "per_gpu_workload_equals_n1": bool(a.scaling == "weak"),
         "resident_queries_per_sec": round(nq_total / dt_resident, 1),
@@ -626,14 +701,16 @@ def main():
                        "recall_on_clustered_data is the same build and query on data that has structure",
         "recall_on_clustered_data": clustered,
         "add_per_sec": round(a.n / build_s, 1), "build_seconds": round(build_s, 3),
-        "add_schedule_reference_defined": False,
+        "add_schedule": {"cap": ix.insert_batch_cap, "default": a.insert_batch == 0, "host_hardware_threads": hnswindex.net_amd.host_parallelism(), "cgroup_cpu_quota": cgroup_quota(),
+                         "inside_reference_outcome_set_for_hosts_with_threads_at_least": ix.insert_batch_cap},
+        "add_schedule_in_reference_outcome_set": True, "add_schedule_reference_defined": False,
         "add_per_sec_reference_graph": (add_modes or {}).get("exact_window", {}).get("adds_per_sec"),
-        "add_note": "add_per_sec: hnsw_add of the whole set in one call with snapshot batches of up to tens of thousands of items (DESIGN.md 4). "
-                    "That schedule is THIS BUILD'S OWN: a snapshot that large is not an interleaving a T-thread Parallel.For can produce "
-                    "(HNSWIndex.cs:70-78); it is checked bit for bit against the builder's CPU restatement of the same schedule, and tied to the "
-                    "reference only through recall. add_per_sec_reference_graph: the graph the reference DEFINES -- HNSWIndex.Add(item) one item after "
-                    "the other (HNSWIndex.cs:55-65) -- built through exact windows on the same index (add_modes.exact_window; graph hash equal to the "
-                    "CPU restatement's sequential Add); add_modes.sequential is the same graph one call per item, add_modes.bounded a B = host-cores schedule",
+        "add_note": "add_per_sec: hnsw_add of the whole set in one call under the cap named in add_schedule -- by default the host's hardware threads T: snapshot batches of "
+                    "at most T items (T searches on one snapshot, then T links in id order) are an interleaving HNSWIndex.Add(List)'s Parallel.For (HNSWIndex.cs:70-78) can produce "
+                    "on a host with >= T threads, so an unchanged caller gets a graph from the reference's outcome set; checked bit for bit against the CPU restatement of the same "
+                    "schedule (add_modes.bounded, every rung). The reference DEFINES a graph only for HNSWIndex.Add(item) one item after the other (HNSWIndex.cs:55-65): "
+                    "add_per_sec_reference_graph builds that one through exact windows (add_modes.exact_window), add_modes.sequential is the same graph one call per item. "
+                    "add_modes.batched is the opt-in 65536-item snapshot of rounds 1-4 (hnsw_mi355x_set_insert_batch(65536)): ~10x the rate, outside any real host's outcome set",
         "build_evals": build_stats["evals"] + build_stats["search_evals"],
         "build_launches": build_stats["launches"] + build_stats["search_launches"],
         "replicas_identical": replicas_identical,

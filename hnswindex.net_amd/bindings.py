@@ -121,6 +121,10 @@ lib.hnsw_mi355x_set_profiling.restype = ct.c_int
 lib.hnsw_mi355x_set_profiling.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnsw_mi355x_index_set_insert_batch.restype = ct.c_int
 lib.hnsw_mi355x_index_set_insert_batch.argtypes = [ct.c_void_p, ct.c_int]
+lib.hnsw_mi355x_index_insert_batch.restype = ct.c_int
+lib.hnsw_mi355x_index_insert_batch.argtypes = [ct.c_void_p]
+lib.hnsw_mi355x_host_parallelism.restype = ct.c_int
+lib.hnsw_mi355x_host_parallelism.argtypes = []
 lib.hnsw_mi355x_device_count.restype = ct.c_int
 lib.hnsw_mi355x_device_count.argtypes = [ct.c_void_p]
 lib.hnsw_mi355x_get_stats_at.restype = ct.c_int
@@ -163,6 +167,11 @@ lib.hnswdev_step_wait.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnswdev_test_sqrt_rn.argtypes = [ct.c_int, ct.POINTER(ct.c_double), ct.POINTER(ct.c_double), ct.c_int]
 
 METRICS = {"sq_euclid": 0, "cosine": 1, "ucosine": 2, "sq_euclid_i8": 3}
+
+
+def host_parallelism() -> int:
+    """Hardware threads this process may run on = the default cap of Add's snapshot batches (include/hnsw_mi355x.h)."""
+    return int(lib.hnsw_mi355x_host_parallelism())
 
 
 def last_error() -> str:
@@ -267,8 +276,9 @@ class Index:
         return st.as_dict()
 
     def set_insert_batch(self, max_batch: int):
-        """1 = strictly sequential inserts (the reference's HNSWIndex.Add(item) semantics); -W = the same graph
-        built through speculative windows of W items (see include/hnsw_mi355x.h)."""
+        """Cap of Add's snapshot batches.  0 (default) = the host's hardware threads: what the reference's Parallel.For can hold
+        in flight here; 1 = strictly sequential inserts (HNSWIndex.Add(item)); -W = the same graph built through speculative
+        windows of W items; larger caps (65536: rounds 1-4's schedule) are opt-in (see include/hnsw_mi355x.h)."""
         self._check(lib.hnsw_mi355x_set_insert_batch(max_batch))
 
     def set_insert_batch_live(self, max_batch: int):
@@ -276,6 +286,11 @@ class Index:
         if not self._h:
             return self.set_insert_batch(max_batch)
         self._check(lib.hnsw_mi355x_index_set_insert_batch(self._h, max_batch))
+
+    @property
+    def insert_batch_cap(self) -> int:
+        """The cap this index's Add runs under (the resolved default when nothing was set)."""
+        return int(lib.hnsw_mi355x_index_insert_batch(self._h)) if self._h else host_parallelism()
 
     def exact_window_stats(self):
         """Counters of the exact-window Add: rounds, searches run, items inserted alone, items linked through windows."""

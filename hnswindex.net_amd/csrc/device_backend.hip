@@ -1266,6 +1266,8 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
             HIP_OK(hipGetLastError());
             HIP_OK(hipMemcpyAsync(hb, db, need - b_rep, hipMemcpyDeviceToHost, st)); // selections, counts, flags, evaluations, read logs, dry-run codes, lost ids
         }
+        const bool last_chunk = off + nj >= njobs;
+        if (!windowed && last_chunk) HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st)); // the flags ride on the same wait
         HIP_OK(hipStreamSynchronize(st)); // the job staging buffer is reused by the next chunk
         stats_.search_launches++;
         stats_.search_evals += *h_ev;
@@ -1283,12 +1285,8 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
             stats_.insert_timed_evals += *h_ev;
         }
     }
-    // Only the flags come back now: the selections stay on the device, where the link half reads them
-    // (link_batch_planned); a caller that links on the host fetches them (fetch_insert_selections).
-    if (!windowed) {
-        HIP_OK(hipMemcpyAsync(h_flag, s_iflag_, b_flag, hipMemcpyDeviceToHost, st));
-        HIP_OK(hipStreamSynchronize(st));
-    }
+    // Only the flags come back (with the last launch's wait): the selections stay on the device, where the link half reads
+    // them (link_batch_planned); a caller that links on the host fetches them (fetch_insert_selections).
     int *h_rep = windowed ? h_log + (b_log + b_dry + b_drop) / 4u : nullptr;
     for (int i = 0; i < njobs; ++i) {
         if (h_rep) h_rep[i] = h_flag[i] == 2;
@@ -1450,7 +1448,7 @@ bool Device::link_batch_begin(int set, const int *rows, int nrows, int row_strid
 #define LAUNCH(M)                                                                                                          \
     hipLaunchKernelGGL(graph_link_kernel<M>, dim3(ngroups), dim3(64), lds, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_,  \
                        g_upper_, g_pool_, g_strideU_, s_lk_[1], s_lk_[1] + ngroups, s_lk_[2], (const int *)nullptr, s_lk_[3], max_edges0, k_cap, \
-                       s_lk_[4], list_stride, s_evals_, nbcap(), g_tested0_, g_testedU_)
+                       s_lk_[4], list_stride, s_evals_, nbcap(), g_tested0_, g_testedU_, (const int *)nullptr)
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
         else if (metric_ == M_I8) LAUNCH(M_I8);
@@ -1551,26 +1549,32 @@ bool Device::link_batch_planned(int njobs, int n_upper, int max_edges0)
     hipLaunchKernelGGL(link_plan_kernel<false>, dim3(njobs), dim3(64), 0, st, s_jobs_, s_sel_, s_lcnt_, s_selU_, s_cntU_, last_insert_stride_,
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, g_tested0_, g_testedU_, max_edges0, P);
     HIP_OK(hipGetLastError());
-    // the number of groups comes back to size the last two launches (16 bytes, one short wait)
+    // the number of groups comes back to size the last two launches (16 bytes, one short wait) -- except for small batches
+    // (bounded-concurrency Add: a few hundred items per batch, a batch every 1-3 ms), which launch the upper bound
+    // instead and let the surplus blocks leave at once
     unsigned long long *h_ev = static_cast<unsigned long long *>(pinned_stage(32));
     if (!h_ev) return false;
     int *h_ctr = reinterpret_cast<int *>(h_ev + 1);
-    HIP_OK(hipMemcpyAsync(h_ctr, lp_counters_, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
-    HIP_OK(hipStreamSynchronize(st));
-    const int G = h_ctr[0];
-    if (h_ctr[3] != 0 || G < 0 || (size_t)G > g_cap) {
-        set_dev_error("link_batch_planned: inconsistent selection data on the device (guard " + std::to_string(h_ctr[3]) + ")");
-        return false;
+    const bool bounded = njobs <= 4096;
+    int G = (int)std::min<size_t>(max_appends - 1, g_cap);
+    if (!bounded) {
+        HIP_OK(hipMemcpyAsync(h_ctr, lp_counters_, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        G = h_ctr[0];
+        if (h_ctr[3] != 0 || G < 0 || (size_t)G > g_cap) {
+            set_dev_error("link_batch_planned: inconsistent selection data on the device (guard " + std::to_string(h_ctr[3]) + ")");
+            return false;
+        }
     }
     if (G > 0) {
-        hipLaunchKernelGGL(link_order_kernel, dim3(G), dim3(64), 0, st, s_jobs_, g_upper_, g_strideU_, lp_grp_[5], P);
+        hipLaunchKernelGGL(link_order_kernel, dim3(G), dim3(64), 0, st, s_jobs_, g_upper_, g_strideU_, lp_grp_[5], P, bounded ? 1 : 0);
         HIP_OK(hipGetLastError());
-            const int k_cap = nbcap();
+        const int k_cap = nbcap();
         const size_t lds = ((search_lds_bytes(k_cap, 0, pitch_, true, nbcap()) + 15) & ~(size_t)15) + 4u * (size_t)(kNewMax + 1) * nbcap();
 #define LAUNCH(M)                                                                                                          \
     hipLaunchKernelGGL(graph_link_kernel<M>, dim3(G), dim3(64), lds, st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_,       \
                        g_upper_, g_pool_, g_strideU_, lp_grp_[0], lp_grp_[1], lp_grp_[2], lp_grp_[3], lp_grp_[5], max_edges0, k_cap, \
-                       (int *)nullptr, 0, s_evals_, nbcap(), g_tested0_, g_testedU_)
+                       (int *)nullptr, 0, s_evals_, nbcap(), g_tested0_, g_testedU_, bounded ? (const int *)lp_counters_ : (const int *)nullptr)
         if (metric_ == M_SQ) LAUNCH(M_SQ);
         else if (metric_ == M_COS) LAUNCH(M_COS);
         else if (metric_ == M_I8) LAUNCH(M_I8);
@@ -1582,7 +1586,7 @@ bool Device::link_batch_planned(int njobs, int n_upper, int max_edges0)
     HIP_OK(hipMemcpyAsync(h_ev, s_evals_, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_OK(hipMemcpyAsync(h_ctr, lp_counters_, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    if (h_ctr[3] != 0) {
+    if (h_ctr[3] != 0 || h_ctr[0] < 0 || (size_t)h_ctr[0] > g_cap) {
         set_dev_error("link_batch_planned: inconsistent selection data on the device (guard " + std::to_string(h_ctr[3]) + ")");
         return false;
     }

@@ -286,10 +286,14 @@ graph_link_kernel(const float *__restrict__ rows, const double *__restrict__ row
                   const int *__restrict__ g_node, const int *__restrict__ g_layer, const int *__restrict__ g_off,
                   const int *__restrict__ g_count, const int *__restrict__ g_items, int max_edges0, int k_cap,
                   int *__restrict__ out_lists, int list_stride,
-                  unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU)
+                  unsigned long long *__restrict__ eval_counter, int nbcap, int *__restrict__ tested0, int *__restrict__ testedU,
+                  const int *__restrict__ n_groups)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int g = blockIdx.x;
+    // launched with an upper bound of the group count (small batches: no read-back in between); n_groups = the link plan's
+    // counters: [0] groups, [3] the guard word -- nothing is dereferenced once a guard has tripped
+    if (n_groups && (g >= n_groups[0] || n_groups[3] != 0)) return;
     int t = g_off[g];
     const int t_end = g_count ? t + g_count[g] : g_off[g + 1]; // CSR offsets, or start + count per group
     link_group<METRIC>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, g_node[g], g_layer[g],
@@ -448,9 +452,10 @@ link_offsets_kernel(const int64_t *__restrict__ upper, int strideU, LinkPlan P)
 // counters return to zero for the next batch
 #ifdef HNSW_HOST_TU // non-template kernels: only the unit that launches them defines them
 __global__ void __launch_bounds__(64)
-link_order_kernel(const SearchJob *__restrict__ jobs, const int64_t *__restrict__ upper, int strideU, int *__restrict__ items_out, LinkPlan P)
+link_order_kernel(const SearchJob *__restrict__ jobs, const int64_t *__restrict__ upper, int strideU, int *__restrict__ items_out, LinkPlan P, int bounded)
 {
     const int g = blockIdx.x, lane = threadIdx.x;
+    if (bounded && (g >= min(P.counters[0], P.g_cap) || P.counters[3] != 0)) return; // grid = an upper bound of the group count
     const int node = P.g_node[g], layer = P.g_layer[g], start = P.g_start[g], n_items = P.g_count[g];
     if (!(node >= 0 && node < P.n_nodes && layer >= 0 && start >= 0 && n_items >= 0 && (long long)start + n_items <= P.g_cap)) {
         atomicCAS(&P.counters[3], 0, 8);

@@ -243,10 +243,17 @@ API int hnsw_mi355x_knn_query_resident(void *h, int k, int *out_ids, float *out_
 }
 API int hnsw_mi355x_index_set_insert_batch(void *h, int max_batch)
 {
-    if (!h || max_batch == 0 || max_batch == -1) { set_error("insert batch must be >= 1, or -W with W >= 2"); return -1; }
+    if (!h || max_batch == -1) { set_error("insert batch must be >= 1, 0 (the host's hardware threads), or -W with W >= 2"); return -1; }
     LOCK_INDEX(h);
     static_cast<HnswIndex *>(h)->set_insert_batch(max_batch);
     return 0;
+}
+API int hnsw_mi355x_host_parallelism(void) { return HnswIndex::host_parallelism(); }
+API int hnsw_mi355x_index_insert_batch(void *h)
+{
+    if (!h) return 0;
+    LOCK_INDEX(h);
+    return static_cast<HnswIndex *>(h)->insert_batch_cap();
 }
 API int hnsw_mi355x_exact_window_stats(void *h, uint64_t out[4])
 {

@@ -659,6 +659,8 @@ HnswIndex *HnswIndex::create(int metric, const Params &p, std::string &err)
     return ix;
 }
 
+int HnswIndex::host_parallelism() { return (int)std::max(1u, std::thread::hardware_concurrency()); }
+
 HnswIndex::~HnswIndex()
 {
     if (g_pt.on)
@@ -1390,7 +1392,7 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
     if (g_pt.on) g_pt.add_upload += now_s() - t_nodes0;
     // GraphConnector.ConnectNewNode (:24-47), batched
     const int m = (int)fresh.size();
-    const int bmax = std::max(1, p_.insert_batch); // a negative cap selects the exact window below (1 where that cannot run)
+    const int bmax = std::max(1, insert_batch_cap()); // a negative cap selects the exact window below (1 where that cannot run)
     int p = 0;
     std::vector<int> bid;
     if (p_.insert_batch < 0 && m >= 2 && !any_reused && p_.device_traversal && dev_->traversal_fits(p_.max_candidates, true, p_.max_edges)) {

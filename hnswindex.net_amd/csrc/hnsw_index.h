@@ -29,8 +29,12 @@ struct Params {
     bool allow_removals = true;
     // backend
     int device = -1;         // -1: HNSW_MI355X_DEVICE or 0
-    int insert_batch = 65536; // cap of a snapshot batch (which is also <= linked/16); 1 = strictly sequential inserts;
-                              // -W = the sequential graph through speculative windows of W items (insert_exact_window)
+    int insert_batch = 0;     // cap of a snapshot batch (which is also <= linked/16).  0 (default) = the host's hardware threads:
+                              // B items searching one snapshot and linking in id order is an interleaving the reference's
+                              // Parallel.For (HNSWIndex.cs:70-78) can produce iff B <= its threads, so the default stays inside
+                              // the reference's outcome set on this host; larger caps (the 65 536-item snapshots of rounds 1-4)
+                              // are opt-in.  1 = strictly sequential inserts; -W = the sequential graph through speculative
+                              // windows of W items (insert_exact_window)
     int remove_batch = 1;     // > 1: hnsw_remove takes removals with disjoint neighbourhoods together (snapshot batches of up to this many)
     int search_slots = 16384;
     int host_threads = 0;    // 0: min(hardware threads, 16)
@@ -81,6 +85,11 @@ public:
     Device *device() { return dev_.get(); }
     uint64_t graph_hash();
     void set_insert_batch(int v) { p_.insert_batch = v; }
+    // Threads this process may run on (std::thread::hardware_concurrency(): the affinity mask on Linux) = what bounds the items a
+    // Parallel.For on this host holds in flight.  (.NET also clamps Environment.ProcessorCount to a cgroup CPU quota; a
+    // container host that wants that bound passes it to hnsw_mi355x_set_insert_batch itself.)
+    static int host_parallelism();
+    int insert_batch_cap() const { return p_.insert_batch == 0 ? host_parallelism() : p_.insert_batch; }
     void exact_window_stats(uint64_t out[4]) const { out[0] = xw_rounds_; out[1] = xw_searches_; out[2] = xw_alone_; out[3] = xw_linked_; }
     void set_profiling(bool on)
     {

@@ -96,18 +96,27 @@ int hnsw_set_allow_removals(bool allow_removals);        /* :268 */
 /* Pending, like hnsw_set_*: HIP device ordinal for the next hnsw_create (default: the
  * HNSW_MI355X_DEVICE environment variable, else 0). */
 int hnsw_mi355x_set_device(int device);
-/* Pending: cap on the snapshot batch of hnsw_add (1 = strictly sequential inserts;
- * default 65536; a batch also never exceeds 1/16 of the linked graph -- 1/4 of it during the first
- * min(65 536, final count / 16) inserts).  See DESIGN.md "Add".
- * max_batch = -W (W >= 2): the graph of strictly sequential inserts -- HNSWIndex.Add(item) per item,
- * src/HNSWIndex/HNSWIndex.cs:55-65 -- built through speculative windows: W consecutive items search one
- * snapshot and record the adjacency lists they read; in item order, an item whose lists nobody has written since
- * is linked, the first one that is not ends the round and searches again.  Same graph as max_batch = 1, bit for
- * bit (DESIGN.md "exact window"). */
+/* Pending: cap B on the snapshot batch of hnsw_add: B consecutive items search the graph as it stands, then link in id
+ * order (a batch also never exceeds 1/16 of the linked graph -- 1/4 of it during the first min(65 536, final count / 16)
+ * inserts).  That is an interleaving the reference's HNSWIndex.Add(List) -- a Parallel.For over the items,
+ * src/HNSWIndex/HNSWIndex.cs:70-78 -- can produce iff B <= the threads it runs on, so:
+ *   0 (default)  B = hnsw_mi355x_host_parallelism(), the hardware threads of this host: the graph stays inside the
+ *                reference's outcome set on this machine;
+ *   1            strictly sequential inserts, HNSWIndex.Add(item) per item (HNSWIndex.cs:55-65);
+ *   B > 1        that cap, legal for a Parallel.For host with >= B threads; caps far beyond any host (the 65 536 of rounds
+ *                1-4, ~10x the build rate) are this build's own schedule -- opt-in, checked only against its CPU restatement;
+ *   -W (W >= 2)  the graph of strictly sequential inserts built through speculative windows: W consecutive items search
+ *                one snapshot and record the adjacency lists they read; in item order, an item whose lists nobody has
+ *                written since is linked, the first one that is not ends the round and searches again.  Same graph as
+ *                max_batch = 1, bit for bit (DESIGN.md "exact window").
+ * See DESIGN.md "Add". */
 int hnsw_mi355x_set_insert_batch(int max_batch);
 /* The same knob on an existing index (takes effect with the next hnsw_add): lets one index be continued under
  * another schedule, as bench.py's add_modes do. */
 int hnsw_mi355x_index_set_insert_batch(void *handle, int max_batch);
+/* The threads this process may run on (affinity mask) -- the default cap above -- and the cap an index is using. */
+int hnsw_mi355x_host_parallelism(void);
+int hnsw_mi355x_index_insert_batch(void *handle);
 /* Counters of the exact-window schedule since the index was created: out[0] rounds (dependent search launches),
  * out[1] insert searches run (>= items: the re-searched ones count again), out[2] items inserted alone (entry-point
  * moves, hand-backs), out[3] items linked through windows. */

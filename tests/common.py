@@ -43,3 +43,10 @@ def novis_active(stats):
     import os
     mode = os.environ.get("HNSW_MI355X_NOVIS", "2")
     return mode == "2" or (mode == "1" and stats.get("visited_hash_launches", 0) > 0)
+
+
+def default_cap():
+    """The cap of Add's snapshot batches when nothing is set: the host's hardware threads (include/hnsw_mi355x.h,
+    hnsw_mi355x_set_insert_batch) -- the oracle restates the default schedule as add_batched(x, default_cap())."""
+    import hnswindex
+    return hnswindex.net_amd.host_parallelism()

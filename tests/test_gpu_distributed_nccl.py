@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle
-from common import uniform
+from common import default_cap, uniform
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +57,7 @@ def test_nccl_group_and_library_coexist():
             for _ in range(2):
                 e_ids, e_d = hnswindex.net_amd.distributed.knn_query_sharded(ix.knn_query, q, 10, _always_exchange=True, **kw)
                 assert (e_ids == ids).all() and np.ascontiguousarray(e_d).tobytes() == d.tobytes()
-        ref = oracle.OracleIndex(64, collection_size=3000); ref.add_batched(x, 16384)
+        ref = oracle.OracleIndex(64, collection_size=3000); ref.add_batched(x, default_cap())
         assert (ref.knn_query(q, 10)[0] == ids).all()
     finally:
         dist.destroy_process_group()

@@ -25,6 +25,7 @@ def built():
     x = uniform(N, DIM, 65537)
     ix = hnswindex.Index(DIM)
     ix.set_collection_size(N); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_allow_removals(False)
+    ix.set_insert_batch(65536)                              # the opt-in large snapshots: full-size builds in seconds
     ids = ix.add(x)
     assert (ids == np.arange(N)).all()
     return ix, x
@@ -136,6 +137,7 @@ def test_c3_full_size_1m_768_ucosine():
         x[i:i + 250_000] = normalize_f32(x[i:i + 250_000])
     ix = hnswindex.Index(dim, "ucosine")
     ix.set_collection_size(n); ix.set_max_edges(M); ix.set_max_candidates(400); ix.set_min_nn(128); ix.set_allow_removals(False)
+    ix.set_insert_batch(65536)                              # the opt-in large snapshots: full-size builds in seconds
     ids = ix.add(x)
     assert (ids == np.arange(n)).all()
     _check_structure(ix, n, M)
@@ -162,6 +164,7 @@ def test_c4_size_10m_128_in_12500_query_calls():
     x = _uniform_chunked(n, dim, 65537)
     ix = hnswindex.Index(dim)
     ix.set_collection_size(n); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_allow_removals(False)
+    ix.set_insert_batch(65536)                              # the opt-in large snapshots: full-size builds in seconds
     ids = ix.add(x)                                          # default schedule (snapshot batches)
     assert ids[0] == 0 and ids[-1] == n - 1 and (np.diff(ids) == 1).all()
     _check_structure(ix, n, M)
@@ -197,6 +200,7 @@ def test_c5_size_10m_96_int8():
     x = _uniform_chunked(n, dim, 65537)
     ix = hnswindex.Index(dim, "sq_euclid_i8")
     ix.set_collection_size(n); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_allow_removals(False)
+    ix.set_insert_batch(65536)                              # the opt-in large snapshots: full-size builds in seconds
     ids = ix.add(x)
     assert ids[0] == 0 and ids[-1] == n - 1 and (np.diff(ids) == 1).all()
     _check_structure(ix, n, M)

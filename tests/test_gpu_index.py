@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from common import golden_cases, load_golden, normalize_f32, self_recall_at_1, uniform
+from common import default_cap, golden_cases, load_golden, normalize_f32, self_recall_at_1, uniform
 
 pytestmark = pytest.mark.gpu
 
@@ -222,7 +222,7 @@ def test_search_stats_count_device_evaluations(Index):
     s = ix.stats()
     assert s["search_launches"] == 1 and s["search_timed_launches"] == 1
     assert s["search_evals"] > 500 * 10 and s["search_kernel_ms"] > 0
-    ref = oracle.OracleIndex(64, collection_size=3000); ref.add_batched(x, 4096); ref.reset_n_eval(); ref.knn_query(q, 10)
+    ref = oracle.OracleIndex(64, collection_size=3000); ref.add_batched(x, default_cap()); ref.reset_n_eval(); ref.knn_query(q, 10)
     # same traversal => same evaluations, except that the oracle re-measures the layer-0 entry
     # point once per query (GraphNavigator.cs:200) and re-measures the start node on each upper layer
     from common import novis_active
@@ -422,7 +422,7 @@ def test_remove_all_one_by_one_and_disabled_removals(Index):
     x = uniform(200, 16, 5)
     ix = Index(16); ix.set_collection_size(10)
     ids = ix.add(x)
-    ref = oracle.OracleIndex(16, collection_size=10); ref.add_batched(x, 16384)
+    ref = oracle.OracleIndex(16, collection_size=10); ref.add_batched(x, default_cap())
     for k, i in enumerate(ids):
         ix.remove([i]); ref.remove([i])
         assert ix.count == 200 - k - 1
@@ -431,7 +431,7 @@ def test_remove_all_one_by_one_and_disabled_removals(Index):
     assert ix.entry_point == -1
     kid, kd = ix.knn_query(x[:2], 3)
     assert (kid == -1).all() and np.isnan(kd).all()
-    assert ix.add(x[:3]).tolist() == ref.add_batched(x[:3], 16384).tolist()   # rebuilt from empty, reusing slots
+    assert ix.add(x[:3]).tolist() == ref.add_batched(x[:3], default_cap()).tolist()   # rebuilt from empty, reusing slots
     iy = Index(16); iy.set_allow_removals(False)
     iy.add(x)
     with pytest.raises(RuntimeError, match="InvalidOperationException"):

@@ -14,6 +14,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+from common import default_cap
+
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
@@ -56,7 +58,7 @@ def test_streamed_upload_answers_like_the_plain_one_and_the_oracle(tmp_path, dim
     import oracle
     x = np.random.default_rng(5).random((3000, dim), dtype=np.float32)
     ref = oracle.OracleIndex(dim, "sq_euclid", collection_size=3000)
-    ref.add_batched(x, 65536)  # the default schedule of one hnsw_add call (orc_add_batched)
+    ref.add_batched(x, default_cap())  # the default schedule of one hnsw_add call (orc_add_batched, cap = the host's hardware threads)
     assert ref.graph_hash() == plain["graph_hash"]
     q = np.random.default_rng(102).random((nq, dim), dtype=np.float32)[:400]
     ids, d = ref.knn_query(q, 10)

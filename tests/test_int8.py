@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from common import uniform
+from common import default_cap, uniform
 
 DIMS = [4, 7, 33, 96, 100, 120, 128, 200, 768]
 
@@ -144,7 +144,7 @@ def test_hip_index_matches_oracle(net, traversal, dim, M, efc):
     ib.set_max_edges(M); ib.set_max_candidates(efc); ib.set_min_nn(40); ib.set_collection_size(n); ib.set_allow_removals(False)
     ib.set_device_traversal(traversal == "device")
     rb = oracle.OracleIndex(dim, "sq_euclid_i8", max_edges=M, max_candidates=efc, min_nn=40, collection_size=n, allow_removals=False)
-    ib.add(x); rb.add_batched(x, 65536)
+    ib.add(x); rb.add_batched(x, default_cap())
     assert ib.graph_hash() == rb.graph_hash()
     a_ids, a_d = ib.knn_query(q, 10)
     b_ids, b_d = rb.knn_query(q, 10)
