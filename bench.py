@@ -90,6 +90,8 @@ def parse():
     p.add_argument("--build", choices=["replicate", "broadcast"], default="replicate",
                    help="N > 1: replicate = every rank builds the same deterministic graph itself, in parallel (wall time of one build, "
                         "no communication; default); broadcast = rank 0 builds, the graph is broadcast (RCCL) and imported by the others")
+    p.add_argument("--dry-run", action="store_true", help="validate the launch plan of --gpus N (launcher, rendezvous, shard bounds, host and HBM memory per rank) and "
+                   "print it as one JSON line WITHOUT touching a GPU or building anything")
     p.add_argument("--traversal", choices=["device", "host"], default="device",
                    help="device: graph-resident search kernel (default); host: the literal north-star split -- traversal on "
                         "host threads, distances batched step by step through the inner C ABI (hnswdev_step_submit / _wait)")
@@ -174,8 +176,95 @@ def relaunch_for_gpus(a):
     raise SystemExit(subprocess.run(cmd).returncode)
 
 
+def dry_run(a):
+    """`bench.py --gpus N --dry-run`: everything that can be checked about an N-rank run without a GPU.  No multi-GPU measurement exists yet
+    (the pool gives one GPU per box); this makes sure the first real one does not die of a launcher, bounds or memory mistake."""
+    import importlib.util
+    native = a.sharding == "native" and a.gpus > 1
+    world = 1 if native else a.gpus
+    nshards = a.gpus
+    nq_total = a.nq * nshards if a.scaling == "weak" else a.nq
+    problems, notes = [], []
+    # shard bounds from the very function the step uses (hnswindex.net_amd/distributed.py::shard_bounds, loaded from its source text:
+    # importing the package would load the HIP library)
+    import typing
+    src = (ROOT / "hnswindex.net_amd" / "distributed.py").read_text()
+    i0 = src.index("def shard_bounds")
+    ns = {"Tuple": typing.Tuple}
+    exec(compile(src[i0:src.index("\n\n\n", i0)], "distributed.py::shard_bounds", "exec"), ns)
+    shards = [tuple(ns["shard_bounds"](nq_total, nshards, r)) for r in range(nshards)]
+    if shards[0][0] != 0 or shards[-1][1] != nq_total or any(shards[i][1] != shards[i + 1][0] for i in range(nshards - 1)):
+        problems.append("shards do not tile the query set")
+    if a.scaling == "weak" and any(hi - lo != a.nq for lo, hi in shards):
+        problems.append("weak scaling: a rank's shard differs from the N = 1 workload")
+    if min(hi - lo for lo, hi in shards) <= 0:
+        problems.append("a rank has no queries")
+    # launcher and rendezvous
+    if importlib.util.find_spec("torch.distributed.run") is None:
+        problems.append("torch.distributed.run not importable")
+    try:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    except OSError as e:
+        problems.append(f"cannot bind a rendezvous port on 127.0.0.1: {e}"); port = None
+    if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+        notes.append("HSA_ENABLE_IPC_MODE_LEGACY is not 0: RCCL needs dmabuf IPC on this pool")
+    gpus_visible = None
+    try:
+        import torch
+        gpus_visible = torch.cuda.device_count()   # counting devices does not initialise the GPU
+        if gpus_visible < a.gpus:
+            notes.append(f"{gpus_visible} GPUs visible here, the plan needs {a.gpus}: it can only be validated, not run, on this machine")
+    except Exception as e:  # noqa: BLE001
+        notes.append(f"torch not importable here ({type(e).__name__})")
+    # memory per rank: every rank generates the base vectors and ALL query sets on the host (deterministic seeds: no broadcast needed)
+    i8 = a.metric == "sq_euclid_i8"
+    row_b = (128 if a.dim <= 120 else ((a.dim + 8 + 63) // 64) * 64) if i8 else a.dim * 4
+    R = max(1, a.query_sets)
+    host = {"base_vectors_f32": a.n * a.dim * 4, "query_sets": R * nq_total * a.dim * 4,
+            "exchange_pinned": 2 * nq_total * a.k * 8, "result_arrays": 2 * nq_total * a.k * 8,
+            "library_pinned_staging": 64 << 20, "host_graph_copy": a.n * (2 * a.max_edges + 2) * 4 + a.n * 24}
+    per_gpu_q = max(hi - lo for lo, hi in shards)
+    hbm = {"rows": a.n * row_b, "graph_mirror_adj0": a.n * (2 * a.max_edges + 2) * 4, "upper_layers_levels_prefix": a.n * 16 + (a.n // 16 + 1) * (a.max_edges + 2) * 4 * 2,
+           "resident_queries": per_gpu_q * row_b, "results_jobs": per_gpu_q * (a.k * 8 + 64),
+           "per_wave_scratch": 256 * 20 * (8192 * 8 + (64 << 10) + (0 if a.n > 4_000_000 else (a.n + 7) // 8)),
+           "broadcast_staging": (a.n * (2 * a.max_edges + 2) * 4 if a.build == "broadcast" and world > 1 else 0)}
+    host_rank = sum(host.values())
+    procs = world
+    mem_total = None
+    try:
+        mem_total = int([l for l in open("/proc/meminfo") if l.startswith("MemTotal")][0].split()[1]) * 1024
+        cg = Path("/sys/fs/cgroup/memory.max").read_text().strip()
+        if cg != "max":
+            mem_total = min(mem_total, int(cg))
+    except Exception:  # noqa: BLE001
+        pass
+    if mem_total and host_rank * procs > 0.8 * mem_total:
+        problems.append(f"host memory: {procs} ranks x {host_rank / 2**30:.1f} GiB exceeds 80 % of the {mem_total / 2**30:.0f} GiB this process may use")
+    if sum(hbm.values()) > 0.9 * 288e9:
+        problems.append("HBM: a replica does not fit one MI355X (288 GB)")
+    cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            "bench.py"] + [x for x in sys.argv[1:] if x != "--dry-run"]) if not native else [sys.executable, "bench.py"] + [x for x in sys.argv[1:] if x != "--dry-run"]
+    print(json.dumps({
+        "dry_run": True, "ok": not problems, "problems": problems, "notes": notes,
+        "plan": {"gpus": a.gpus, "processes": procs, "sharding": "native (one process, n device contexts)" if native else "ranks (one process per GPU, torch.distributed nccl = RCCL)",
+                 "scaling": a.scaling, "queries_per_step_total": nq_total, "shards": shards, "collective_per_step": None if native else
+                 {"op": "all_gather_into_tensor", "bytes_per_rank": per_gpu_q * a.k * 8, "bytes_gathered": nq_total * a.k * 8},
+                 "build": a.build if world > 1 else "one build", "replica_check": "all_gather of the graph hash (replicas_identical)",
+                 "launch": " ".join(cmd), "children_started_before_any_gpu_call": True, "gpus_visible_here": gpus_visible},
+        "memory": {"host_bytes_per_rank": host, "host_GiB_per_rank": round(host_rank / 2**30, 2), "host_GiB_all_ranks": round(host_rank * procs / 2**30, 2),
+                   "host_GiB_available": round(mem_total / 2**30, 1) if mem_total else None,
+                   "hbm_bytes_per_gpu": hbm, "hbm_GiB_per_gpu": round(sum(hbm.values()) / 2**30, 2)},
+        "measured_on_more_than_one_gpu": False,
+        "note": "no N > 1 measurement exists: every multi-GPU path of this repository has run as ranks / contexts sharing ONE GPU only"}))
+    raise SystemExit(0 if not problems else 1)
+
+
 def main():
     a = parse()
+    if a.dry_run:
+        dry_run(a)
     native = a.sharding == "native" and a.gpus > 1
     if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not native:
         relaunch_for_gpus(a)
@@ -440,6 +529,8 @@ def main():
         in_kernel = add_evals * rb / (ins_s + lnk_s) / 1e9
         roofline_add = {
             "bound": "hbm", "kernels": "graph_insert_search_kernel + link half (link_plan/offsets/order + graph_link_kernel)",
+            "schedule": f"the build under cap {ix.insert_batch_cap}" + ("" if ix.insert_batch_cap >= 4096 else ": launches of a few hundred traversals that do not fill the chip -- bound by the dependent chain "
+                        "of ONE traversal (latency variants, DESIGN.md 3.6), not by bytes; the opt-in large snapshots' kernels are priced in add_modes.batched.roofline"),
             "achieved": round(in_kernel, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(in_kernel / HBM_PEAK_GBPS, 4),
             "traffic": (round(sum(v["traffic_bytes_total"] for v in traffic_add.values())) if len(traffic_add) == 2 else None),
             "traffic_over_algorithmic": ({k: round(v["traffic_over_algorithmic"], 3) for k, v in traffic_add.items()} or None),
@@ -575,9 +666,19 @@ def main():
             return d
         def batched_leg():
             ix.set_insert_batch_live(65536)
+            ix.set_profiling(True)          # HIP events around the two Add kernels of this one large snapshot: the opt-in schedule's roofline
             d = leg("batched", e_bat, max(1, a.batched_adds), f"one snapshot batch of {a.batched_adds} into the built index (opt-in cap 65536: this build's own schedule, "
                     "not an interleaving any real host's Parallel.For produces; checked against its CPU restatement only)")
+            sb = ix.stats()
+            ix.set_profiling(False)
             ix.set_insert_batch_live(a.insert_batch)
+            i_s, l_s = sb["insert_kernel_ms"] / 1e3, sb["link_kernel_ms"] / 1e3
+            if a.traversal == "device" and i_s > 0:
+                d["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "bytes_per_eval": sb["row_bytes"],
+                                 "insert_search": {"seconds": round(i_s, 5), "evals": sb["insert_timed_evals"], "frac": round(sb["insert_timed_evals"] * sb["row_bytes"] / i_s / 1e9 / HBM_PEAK_GBPS, 4)},
+                                 "link_half": {"seconds": round(l_s, 5), "evals": sb["link_timed_evals"], "frac": round(sb["link_timed_evals"] * sb["row_bytes"] / max(l_s, 1e-9) / 1e9 / HBM_PEAK_GBPS, 4)},
+                                 "frac": round((sb["insert_timed_evals"] + sb["link_timed_evals"]) * sb["row_bytes"] / (i_s + l_s) / 1e9 / HBM_PEAK_GBPS, 4),
+                                 "note": "rows the two kernels read (device-counted) x row bytes / HIP-event kernel time, one 32 768-item snapshot on the built index"}
             return d
         def bounded_ladder():
             # one hnsw_add call per rung under cap B: consecutive snapshot batches of B items (the library's own loop), CPU restatement

@@ -5,5 +5,5 @@ hnswindex.net_amd -- MI355X-native distance backend behind HNSWIndex.Net's own s
 ctypes handle of the C-ABI library (include/hnsw_mi355x.h).  Distances are computed only by
 the HIP kernels in csrc/; nothing in this package falls back to the CPU.
 """
-from .bindings import Index, DeviceBackend, lib, last_error, host_parallelism, LIB_PATH  # noqa: F401
+from .bindings import Index, DeviceBackend, lib, last_error, host_parallelism, set_options, default_options, Options, LIB_PATH  # noqa: F401
 from . import distributed  # noqa: F401

@@ -54,7 +54,8 @@ class Stats(ct.Structure):
                 ("range_launches", ct.c_uint64), ("range_evals", ct.c_uint64), ("range_timed_launches", ct.c_uint64),
                 ("range_timed_evals", ct.c_uint64), ("range_kernel_ms", ct.c_double), ("range_handbacks", ct.c_uint64),
                 ("replica_bytes", ct.c_uint64),
-                ("tie_windows", ct.c_uint64), ("peer_direct_copies", ct.c_uint64), ("peer_staged_copies", ct.c_uint64), ("entry_block_launches", ct.c_uint64), ("lat_launches", ct.c_uint64)]
+                ("tie_windows", ct.c_uint64), ("peer_direct_copies", ct.c_uint64), ("peer_staged_copies", ct.c_uint64), ("lat_launches", ct.c_uint64),
+                ("insert_tie_reruns", ct.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -167,6 +168,38 @@ lib.hnswdev_step_wait.argtypes = [ct.c_void_p, ct.c_int]
 lib.hnswdev_test_sqrt_rn.argtypes = [ct.c_int, ct.POINTER(ct.c_double), ct.POINTER(ct.c_double), ct.c_int]
 
 METRICS = {"sq_euclid": 0, "cosine": 1, "ucosine": 2, "sq_euclid_i8": 3}
+
+
+class Options(ct.Structure):
+    """hnsw_mi355x_options, version 1 (include/hnsw_mi355x.h): every knob of the backend."""
+    _fields_ = [("struct_size", ct.c_uint32), ("device", ct.c_int32), ("devices", ct.c_int32), ("insert_batch", ct.c_int32),
+                ("remove_batch", ct.c_int32), ("host_threads", ct.c_int32), ("search_slots", ct.c_int32), ("device_traversal", ct.c_int32),
+                ("diagnostics", ct.c_char_p)]
+
+
+lib.hnsw_mi355x_default_options.restype = ct.c_int
+lib.hnsw_mi355x_default_options.argtypes = [ct.POINTER(Options)]
+lib.hnsw_mi355x_set_options.restype = ct.c_int
+lib.hnsw_mi355x_set_options.argtypes = [ct.POINTER(Options)]
+
+
+def default_options() -> Options:
+    o = Options()
+    if lib.hnsw_mi355x_default_options(ct.byref(o)) != 0:
+        raise RuntimeError("hnsw_mi355x_default_options failed")
+    return o
+
+
+def set_options(**knobs) -> None:
+    """Sets the pending backend knobs for the next Index (defaults for whatever is not named): device, devices, insert_batch,
+    remove_batch, host_threads, search_slots, device_traversal, diagnostics (str or None)."""
+    o = default_options()
+    for k, v in knobs.items():
+        if k not in dict(Options._fields_) or k == "struct_size":
+            raise TypeError(f"unknown option {k!r}")
+        setattr(o, k, v.encode() if isinstance(v, str) else v)
+    if lib.hnsw_mi355x_set_options(ct.byref(o)) != 0:
+        raise RuntimeError(last_error())
 
 
 def host_parallelism() -> int:

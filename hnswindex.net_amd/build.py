@@ -30,17 +30,18 @@ def hipcc() -> str:
 BUILD_ID_TAG = b"HNSW_MI355X_BUILD_ID="
 
 
-def source_id() -> str:
+def source_id(extra=()) -> str:
     """sha256 over everything the library is compiled from: csrc/* and include/*, by name and content, plus the
-    compiler flags.  The same string is compiled into the library (hnsw_mi355x_build_id()), so a binary says which
-    sources it came from -- file times say nothing once a tree has been copied."""
+    compiler flags (and the extra flags of a diagnostic build).  The same string is compiled into the library
+    (hnsw_mi355x_build_id()), so a binary says which sources it came from -- file times say nothing once a tree has
+    been copied."""
     import hashlib
     h = hashlib.sha256()
     files = sorted(list(CSRC.glob("*")) + list((PKG.parent / "include").glob("*.h")), key=lambda f: f.name)
     for f in files:
         if f.is_file():
             h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(list(FLAGS) + sorted(extra)).encode())
     return h.hexdigest()
 
 
@@ -52,7 +53,10 @@ def embedded_id(lib: Path = None) -> str:
     except OSError:
         return ""
     i = blob.find(BUILD_ID_TAG)
-    return blob[i + len(BUILD_ID_TAG):i + len(BUILD_ID_TAG) + 64].decode("ascii", "replace") if i >= 0 else ""
+    if i < 0:
+        return ""
+    j = blob.find(b"\0", i)   # the WHOLE string up to its terminator: "<sha256>+variant" is not "<sha256>"
+    return blob[i + len(BUILD_ID_TAG):j if j >= 0 else i + len(BUILD_ID_TAG) + 64].decode("ascii", "replace")
 
 
 def needs_build() -> bool:
@@ -76,7 +80,7 @@ def build(force: bool = False, verbose: bool = False, out: Path = None) -> Path:
         extra = sorted(set(extra) | {"-DHNSW_SINGLE_TU"})
         sources = [s for s in sources if not s.startswith("traverse_")]
 
-    sid = source_id() if out is None and not extra else source_id() + "+variant"
+    sid = source_id() if out is None and not extra else source_id(extra) + "+variant"
 
     def compile_one(src):
         obj = OBJ / (Path(src).stem + ".o")

@@ -290,7 +290,7 @@ private:
     int *s_vistab_ = nullptr; // per-wave visited-id hash tables
     size_t s_vistab_cap_ = 0;
     int s_vistab_each_ = 0;
-    bool visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_cap, int min_cap = 512);
+    bool visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_cap, int min_cap = 512, bool allow_hash = true);
     int num_cu_ = 256;
     // Persistent launches never use more than 16 one-wave blocks per CU (the traversal kernels need
     // >= 128 VGPRs): the per-wave scratch (visited bitsets, spill areas, logs) is sized for that.
@@ -371,7 +371,6 @@ private:
     hnswdev_stats stats_{};
     bool shadows_allowed_ = true;
     int uj_len_ = 0, uj_entry_ = -1, uj_layer_ = -1; // s_jobs_ holds search_queries' jobs 0 .. uj_len_-1 for that entry point
-    bool uj_hinted_ = false;                          // ... with entry_block_kernel's hints of the LAST query set in them
     bool search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_out, int *out_ids, float *out_d, int *out_flag, bool keep_repeat_flag,
                            bool two_heap, int u_entry, int u_layer);
 };

@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "device_backend.h"
+#include "diag.h"
 #define HNSW_HOST_TU
 #include "device_kernels.h"
 #include "range_replay.h"
@@ -943,9 +944,8 @@ bool Device::set_graph(const int *adj0, long long n, int stride0, const int *lev
 // only.  HNSW_MI355X_SORTED_TOP=0 forces the latter (the tests run both).
 static int sorted_top_sets(int k)
 {
-    const char *e = std::getenv("HNSW_MI355X_SORTED_TOP");
-    if (e && std::atoi(e) == 0) return 0;
-    return k <= 64 ? 1 : k <= 128 ? 2 : k <= 256 ? 4 : k <= 512 ? 8 : 0;
+    if (diag("sorted_top", 1) == 0) return 0;
+    return k <= 128 ? 2 : k <= 256 ? 4 : k <= 512 ? 8 : 0; // (a beam of up to 64 entries runs in the two-set form as well)
 }
 constexpr long long kSortedTopMaxNodes = 1LL << 30; // the sorted list keeps two mark bits in the id word
 
@@ -953,8 +953,7 @@ int Device::max_waves_per_cu()
 {
     // 20 = five per SIMD: what the int8 kernels' 92 VGPRs allow (10M x 96 int8, 12 500-query calls: 2.19 M queries/s at
     // 16, 2.31 M at 20); the float kernels (168 VGPRs) keep 12 resident whatever this says
-    static const int v = [] { const char *e = std::getenv("HNSW_MI355X_MAX_WAVES_PER_CU"); return e ? std::max(1, std::min(32, std::atoi(e))) : 20; }();
-    return v;
+    return 20;
 }
 
 // Blocks (= waves) of a persistent traversal launch: what stays resident on the chip.
@@ -963,21 +962,20 @@ static int resident_blocks(K kernel, size_t lds, int num_cu, int threads = 64)
 {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1) per_cu = threads > 64 ? 4 : 8;
-    if (const char *e = std::getenv("HNSW_MI355X_WAVES_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e))); // experiments: fewer persistent waves
     return per_cu * std::max(1, num_cu);
 }
 
 static int cand_lds_cap(int k, int dim, bool heur, int nbcap)
 {
     int cap = std::min(std::max(4 * k, 256), 4096);
-    if (const char *e = std::getenv("HNSW_MI355X_CAND_CAP")) cap = std::max(1, std::atoi(e)); // tests: force spill / hand-back
+    if (const int c = diag("cand_cap", 0)) cap = std::max(1, c); // tests: force spill / hand-back
     while (cap > 64 && search_lds_bytes(k, cap, dim, heur, nbcap) > 64 * 1024) cap /= 2;
     return cap;
 }
 static int spill_cap_for_tests()
 {
-    if (const char *e = std::getenv("HNSW_MI355X_SPILL_CAP")) return std::max(0, std::min(kSpillCap, std::atoi(e)));
-    return kSpillCap;
+    const int c = diag("spill_cap", -1);
+    return c < 0 ? kSpillCap : std::min(kSpillCap, c);
 }
 
 
@@ -990,13 +988,11 @@ static int spill_cap_for_tests()
 // traversal of the jobs still running.  HNSW_MI355X_SHADOW=0 disables (tests run both).
 static bool shadow_mode()
 {
-    const char *e = std::getenv("HNSW_MI355X_SHADOW");
-    return !e || std::atoi(e) != 0;
+    return diag("shadow", 1) != 0;
 }
 static int overlap_mode()
 {
-    const char *e = std::getenv("HNSW_MI355X_OVERLAP");
-    return e ? std::atoi(e) : 1;
+    return diag("overlap", 1);
 }
 // The latency variants of the traversal kernels (device_kernels.h, LAT) for launches that do not fill the chip -- B = 1
 // Add, the exact window's rounds, small query calls: 0 never, 1 (default) when the jobs fit the variant's resident waves,
@@ -1009,39 +1005,37 @@ static int overlap_mode()
 // 1.68 -> 2.03 M, C5-size 2.26 -> 2.70 M.
 static int novis_mode() // 0 never, 1 hash-table graphs only, 2 (default) every graph
 {
-    const char *e = std::getenv("HNSW_MI355X_NOVIS");
-    return e ? std::atoi(e) : 2;
+    return diag("novis", 2);
 }
 static constexpr size_t kTeamLds = ((sizeof(TeamMail) + 15) & ~(size_t)15) + 16; // the latency variants' mailbox, behind the traversal's LDS
 static int lat_mode()
 {
-    const char *e = std::getenv("HNSW_MI355X_LAT");
-    return e ? std::atoi(e) : 1;
+    return diag("lat", 1);
 }
 
 // The MFMA Gram-block prefilter of RelativeNeighborPruning (device_kernels.h): on by default where it applies
 // (cosine family, dim % 8 == 0); HNSW_MI355X_MFMA=0 keeps the exact-only forms (the tests run both).
 static bool mfma_heuristic()
 {
-    const char *e = std::getenv("HNSW_MI355X_MFMA");
-    return !e || std::atoi(e) != 0;
+    return diag("mfma", 1) != 0;
 }
 
 // The per-wave visited-id hash tables (VisitedSet): capacity a power of two, >= 16384 and >= 64 per
 // beam entry (a traversal visits roughly 35 ids per beam entry), all entries -1 between jobs.
 // HNSW_MI355X_VIS_HASH=1/0 forces / forbids them; HNSW_MI355X_VIS_HASH_CAP overrides the capacity (tests).
-bool Device::visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_cap, int min_cap)
+bool Device::visited_table(size_t vis_bytes_per_job, int k, int **out, int *out_cap, int min_cap, bool allow_hash)
 {
     *out = nullptr;
     *out_cap = 0;
-    const char *e = std::getenv("HNSW_MI355X_VIS_HASH");
+    if (!allow_hash) return true; // (the eight-set kernels have no hash-table form: their launches keep bitsets whatever the graph's size)
+    const int e = diag("vis_hash", -1);
     // measured: at 1M nodes (125-KB bitsets) the bitset is faster (2.5 M vs 1.9 M queries/s on C2); at
     // 10M (1.25 MB) the table wins (1.48 M vs 1.28 M with the log-cleared bitset, 0.98 M streaming it)
-    const bool want = e ? std::atoi(e) != 0 : vis_bytes_per_job > (512u << 10);
+    const bool want = e >= 0 ? e != 0 : vis_bytes_per_job > (512u << 10);
     if (!want) return true;
     int cap = 16384;
     while (cap < 64 * k && cap < (1 << 22)) cap <<= 1;
-    if (const char *c = std::getenv("HNSW_MI355X_VIS_HASH_CAP")) { cap = 64; while (cap < std::atoi(c) && cap < (1 << 22)) cap <<= 1; }
+    if (const int c = diag("vis_hash_cap", 0)) { cap = 64; while (cap < c && cap < (1 << 22)) cap <<= 1; }
     // a traversal step inserts up to min_cap / 4 ids between two looks at crowded() (limit: 3/4 of the table)
     while (cap < min_cap) cap <<= 1;
     const size_t need = (size_t)max_slots() * (size_t)cap;
@@ -1123,7 +1117,9 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     const int cand_cap = cand_lds_cap(k, pitch_, true, nbcap());
     const size_t lds = search_lds_bytes(k, cand_cap, pitch_, true, nbcap());
     if (lds > 64 * 1024) { set_dev_error("insert_search_batch: beam width / dimension exceed the LDS budget"); return false; }
-    const int ns = g_n_ < kSortedTopMaxNodes ? sorted_top_sets(k) : 0;
+    const int ns_req = g_n_ < kSortedTopMaxNodes ? sorted_top_sets(k) : 0;
+    const bool exact_only = ns_req == 0;           // beams beyond 512 entries / HNSW_MI355X_SORTED_TOP=0: the two-set form with launch flag 0x200
+    const int ns = exact_only ? 2 : ns_req;
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     const int sel_stride = max_edges0;
@@ -1132,7 +1128,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     const long long chunk = std::min<long long>(njobs, 1 << 20);
     int *vis_tab = nullptr;
     int vis_tab_cap = 0;
-    if (!visited_table(vis_bytes_per_job, k, &vis_tab, &vis_tab_cap)) return false;
+    if (!visited_table(vis_bytes_per_job, k, &vis_tab, &vis_tab_cap, 512, ns != 8)) return false;
     if (vis_tab) { vis_words = 0; vis_bytes_per_job = 16; } // the HASHED kernels never touch the bitset arena: do not allocate one
     if (!ensure_search_scratch(chunk, max_slots(), 0, vis_bytes_per_job)) return false;
     const size_t nU = (size_t)std::max(n_upper, 1);
@@ -1196,7 +1192,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
             }
         }
         // (Add's searches without a visited set as well -- see novis_mode(); HNSW_MI355X_NOVIS_INSERT=0 keeps the sets there)
-        static const bool novis_ins_on = [] { const char *e = std::getenv("HNSW_MI355X_NOVIS_INSERT"); return !e || std::atoi(e) != 0; }();
+        const bool novis_ins_on = diag("novis_insert", 1) != 0; // (read per call, like every other switch)
         const bool novis_ins_ = novis_ins_on && g_stride0_ - 2 <= 64 && overlap_mode() != 0 && (size_t)pitch_ * sizeof(float) <= 1024 && (novis_mode() == 2 || (novis_mode() == 1 && vis_tab != nullptr));
         HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int), st));
         HIP_OK(hipMemsetAsync(p_evals, 0, sizeof(unsigned long long), st));
@@ -1207,12 +1203,12 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
                        dim3(LAT_ ? 128 : 64), (LDS) + (LAT_ ? kTeamLds : 0), st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, p_sel0 + (size_t)off * sel_stride, p_cnt0 + off, p_selU, p_cntU,        \
-                       sel_stride, p_flag + off, p_evals, nbcap(), GRID, s_jobctr_, (novis_ins_ ? 9 : (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
+                       sel_stride, p_flag + off, p_evals, nbcap(), GRID, s_jobctr_, (exact_only ? 0x200 : 0) | (novis_ins_ ? 9 : (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
                        windowed ? p_log : (int *)nullptr, read_log_cap)
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \
-        const int lslots_ = NS_ > 0 && lat_mode() != 0 && g_stride0_ - 2 <= 64 && (LDS) + kTeamLds <= 64 * 1024 ? std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, (NS_ > 0 ? NS_ : 1), H_, true>, (LDS) + kTeamLds, num_cu_, 128)) : 0; \
-        if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, (NS_ > 0 ? NS_ : 1), H_, true, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
+        const int lslots_ = !exact_only && lat_mode() != 0 && g_stride0_ - 2 <= 64 && (LDS) + kTeamLds <= 64 * 1024 ? std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_, true>, (LDS) + kTeamLds, num_cu_, 128)) : 0; \
+        if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, NS_, H_, true, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
         else { \
             const int slots_ = std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_, false>, LDS, num_cu_)); \
             LAUNCH2L(M, NS_, H_, false, slots_, GRID, LDS, CAP); \
@@ -1231,11 +1227,9 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         else LAUNCH3(NS_, false, GRID, LDS, CAP);                                                                     \
     } while (0)
         switch (ns) {
-        case 1: LAUNCH(1, nj, lds, cand_cap); break;
         case 2: LAUNCH(2, nj, lds, cand_cap); break;
         case 4: LAUNCH(4, nj, lds, cand_cap); break;
-        case 8: LAUNCH(8, nj, lds, cand_cap); break;
-        default: LAUNCH(0, nj, lds, cand_cap); break;
+        default: LAUNCH3(8, false, nj, lds, cand_cap); break; // (no hash-table form: visited_table() was told so)
         }
         HIP_OK(hipGetLastError());
 #undef LAUNCH
@@ -1290,7 +1284,7 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
     int *h_rep = windowed ? h_log + (b_log + b_dry + b_drop) / 4u : nullptr;
     for (int i = 0; i < njobs; ++i) {
         if (h_rep) h_rep[i] = h_flag[i] == 2;
-        if (h_flag[i] == 2) { stats_.search_repeats++; h_flag[i] = 0; }
+        if (h_flag[i] == 2) { stats_.search_repeats++; stats_.insert_tie_reruns++; h_flag[i] = 0; }
         stats_.search_overflows += (uint64_t)(h_flag[i] != 0);
     }
     last_insert_jobs_ = (njobs <= chunk && !windowed) ? njobs : 0; // a single launch left everything in place (windowed: in its own block)
@@ -1695,7 +1689,9 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
     const int cand_cap = cand_lds_cap(k, pitch_, false, nbcap());
     const size_t lds = search_lds_bytes(k, cand_cap, pitch_, false, nbcap());
     if (lds > 64 * 1024) { set_dev_error("search_batch: beam width / dimension exceed the LDS budget"); return false; }
-    const int ns = (g_n_ < kSortedTopMaxNodes && !two_heap) ? sorted_top_sets(k) : 0;
+    const int ns_req = (g_n_ < kSortedTopMaxNodes && !two_heap) ? sorted_top_sets(k) : 0;
+    const bool exact_only = ns_req == 0;           // two_heap callers, beams beyond 512 entries, HNSW_MI355X_SORTED_TOP=0: launch flag 0x200
+    const int ns = exact_only ? 2 : ns_req;
     if (!bind()) return false;
     hipStream_t st = S(stream_);
     long long vis_words = ((g_n_ + 31) / 32 + 3) & ~3LL;
@@ -1703,7 +1699,7 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
     const long long chunk = std::min<long long>(njobs, 1 << 20);
     int *vis_tab = nullptr;
     int vis_tab_cap = 0;
-    if (!visited_table(vis_bytes_per_job, k, &vis_tab, &vis_tab_cap)) return false;
+    if (!visited_table(vis_bytes_per_job, k, &vis_tab, &vis_tab_cap, 512, ns != 8)) return false;
     if (vis_tab) { vis_words = 0; vis_bytes_per_job = 16; } // see insert_search_batch
     if (!ensure_search_scratch(chunk, max_slots(), k_out, vis_bytes_per_job)) return false;
     // pinned layout: [evals (16 B) | jobs | ids | dists | flags]
@@ -1736,33 +1732,14 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
     struct TailGuard { Device *d; ~TailGuard() { if (d->tail_.n > 0) d->n_queries_ = 0; d->tail_.n = 0; } } tail_guard{this};
     for (long long off = 0; off < njobs; off += chunk) {
         const int nj = (int)std::min<long long>(chunk, njobs - off);
-        // the queries' shared first hop as one dense MFMA block (entry_block_kernel): float metrics, rows of a multiple of 8
-        // floats, a top layer to descend from, every query row resident (not the streamed upload); HNSW_MI355X_MFMA_ENTRY=0: off
-        // (a launch of its own, 10-20 microseconds: not for calls of a few queries, which are all latency)
-        const char *entry_env = std::getenv("HNSW_MI355X_MFMA_ENTRY");
-        const bool entry_on = !entry_env || std::atoi(entry_env) != 0;
-        const bool entry_block = !jobs && entry_on && nj >= 256 && metric_ != M_I8 && (pitch_ & 7) == 0 && u_layer >= 1 && gate == nullptr && ns > 0 && g_strideU_ - 2 <= 31;
         if (jobs) {
             memcpy(h_jobs, jobs + off, sizeof(SearchJob) * (size_t)nj);
-            for (int i = 0; i < nj; ++i) h_jobs[i].stop_layer = 0; // (a search job's stop_layer is the entry block's hint: none)
             HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
             uj_len_ = 0;
-        } else if (!(uj_len_ >= nj && uj_entry_ == u_entry && uj_layer_ == u_layer) || (uj_hinted_ && !entry_block)) {
+        } else if (!(uj_len_ >= nj && uj_entry_ == u_entry && uj_layer_ == u_layer)) {
             for (int i = 0; i < nj; ++i) h_jobs[i] = SearchJob{i, u_entry, u_layer, 0, -1, 0};
             HIP_OK(hipMemcpyAsync(s_jobs_, h_jobs, sizeof(SearchJob) * (size_t)nj, hipMemcpyHostToDevice, st));
-            uj_len_ = nj; uj_entry_ = u_entry; uj_layer_ = u_layer; uj_hinted_ = false;
-        }
-        if (entry_block) { // every job of this launch gets its hint (or 0) rewritten: the resident query set may be a new one
-            const int tiles = (nj + 31) / 32;
-#define LAUNCH_EB(M) hipLaunchKernelGGL(entry_block_kernel<M>, dim3(tiles), dim3(64), 0, st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, g_upper_, g_pool_, \
-                                        g_strideU_, u_entry, u_layer, s_jobs_, nj, (unsigned long long *)nullptr)
-            if (metric_ == M_SQ) LAUNCH_EB(M_SQ);
-            else if (metric_ == M_COS) LAUNCH_EB(M_COS);
-            else LAUNCH_EB(M_UCOS);
-#undef LAUNCH_EB
-            HIP_OK(hipGetLastError());
-            uj_hinted_ = true;
-            stats_.entry_block_launches++;
+            uj_len_ = nj; uj_entry_ = u_entry; uj_layer_ = u_layer;
         }
         HIP_OK(hipMemsetAsync(s_jobctr_, 0, sizeof(int) * (4 + (size_t)nj), st));
         if (!compact) HIP_OK(hipMemsetAsync(s_evals_, 0, sizeof(unsigned long long), st));
@@ -1772,12 +1749,12 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_, LAT_>), dim3(std::min<int>(GRID, SLOTS)), \
                        dim3(LAT_ ? 128 : 64), (LDS) + (LAT_ ? kTeamLds : 0), st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
-                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, d_flag, d_ev, nbcap(), GRID, s_jobctr_, (novis_ ? 9 : (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
+                       spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, d_flag, d_ev, nbcap(), GRID, s_jobctr_, (exact_only ? 0x200 : 0) | (novis_ ? 9 : (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
                        gate)
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \
-        const int lslots_ = NS_ > 0 && lat_mode() != 0 && g_stride0_ - 2 <= 64 && (LDS) + kTeamLds <= 64 * 1024 ? std::min(max_slots(), resident_blocks(graph_search_kernel<M, (NS_ > 0 ? NS_ : 1), H_, true>, (LDS) + kTeamLds, num_cu_, 128)) : 0; \
-        if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, (NS_ > 0 ? NS_ : 1), H_, true, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
+        const int lslots_ = !exact_only && lat_mode() != 0 && g_stride0_ - 2 <= 64 && (LDS) + kTeamLds <= 64 * 1024 ? std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_, true>, (LDS) + kTeamLds, num_cu_, 128)) : 0; \
+        if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, NS_, H_, true, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
         else { \
             const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_, false>, LDS, num_cu_)); \
             LAUNCH2L(M, NS_, H_, false, slots_, GRID, LDS, CAP); \
@@ -1796,11 +1773,9 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
         else LAUNCH3(NS_, false, GRID, LDS, CAP);                                                                     \
     } while (0)
         switch (ns) {
-        case 1: LAUNCH(1, nj, lds, cand_cap); break;
         case 2: LAUNCH(2, nj, lds, cand_cap); break;
         case 4: LAUNCH(4, nj, lds, cand_cap); break;
-        case 8: LAUNCH(8, nj, lds, cand_cap); break;
-        default: LAUNCH(0, nj, lds, cand_cap); break;
+        default: LAUNCH3(8, false, nj, lds, cand_cap); break; // (no hash-table form: visited_table() was told so)
         }
         HIP_OK(hipGetLastError());
 #undef LAUNCH

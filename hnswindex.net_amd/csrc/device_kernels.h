@@ -11,7 +11,6 @@
 //   dk_pool_top.h        SearchLayer on an unsorted register pool (the latency variants' logic wave)
 //   dk_traverse_exact.h  the exact two-heap traversal
 //   dk_heuristic.h       RelativeNeighborPruning (with its MFMA Gram-block prefilter)
-//   dk_entry_block.h     the queries' shared first hop as one dense MFMA block (prefilter)
 //   dk_search_kernels.h  graph_search_kernel, graph_range_kernel
 //   dk_insert_kernels.h  graph_insert_search_kernel
 //   dk_link.h            the link half of Add, Remove's re-link
@@ -28,7 +27,6 @@
 #include "dk_pool_top.h"
 #include "dk_traverse_exact.h"
 #include "dk_heuristic.h"
-#include "dk_entry_block.h"
 #include "dk_search_kernels.h"
 #include "dk_insert_kernels.h"
 #include "dk_link.h"
@@ -38,13 +36,17 @@ namespace hnsw {
 
 // Explicit instantiations of the two traversal kernels live in traverse_<metric>_<search|insert>.hip;
 // every other unit only declares them.
+// Ten forms per metric and kernel (eighteen until round 5): register sets NS in {2, 4, 8} (beams up to 128 / 256 / 512; a beam of
+// up to 64 runs in the two-set form), the visited set as a bitset or (graphs above 4M nodes, NS <= 4) a per-wave hash table, and the
+// latency variant of each.  What used to be forms of their own: NS = 1 (same code with one register less), NS = 0 (the exact
+// two-heap traversal alone: now launch flag 0x200 of the two-set form), hash tables for NS = 8 (such launches keep bitsets).
 #define HNSW_FOR_EACH_TRAVERSAL(X, M) \
-    X(M, 0, false, false) X(M, 1, false, false) X(M, 2, false, false) X(M, 4, false, false) X(M, 8, false, false) \
-    X(M, 0, true, false) X(M, 1, true, false) X(M, 2, true, false) X(M, 4, true, false) X(M, 8, true, false)
-// the latency variants (sorted-list kernels only): units of their own
+    X(M, 2, false, false) X(M, 4, false, false) X(M, 8, false, false) \
+    X(M, 2, true, false) X(M, 4, true, false)
+// the latency variants: units of their own
 #define HNSW_FOR_EACH_TRAVERSAL_LAT(X, M) \
-    X(M, 1, false, true) X(M, 2, false, true) X(M, 4, false, true) X(M, 8, false, true) \
-    X(M, 1, true, true) X(M, 2, true, true) X(M, 4, true, true) X(M, 8, true, true)
+    X(M, 2, false, true) X(M, 4, false, true) X(M, 8, false, true) \
+    X(M, 2, true, true) X(M, 4, true, true)
 #define HNSW_SEARCH_SIGNATURE(PREFIX, M, NS, H, LT)                                                                                  \
     PREFIX template __global__ void graph_search_kernel<M, NS, H, LT>(                                                              \
         const float *__restrict__, const double *__restrict__, const float *__restrict__, const double *__restrict__, int,      \

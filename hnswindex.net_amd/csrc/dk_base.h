@@ -13,6 +13,10 @@
 #define HNSW_WAVES(x) (x)
 #endif
 
+#ifndef HNSW_I8_WAVES // waves per SIMD of the int8 search kernels with up to two register sets (build experiment: -DHNSW_I8_WAVES=4 / 6)
+#define HNSW_I8_WAVES 5
+#endif
+
 namespace hnsw {
 
 // Every block of the kernels below that stage data through LDS is ONE wavefront working on its own job (the latency

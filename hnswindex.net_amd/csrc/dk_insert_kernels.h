@@ -50,9 +50,10 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         int top_n = 0;
         const int rl_n0 = RL.n;
         const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
-        bool exact = NS == 0, order_tie = false;
+        const bool exact_only = (overlap_and_flags & 0x200) != 0; // the launch runs the exact two-heap traversal only (beams beyond 512 entries)
+        bool exact = exact_only, order_tie = false;
         const unsigned long long ev0 = evals;
-        if constexpr (NS > 0) {
+        if (!exact_only) {
             bool tie = false;
             if constexpr (LAT) ok = traverse_pool<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, RL, &order_tie, nullptr, port);
             else ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap_and_flags & 9, RL, &order_tie); // Span.Sort consumes all
@@ -65,7 +66,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         int rc = 0;
         for (;;) {
             if (exact) {
-                if constexpr (NS > 0) {
+                if (!exact_only) {
                     repeat = true;
                     evals = ev0;
                     top_n = 0;

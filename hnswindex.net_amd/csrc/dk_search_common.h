@@ -164,7 +164,7 @@ struct ReadLog {
 template <int METRIC, bool TWO = false>
 __device__ __forceinline__ void descend(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                         const GraphView &G, const SearchJob jb, const SearchLds &L, int lane, int &best, float &cur,
-                                        unsigned long long &evals, ReadLog &RL, int first_pass_hint = 0)
+                                        unsigned long long &evals, ReadLog &RL)
 {
     int *nbuf = L.nbuf;
     float *dbuf = L.dbuf;
@@ -180,25 +180,8 @@ __device__ __forceinline__ void descend(const float *__restrict__ rows, const do
     for (int layer = jb.entry_layer; layer > jb.search_layer; --layer) {
         bool changed = true;
         RL.layer(layer, lane);
-        bool hinted = first_pass_hint > 0 && layer == jb.entry_layer; // the first pass's outcome is known (entry_block_kernel): node hint - 1
         while (changed) { // :60
             changed = false;
-            if (hinted) {
-                hinted = false;
-                const int b1 = first_pass_hint - 1;
-                if (b1 != best) { // the pass ends on b1: its distance in the reference's lane order is what the next pass compares against
-                    best = b1;
-                    wave_sync();
-                    if (lane == 0) nbuf[0] = b1;
-                    wave_sync();
-                    measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, 1, lane);
-                    wave_sync();
-                    cur = dbuf[0];
-                    evals += 1;
-                    changed = true;
-                }
-                continue;
-            }
             const int *l = G.list(best, layer);
             const int n = l[0];
             RL.put(best, lane);

@@ -6,9 +6,9 @@
 
 namespace hnsw {
 
-// NS > 0: sorted-list traversal with NS register sets (k <= 64 * NS); a wave that meets equal
-// distances where the heap layout shows starts over with the exact two-heap traversal (out_flag 2,
-// informational).  NS = 0: two-heap traversal only.
+// Sorted-list traversal with NS register sets (k <= 64 * NS); a wave that meets equal distances where the heap layout
+// shows starts over with the exact two-heap traversal (out_flag 2, informational).  Launch flag 0x200 (beams beyond 512
+// entries, HNSW_MI355X_SORTED_TOP=0): the two-heap traversal only.
 // One job on this wave.  `vis` / `spill`: the wave's own scratch (vis all zero on entry; the caller
 // clears it afterwards).
 // Job words of a launch with SHADOW traversals (graph_search_kernel): bit 0 answered (results written), bit 1 the
@@ -54,7 +54,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         return (__builtin_amdgcn_readfirstlane(old) & kJobAnswered) == 0;
     };
     if constexpr (NS > 0) {
-        if (jb.aux != -2 && !shadow) {
+        if (jb.aux != -2 && !shadow && !(overlap & 0x200)) { // (0x200: this launch runs the exact two-heap traversal only)
         bool tie = false;
         // OrderBy + Take(k_out) reads k_out entries in order and decides between entries k_out - 1 and k_out
         bool window = false;
@@ -159,7 +159,7 @@ template <int METRIC, int NS, bool HASHED, bool LAT = false>
 // float rows: 168 VGPRs, three waves per SIMD; int8 records keep 16 registers of rows in flight, not 64: five waves.
 // LAT (launches that do not fill the chip): no occupancy to buy -- every spilled register is a memory round trip a lone wave
 // waits out in full -- so two waves per SIMD at most (256 VGPRs), one with eight register sets
-__global__ void __launch_bounds__(LAT ? 128 : 64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(LAT ? (NS <= 4 ? 2 : 1) : METRIC == M_I8 ? (NS <= 2 ? 5 : 4) : (NS <= 4 ? 3 : 2)))))
+__global__ void __launch_bounds__(LAT ? 128 : 64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(LAT ? (NS <= 4 ? 2 : 1) : METRIC == M_I8 ? (NS <= 2 ? HNSW_I8_WAVES : 4) : (NS <= 4 ? 3 : 2)))))
 graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
@@ -203,7 +203,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     // job soon after and the shadow stops at its next expansion; when the owner meets a tie it finds the exact
     // traversal already under way and leaves it to the shadow.  Results are written by whoever finishes first -- both
     // compute the reference's answer.
-    const bool shadows = (overlap & 0x100) != 0 && NS > 0;
+    const bool shadows = (overlap & 0x100) != 0 && NS > 0 && !(overlap & 0x200);
     int *job_words = job_counter + 4;
     int known_ready = 0;
     bool v_clean = false;

@@ -260,7 +260,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     PH_DECL();
     int best;
     float cur;
-    descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals, RL, order_tie_out ? 0 : jb.stop_layer); // (a search job's stop_layer carries entry_block_kernel's hint)
+    descend<METRIC>(rows, row_sn, dim, sb, G, jb, L, lane, best, cur, evals, RL);
     // ---- SearchLayer (GraphNavigator.cs:123-189) ----
     const int layer = jb.search_layer;
     RL.layer(layer, lane);

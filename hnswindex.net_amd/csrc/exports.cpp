@@ -2,6 +2,7 @@
 // (/root/reference/bindings/HNSWIndex.Native/HNSWIndexExports.cs:27-273), same names,
 // signatures, return codes and padding, over the MI355X-backed HnswIndex.
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,6 +13,7 @@
 
 #include "../../include/hnsw_mi355x.h"
 #include "hnsw_index.h"
+#include "diag.h"
 #include "range_replay.h"
 #include "snapshot_io.h"
 
@@ -194,6 +196,33 @@ SETTER(hnsw_mi355x_set_search_slots, search_slots, int)
 SETTER(hnsw_mi355x_set_host_threads, host_threads, int)
 SETTER(hnsw_mi355x_set_device_traversal, device_traversal, int)
 SETTER(hnsw_mi355x_set_devices, devices, int)
+
+// The knobs as one versioned struct (include/hnsw_mi355x.h): the documented way to configure the backend.
+API int hnsw_mi355x_default_options(hnsw_mi355x_options *out)
+{
+    if (!out) return -1;
+    const Params d;
+    *out = hnsw_mi355x_options{(uint32_t)sizeof(hnsw_mi355x_options), 0, 1, d.insert_batch, d.remove_batch, d.host_threads, d.search_slots, d.device_traversal, nullptr};
+    return 0;
+}
+API int hnsw_mi355x_set_options(const hnsw_mi355x_options *opt)
+{
+    if (!opt || opt->struct_size < 8 || opt->struct_size > 4096) { set_error("hnsw_mi355x_set_options: struct_size not set"); return -1; }
+    hnsw_mi355x_options o;
+    (void)hnsw_mi355x_default_options(&o);
+    std::memcpy(&o, opt, std::min<size_t>(opt->struct_size, sizeof o)); // an older caller's shorter struct: the rest keeps the defaults
+    if (o.insert_batch == -1 || o.remove_batch < 1 || o.devices < 0 || o.devices > 64 || o.device < -1 || o.host_threads < 0 || o.search_slots < 0) {
+        set_error("hnsw_mi355x_set_options: value out of range");
+        return -1;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_pending.device = o.device; g_pending.devices = o.devices; g_pending.insert_batch = o.insert_batch; g_pending.remove_batch = o.remove_batch;
+        g_pending.host_threads = o.host_threads; if (o.search_slots > 0) g_pending.search_slots = o.search_slots; g_pending.device_traversal = o.device_traversal;
+    }
+    if (opt->struct_size >= offsetof(hnsw_mi355x_options, diagnostics) + sizeof(const char *)) hnsw::set_diag_string(o.diagnostics);
+    return 0;
+}
 
 API int hnsw_set_distribution_rate(float dist_rate) // :247 -- crosses the ABI as float, widened to double
 {
@@ -454,6 +483,7 @@ API int hnswhost_test_snapshot_transcode(const char *in_path, const char *out_pa
     return 0;
 }
 
+API int hnswhost_test_diag(const char *name, int dflt) { return name ? hnsw::diag(name, dflt) : dflt; } // what csrc/diag.h answers right now
 API void hnswhost_test_random_next(int seed, int n, int *out)
 {
     hnsw::DotnetRandom r(seed);

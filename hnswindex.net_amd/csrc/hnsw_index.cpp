@@ -1,6 +1,7 @@
 // hnsw_index.cpp -- Add / KnnQuery on the lock-step engine.  Citations relative to
 // /root/reference/.
 #include "hnsw_index.h"
+#include "diag.h"
 
 #include <algorithm>
 #include <atomic>
@@ -605,7 +606,7 @@ struct PhaseTimers {
     long xw_end[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // what ended a round's prefix: 0 window exhausted, 1 stale result (searched on an older graph, list written since), 2 second change of a list,
                                                // 3 change with unknown lost ids, 4 reader answered by the exact traversal, 5 expansion without a bound, 6 the change shows (pair distance), 7 upper layers / overflow
     long rounds = 0, batches = 0, prune_jobs = 0;
-    bool on = std::getenv("HNSW_MI355X_TRACE") != nullptr;
+    bool on = diag("trace", 0) != 0;
 };
 PhaseTimers g_pt;
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -628,14 +629,11 @@ HnswIndex *HnswIndex::create(int metric, const Params &p, std::string &err)
         return nullptr;
     }
     int dev = p.device;
-    if (dev < 0) {
-        const char *e = std::getenv("HNSW_MI355X_DEVICE");
-        dev = e ? std::atoi(e) : 0;
-    }
+    if (dev < 0) dev = 0;
     if (dev < 0 || dev >= ndev) { err = "HNSWIndex MI355X backend: device ordinal out of range"; return nullptr; }
     if (p.max_edges < 1) { err = "MaxEdges must be >= 1"; return nullptr; }
     int devices = p.devices;
-    if (devices <= 0) { const char *e = std::getenv("HNSW_MI355X_DEVICES"); devices = e ? std::atoi(e) : 1; }
+    if (devices <= 0) devices = 1;
     if (devices < 1 || devices > 64) { err = "HNSWIndex MI355X backend: device contexts must be between 1 and 64"; return nullptr; }
     HnswIndex *ix = new HnswIndex();
     ix->metric_ = metric;
@@ -650,10 +648,6 @@ HnswIndex *HnswIndex::create(int metric, const Params &p, std::string &err)
     ix->rng_.init(seed);
     ix->capacity_ = std::max(1, p.collection_size);
     int th = p.host_threads;
-    if (th <= 0) {
-        const char *e = std::getenv("HNSW_MI355X_THREADS");
-        th = e ? std::atoi(e) : 0;
-    }
     if (th <= 0) th = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     ix->threads_ = th;
     return ix;
@@ -837,8 +831,7 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
     // host: own lists, grouping of the appends and the appends themselves run there, the host does
     // nothing in between (HNSW_MI355X_LINK_PLAN=0 keeps the host-grouped path below, which is also
     // the one used after a hand-back).
-    const char *plan_env = std::getenv("HNSW_MI355X_LINK_PLAN");
-    const bool plan_on_device = !plan_env || std::atoi(plan_env) != 0;
+    const bool plan_on_device = diag("link_plan", 1) != 0;
     bool any_own = false;
     for (int i = 0; i < n; ++i) any_own = any_own || sel.has_own[(size_t)i];
     if (plan_on_device && !any_own && n <= (1 << 20)) { // (a larger batch is searched in several launches: host path)
@@ -853,7 +846,7 @@ bool HnswIndex::link_half_device(const std::vector<int> &bid, const Selection &s
     // adjacency list sub-batch after sub-batch is the same sequence as appending them all in item
     // order, so the outcome is unchanged -- but while the GPU links one sub-batch the host groups
     // the next and files the previous one's lists.
-    static const int split = [] { const char *e = std::getenv("HNSW_MI355X_LINK_SPLIT"); return e ? std::max(1, std::atoi(e)) : 4; }();
+    constexpr int split = 4;
     const int S = n >= 2048 ? split : 1;
     // The lists the link kernel leaves behind stay in the HBM mirror; the host copy is marked stale
     // and fetched back when something on the host needs it (refresh_host_lists).
@@ -1035,8 +1028,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
     std::vector<Todo> todo;
     std::vector<int> bid, upper_base, upper_owner;
     std::vector<SearchJob> jobs;
-    static const bool dry_on = [] { const char *e = std::getenv("HNSW_MI355X_XW_DRY"); return !e || std::atoi(e) != 0; }();
-    static const bool stage_on = [] { const char *e = std::getenv("HNSW_MI355X_XW_STAGE"); return !e || std::atoi(e) != 0; }();
+    const bool dry_on = diag("xw_dry", 1) != 0, stage_on = diag("xw_stage", 1) != 0;
     // links in flight: two staging sets, finished when their set is needed again and before anything returns
     bool pend[2] = {false, false};
     int next_set = 0;
@@ -1074,7 +1066,7 @@ bool HnswIndex::insert_exact_window(const std::vector<int> &fresh, int &p, int W
         // searched ahead follow the live window too.  (Measured, same box: at 1M nodes the prefix is 29-30 items whatever W
         // is, and W = 256 does 15.0 k adds/s beside W = 64's 15.4 k -- 13.4 k with three times the prefix and the look-ahead
         // sized by W; at 10M the prefix is 86 and W = 256 does 26.4 k beside W = 64's 21.2 k.)
-        static const double xw_factor = [] { const char *e = std::getenv("HNSW_MI355X_XW_FACTOR"); return e ? std::atof(e) : 2.0; }(); // experiments
+        constexpr double xw_factor = 2.0; // swept in rounds 3 and 4 (1.5 / 2 / 3 / 4: 17.5 / 18.2 / 17.7 / 16.4 k adds/s at 1M)
         const int W_now = std::min(W, std::max(8, (int)(xw_factor * xw_prefix_ema_) + 4));
         int hi = std::min(m, p + W_now), hi_up = std::min(m, p + std::min(ring, W_now * (1 + kAhead)));
         for (int t = p + 1; t < hi_up; ++t) if (graph_.level[(size_t)fresh[(size_t)t]] > top) { hi_up = t; break; }
@@ -1410,12 +1402,8 @@ int HnswIndex::add(const float *vectors, int count, int dim, int *out_ids, std::
             continue;
         }
         const int linked = graph_.count - (m - p); // nodes already linked (== the id when nothing was ever removed)
-        static const int growth_div = [] { const char *e = std::getenv("HNSW_MI355X_BATCH_DIV"); return e ? std::max(1, std::atoi(e)) : kBatchGrowthDiv; }(); // experiments only
-        static const int growth_div_late = [] { const char *e = std::getenv("HNSW_MI355X_BATCH_DIV_LATE"); return e ? std::max(1, std::atoi(e)) : 0; }();
-        static const bool div_from_env = std::getenv("HNSW_MI355X_BATCH_DIV") != nullptr;
         const int early_limit = std::min(kEarlyLinked, graph_.count / kBatchGrowthDiv); // graph_.count: nodes once this call is done
-        const int div_now = div_from_env ? (growth_div_late > 0 && linked >= kEarlyLinked ? growth_div_late : growth_div)
-                                         : (linked < early_limit ? kEarlyGrowthDiv : kBatchGrowthDiv);
+        const int div_now = linked < early_limit ? kEarlyGrowthDiv : kBatchGrowthDiv;
         const int b = std::min(bmax, std::max(1, linked / div_now));
         while ((int)bid.size() < b && p + (int)bid.size() < m && graph_.level[(size_t)fresh[(size_t)(p + (int)bid.size())]] <= top)
             bid.push_back(fresh[(size_t)(p + (int)bid.size())]);
@@ -1548,7 +1536,7 @@ static constexpr int kStreamMin = 32768, kStreamHead = 4096;
 // hnsw_knn_query from several host threads at once (lock held shared): one query lane per call.
 int HnswIndex::knn_query_concurrent(const float *queries, int count, int dim, int k, int *out_ids, float *out_dists, int &rc, std::string &err)
 {
-    static const bool enabled = [] { const char *e = std::getenv("HNSW_MI355X_CONCURRENT_QUERIES"); return !e || std::atoi(e) != 0; }();
+    const bool enabled = diag("concurrent_queries", 1) != 0;
     if (!enabled || !failed_msg_.empty() || p_.devices > 1 || !p_.device_traversal || !dev_ || dim != dim_ || count <= 0 || k < 1 ||
         graph_.entry < 0 || graph_.count <= 0 || graph_dirty_ || dev_->graph_nodes() != graph_.length)
         return 0;
@@ -1606,7 +1594,7 @@ void HnswIndex::collect_stats(hnswdev_stats *out)
         out->search_launches += s.search_launches; out->search_evals += s.search_evals; out->search_timed_launches += s.search_timed_launches;
         out->search_timed_evals += s.search_timed_evals; out->search_kernel_ms += s.search_kernel_ms; out->search_overflows += s.search_overflows;
         out->search_repeats += s.search_repeats; out->visited_hash_launches += s.visited_hash_launches;
-        out->tie_windows += s.tie_windows; out->lat_launches += s.lat_launches; out->peer_direct_copies += s.peer_direct_copies; out->peer_staged_copies += s.peer_staged_copies; out->entry_block_launches += s.entry_block_launches;
+        out->tie_windows += s.tie_windows; out->lat_launches += s.lat_launches; out->peer_direct_copies += s.peer_direct_copies; out->peer_staged_copies += s.peer_staged_copies; out->insert_tie_reruns += s.insert_tie_reruns;
     }
 }
 
@@ -1619,7 +1607,7 @@ void HnswIndex::reset_all_stats()
 
 int HnswIndex::set_resident_queries(const float *queries, int count, int dim, std::string &err, bool streamed)
 {
-    static const bool stream_on = [] { const char *e = std::getenv("HNSW_MI355X_STREAM_QUERIES"); return !e || std::atoi(e) != 0; }();
+    const bool stream_on = diag("stream_queries", 1) != 0;
     streamed = streamed && stream_on;
     if (!ensure_dim(dim, err)) return -1;
     Tick t(g_pt.set_queries);

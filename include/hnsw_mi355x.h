@@ -93,8 +93,30 @@ int hnsw_set_allow_removals(bool allow_removals);        /* :268 */
 
 /* ---- additions next to the reference's surface (not in the reference) ---------------- */
 
-/* Pending, like hnsw_set_*: HIP device ordinal for the next hnsw_create (default: the
- * HNSW_MI355X_DEVICE environment variable, else 0). */
+/* THE BACKEND'S KNOBS, all of them (version 1 = this layout; struct_size = sizeof(hnsw_mi355x_options) names the version, a
+ * library that knows a longer struct fills the rest with defaults).  Pending like hnsw_set_*: consumed by the next hnsw_create /
+ * hnsw_mi355x_deserialize and reset to the defaults afterwards.  The hnsw_mi355x_set_<knob>() functions below set one field each.
+ * Nothing else configures the product: the HNSW_MI355X_* environment switches of rounds 1-4 are gone. */
+typedef struct hnsw_mi355x_options {
+    uint32_t struct_size;      /* sizeof(hnsw_mi355x_options) */
+    int32_t device;            /* first HIP device ordinal (default 0) */
+    int32_t devices;           /* device contexts hnsw_knn_query shards its queries over (default 1; see hnsw_mi355x_set_devices) */
+    int32_t insert_batch;      /* hnsw_add's schedule: 0 = snapshot batches of at most the host's hardware threads (default: inside the
+                                * reference's Parallel.For outcome set), 1 = one item after the other, B > 1 = that cap, -W = the sequential
+                                * graph through exact windows (see hnsw_mi355x_set_insert_batch) */
+    int32_t remove_batch;      /* hnsw_remove's schedule: 1 = sequential (default), B > 1 = disjoint neighbourhoods together */
+    int32_t host_threads;      /* host worker threads, 0 = min(hardware threads, 16) */
+    int32_t search_slots;      /* concurrent searches of the host lock-step driver (default 16384) */
+    int32_t device_traversal;  /* 1 = graph traversal on the device (default), 0 = on the host, distances batched to the device */
+    const char *diagnostics;   /* NULL (default), or test hooks "name=value,..." (csrc/diag.h; process-wide, replaces the environment
+                                * variable HNSW_MI355X_DIAG while set): forces code paths for the test tiers, never needed by a caller */
+} hnsw_mi355x_options;
+/* Fills *out with the defaults (struct_size set).  0 / -1. */
+int hnsw_mi355x_default_options(hnsw_mi355x_options *out);
+/* Sets every pending knob from *opt (opt->struct_size must be set; fields beyond it keep their defaults).  0 / -1 on a bad value. */
+int hnsw_mi355x_set_options(const hnsw_mi355x_options *opt);
+
+/* Pending, like hnsw_set_*: HIP device ordinal for the next hnsw_create (default 0). */
 int hnsw_mi355x_set_device(int device);
 /* Pending: cap B on the snapshot batch of hnsw_add: B consecutive items search the graph as it stands, then link in id
  * order (a batch also never exceeds 1/16 of the linked graph -- 1/4 of it during the first min(65 536, final count / 16)
@@ -136,7 +158,7 @@ int hnsw_mi355x_set_host_threads(int threads);
  * 0 = traversal on the host, distances batched to the device step by step.  Same results. */
 int hnsw_mi355x_set_device_traversal(int enabled);
 
-/* Pending: number of device contexts of the next index (default: HNSW_MI355X_DEVICES, else 1).  With n > 1,
+/* Pending: number of device contexts of the next index (default 1).  With n > 1,
  * hnsw_knn_query -- BatchKnnQuery, a Parallel.For over independent searches, src/HNSWIndex/HNSWIndex.cs:129-137 via
  * bindings/HNSWIndex.Native/HNSWIndexExports.cs:119-149 -- shards its queries over n GPUs of the node inside this
  * one process: context g (device ordinal hnsw_mi355x_set_device + g, modulo the devices present) holds a replica of
@@ -249,8 +271,11 @@ typedef struct hnswdev_stats {
     uint64_t tie_windows;           /* searches that met open candidates of equal distance and were shown to be order-free (no exact re-run) */
     uint64_t peer_direct_copies;    /* replica / query-set copies between contexts whose devices have peer access enabled (one device: counted here) */
     uint64_t peer_staged_copies;    /* ... and those the runtime had to stage through host memory (no peer access between the two devices) */
-    uint64_t entry_block_launches;  /* search launches preceded by the MFMA block of the queries' shared first hop (entry_block_kernel) */
     uint64_t lat_launches;          /* traversal launches that ran the latency variant of their kernel (fewer jobs than its resident waves) */
+    uint64_t insert_tie_reruns;     /* Add searches answered by the exact two-heap traversal because equal distances could show in what the insert
+                                     * consumes in order (Span.Sort among equal keys, Heuristic.cs:22; heap layout at the far end of the list): the inserts
+                                     * whose outcome rests on BCL tie behaviour this build restates from memory -- the "parity unpinned" exposure as a number
+                                     * (also counted in search_repeats) */
 } hnswdev_stats;
 
 /* All return 0 on success, < 0 on error (message via hnswdev_ctx_last_error / hnswdev_last_error).

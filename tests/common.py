@@ -36,12 +36,24 @@ def self_recall_at_1(index, x, ids, **kw):
     return float((res[:, 0] == ids).mean())
 
 
+def diag_values():
+    """The test hooks currently in force: HNSW_MI355X_DIAG = "name=value,..." (csrc/diag.h, read by the library on every use)."""
+    import os
+    return dict(p.strip().split("=", 1) for p in os.environ.get("HNSW_MI355X_DIAG", "").split(",") if "=" in p)
+
+
+def set_diag(monkeypatch, **kw):
+    """Adds test hooks to HNSW_MI355X_DIAG for the rest of the test (set_diag(monkeypatch, lat=2, novis=0))."""
+    cur = diag_values()
+    cur.update({k: str(v) for k, v in kw.items()})
+    monkeypatch.setenv("HNSW_MI355X_DIAG", ",".join(f"{k}={v}" for k, v in cur.items()))
+
+
 def novis_active(stats):
-    """True when the search launches behind `stats` ran without a visited set (the default; HNSW_MI355X_NOVIS=0 keeps the
+    """True when the search launches behind `stats` ran without a visited set (the default; diagnostic novis=0 keeps the
     sets, =1 drops them on hash-table graphs only): the kernel then counts every row it measures, which includes the
     neighbours the reference had already seen and skips."""
-    import os
-    mode = os.environ.get("HNSW_MI355X_NOVIS", "2")
+    mode = diag_values().get("novis", "2")
     return mode == "2" or (mode == "1" and stats.get("visited_hash_launches", 0) > 0)
 
 

@@ -120,3 +120,46 @@ def test_product_never_references_the_oracle():
     assert len(files) > 8
     for p in files:
         assert not pat.search(p.read_text()), p
+
+
+def test_options_struct_is_the_documented_surface(net, monkeypatch):
+    """hnsw_mi355x_options (version 1): defaults, range checks, a shorter (older) struct, and the one diagnostics mechanism --
+    the options' string while set, else the environment variable HNSW_MI355X_DIAG, read on every use (csrc/diag.h)."""
+    import ctypes as ct
+    L = net.lib
+    o = net.default_options()
+    assert o.struct_size == ct.sizeof(net.Options) and (o.device, o.devices, o.insert_batch, o.remove_batch) == (0, 1, 0, 1)
+    assert (o.host_threads, o.search_slots, o.device_traversal) == (0, 16384, 1) and o.diagnostics is None
+    L.hnswhost_test_diag.restype = ct.c_int
+    L.hnswhost_test_diag.argtypes = [ct.c_char_p, ct.c_int]
+    monkeypatch.delenv("HNSW_MI355X_DIAG", raising=False)
+    assert L.hnswhost_test_diag(b"lat", 1) == 1
+    monkeypatch.setenv("HNSW_MI355X_DIAG", "novis=0, lat=2,vis_hash_cap=64")
+    assert (L.hnswhost_test_diag(b"lat", 1), L.hnswhost_test_diag(b"novis", 2), L.hnswhost_test_diag(b"vis_hash_cap", 0)) == (2, 0, 64)
+    assert L.hnswhost_test_diag(b"vis_hash", -1) == -1 and L.hnswhost_test_diag(b"la", 7) == 7      # a prefix of a name is not the name
+    net.set_options(insert_batch=256, devices=2, diagnostics="lat=0")                                 # the struct's string wins while set ...
+    assert L.hnswhost_test_diag(b"lat", 1) == 0 and L.hnswhost_test_diag(b"novis", 2) == 2
+    net.set_options()                                                                                 # ... NULL: back to the environment
+    assert L.hnswhost_test_diag(b"lat", 1) == 2
+    for bad in (dict(insert_batch=-1), dict(remove_batch=0), dict(devices=65), dict(host_threads=-3)):
+        with pytest.raises(RuntimeError):
+            net.set_options(**bad)
+    with pytest.raises(TypeError):
+        net.set_options(no_such_knob=1)
+    short = net.default_options(); short.struct_size = 16; short.insert_batch = 64          # an older caller: four fields only
+    assert L.hnsw_mi355x_set_options(ct.byref(short)) == 0
+    zero = net.Options()                                                                     # struct_size not set
+    assert L.hnsw_mi355x_set_options(ct.byref(zero)) == -1
+    net.set_options()                                                                        # leave the pending block at its defaults
+
+
+def test_no_environment_switch_but_the_documented_one():
+    """The 27 HNSW_MI355X_* environment switches of rounds 1-4 are one: HNSW_MI355X_DIAG.  (HNSW_MI355X_LIB / _NO_TORCH belong to
+    the Python loader, _EXTRA_FLAGS / _REBUILD to the build recipe.)"""
+    import re
+    root = Path(__file__).resolve().parent.parent
+    names = set()
+    for f in [f for f in (root / "hnswindex.net_amd" / "csrc").glob("*") if f.is_file()] + list((root / "include").glob("*.h")):
+        names |= set(re.findall(r'getenv\("(HNSW_MI355X_[A-Z_0-9]+)"\)', f.read_text()))
+    assert names == {"HNSW_MI355X_DIAG"}, names
+

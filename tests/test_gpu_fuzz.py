@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from common import normalize_f32
+from common import normalize_f32, set_diag
 
 pytestmark = pytest.mark.gpu
 
@@ -99,7 +99,7 @@ def test_sorted_list_and_two_heap_traversals_agree_with_the_oracle(Index, monkey
     # the device traversal has a fast variant (one sorted list in registers, exact when no two
     # coexisting candidates are equidistant) and the exact two-heap variant it falls back to
     from common import uniform
-    monkeypatch.setenv("HNSW_MI355X_SORTED_TOP", sorted_top)
+    set_diag(monkeypatch, sorted_top=sorted_top)
     for (M, efc, ef, k) in [(8, 60, 40, 10), (16, 200, 128, 10), (12, 400, 300, 20), (6, 30, 600, 5)]:
         x, q = uniform(3000, 32, 77), uniform(300, 32, 78)
         ref = oracle.OracleIndex(32, max_edges=M, max_candidates=efc, min_nn=ef, collection_size=3000)
@@ -133,7 +133,7 @@ def test_draining_launch_with_ties_shadow_traversals(Index, monkeypatch, shadow)
     # idle waves start exact "shadow" traversals of the jobs still running (graph_search_kernel), and whoever finishes
     # first answers.  Every answer must still be the oracle's, with the shadows on and off, and on the hashed visited
     # set as well.
-    monkeypatch.setenv("HNSW_MI355X_SHADOW", shadow)
+    set_diag(monkeypatch, shadow=shadow)
     rng = np.random.default_rng(11)
     x = rng.integers(0, 4, (6000, 12)).astype(np.float32)
     x += rng.random((6000, 12), dtype=np.float32) * np.float32(1e-3) * (rng.random((6000, 1)) < 0.7)  # ties in a third of the rows
@@ -142,7 +142,7 @@ def test_draining_launch_with_ties_shadow_traversals(Index, monkeypatch, shadow)
     ref.add_batched(x, 16384)
     want = ref.knn_query(q, 10)
     for vis_hash in ("0", "1"):
-        monkeypatch.setenv("HNSW_MI355X_VIS_HASH", vis_hash)
+        set_diag(monkeypatch, vis_hash=vis_hash)
         ix = _build(Index, x, 12, 60, 48, 16384)
         assert ix.graph_hash() == ref.graph_hash()
         for _ in range(2):
@@ -193,7 +193,7 @@ def test_row_loads_overlapped_with_visited_atomics(Index, monkeypatch, overlap):
     # launches that do not fill the chip fetch the rows of all listed neighbours together with the
     # visited atomics (2 forces that for every launch, 0 forbids it): same results either way
     from common import uniform
-    monkeypatch.setenv("HNSW_MI355X_OVERLAP", overlap)
+    set_diag(monkeypatch, overlap=overlap)
     x, q = uniform(8000, 20, 601), uniform(20_000, 20, 602)
     ref = oracle.OracleIndex(20, max_edges=10, max_candidates=60, min_nn=32, collection_size=8000)
     ref.add_batched(x, 16384)
@@ -205,11 +205,11 @@ def test_row_loads_overlapped_with_visited_atomics(Index, monkeypatch, overlap):
     ref.reset_n_eval()
     ix.knn_query(q[:2000], 7); ref.knn_query(q[:2000], 7)
     # evaluations are counted for the unvisited neighbours only, overlapped or not -- unless the launch ran without a visited set
-    # (hash-table graphs, forced from outside by HNSW_MI355X_VIS_HASH=1): then every row measured counts
+    # (hash-table graphs, forced from outside by diagnostic vis_hash=1): then every row measured counts
     st = ix.stats()
     from common import novis_active
     if novis_active(st):
-        assert st["search_evals"] >= ref.n_eval - 2000 * (1 + ref.levels().max())
+        assert ref.n_eval - 2000 * (1 + ref.levels().max()) <= st["search_evals"] <= 1.15 * ref.n_eval + 2000 * (1 + ref.levels().max())
     else:
         assert abs(st["search_evals"] - ref.n_eval) <= 2000 * (1 + ref.levels().max())
 
@@ -223,10 +223,10 @@ def test_visited_id_hash_table(Index, monkeypatch, sorted_top, novis, cap, expec
     # the shadow traversals of a draining launch do -- whether one of those fills a 512-entry table is a matter of timing,
     # so that leg checks the answers only
     from common import uniform
-    monkeypatch.setenv("HNSW_MI355X_VIS_HASH", "1")
-    monkeypatch.setenv("HNSW_MI355X_VIS_HASH_CAP", cap)
-    monkeypatch.setenv("HNSW_MI355X_SORTED_TOP", sorted_top)
-    monkeypatch.setenv("HNSW_MI355X_NOVIS", novis)
+    set_diag(monkeypatch, vis_hash="1")
+    set_diag(monkeypatch, vis_hash_cap=cap)
+    set_diag(monkeypatch, sorted_top=sorted_top)
+    set_diag(monkeypatch, novis=novis)
     x, q = uniform(6000, 24, 701), uniform(6000, 24, 702)
     ref = oracle.OracleIndex(24, max_edges=8, max_candidates=50, min_nn=96, collection_size=6000)
     ref.add_batched(x, 16384)

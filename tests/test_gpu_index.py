@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from common import default_cap, golden_cases, load_golden, normalize_f32, self_recall_at_1, uniform
+from common import default_cap, golden_cases, load_golden, normalize_f32, self_recall_at_1, set_diag, uniform
 
 pytestmark = pytest.mark.gpu
 
@@ -200,9 +200,9 @@ def test_candidate_heap_spill_and_handback_are_exact(Index, monkeypatch, spill_c
     ref = oracle.OracleIndex(64, collection_size=4000, min_nn=64)
     ref.add_batched(x, 512)
     want_ids, want_d = ref.knn_query(q, 10)
-    monkeypatch.setenv("HNSW_MI355X_SORTED_TOP", "0")   # the two-heap traversal is the one with a candidate heap
-    monkeypatch.setenv("HNSW_MI355X_CAND_CAP", "24")
-    monkeypatch.setenv("HNSW_MI355X_SPILL_CAP", spill_cap)
+    set_diag(monkeypatch, sorted_top="0")   # the two-heap traversal is the one with a candidate heap
+    set_diag(monkeypatch, cand_cap="24")
+    set_diag(monkeypatch, spill_cap=spill_cap)
     ix = Index(64); ix.set_collection_size(4000); ix.set_min_nn(64); ix.set_insert_batch(512)
     ix.add(x)
     assert ix.graph_hash() == ref.graph_hash()
@@ -212,7 +212,11 @@ def test_candidate_heap_spill_and_handback_are_exact(Index, monkeypatch, spill_c
     assert (ix.stats()["search_overflows"] > 0) == expect_handback
 
 
-def test_search_stats_count_device_evaluations(Index):
+@pytest.mark.parametrize("novis", ["2", "0"])
+def test_search_stats_count_device_evaluations(Index, monkeypatch, novis):
+    # novis=2 is the default (search launches keep no visited set and count every row they MEASURE); novis=0 keeps the sets:
+    # the device then evaluates exactly the reference's pairs
+    set_diag(monkeypatch, novis=novis)
     x, q = uniform(3000, 64, 71), uniform(500, 64, 72)
     ix = Index(64); ix.set_collection_size(3000)
     ix.add(x)
@@ -225,13 +229,15 @@ def test_search_stats_count_device_evaluations(Index):
     ref = oracle.OracleIndex(64, collection_size=3000); ref.add_batched(x, default_cap()); ref.reset_n_eval(); ref.knn_query(q, 10)
     # same traversal => same evaluations, except that the oracle re-measures the layer-0 entry
     # point once per query (GraphNavigator.cs:200) and re-measures the start node on each upper layer
+    slack = 500 * (1 + ref.levels().max())
     from common import novis_active
+    assert novis_active(s) == (novis == "2")
     if novis_active(s):
-        # hash-table graphs (forced here by HNSW_MI355X_VIS_HASH=1) are searched WITHOUT a visited set: the kernel counts the rows it
-        # measures, which includes neighbours the reference had already seen and skips
-        assert s["search_evals"] >= ref.n_eval - 500 * (1 + ref.levels().max())
+        # without a visited set the kernel also measures neighbours the reference had already seen and skips: a few per cent more
+        # rows, never fewer -- and never many more (a broken listed-id lookup would re-measure every neighbour)
+        assert ref.n_eval - slack <= s["search_evals"] <= 1.15 * ref.n_eval + slack
     else:
-        assert abs(s["search_evals"] - ref.n_eval) <= 500 * (1 + ref.levels().max())
+        assert abs(s["search_evals"] - ref.n_eval) <= slack
 
 
 def test_config_c1_full_size_sequential(Index):
@@ -274,7 +280,7 @@ def test_mfma_prefiltered_heuristic_decides_like_the_exact_one(Index, monkeypatc
     # floats): the approximate dot products only ever settle a comparison whose margin exceeds the rounding
     # bound; everything else is measured exactly -- so the graph is the oracle's, with the prefilter on or off.
     # "long": rows of length 3 under ucosine (the bound assumes unit rows: those blocks must take the exact path).
-    monkeypatch.setenv("HNSW_MI355X_MFMA", mfma)
+    set_diag(monkeypatch, mfma=mfma)
     n, M, efc = 2500, 24, 300
     x = uniform(n, dim, 71)
     if kind == "unit":
@@ -353,11 +359,11 @@ def test_range_query_runs_on_the_device_and_hands_back_what_it_must(Index, metri
     assert same(1e30, q[:3]) == 3 * n            # the whole graph: beyond a wave's list, run again with lists as long as the graph
     assert ix.stats()["range_launches"] >= 2 and ix.stats()["range_handbacks"] == 0
     # per-wave visited hash tables (graphs above 4M nodes), forced here
-    monkeypatch.setenv("HNSW_MI355X_VIS_HASH", "1")
+    set_diag(monkeypatch, vis_hash="1")
     ix.reset_stats()
     assert same(0.9, q) > 200
     assert ix.stats()["visited_hash_launches"] >= 1 and ix.stats()["range_handbacks"] == 0
-    monkeypatch.setenv("HNSW_MI355X_VIS_HASH_CAP", "64")   # (raised to 4096:) 3072 visited ids, then the traversal is handed back
+    set_diag(monkeypatch, vis_hash_cap="64")   # (raised to 4096:) 3072 visited ids, then the traversal is handed back
     ix.reset_stats()
     assert same(1.3, q) > 10000
     assert 0 < ix.stats()["range_handbacks"] < len(q)
@@ -528,28 +534,29 @@ def test_batched_removal_matches_its_cpu_restatement(Index, metric, batch):
     assert (c == d).all() and ix.graph_hash() == ref.graph_hash()
 
 
-@pytest.mark.parametrize("metric", ["sq_euclid", "cosine", "ucosine"])
-def test_mfma_entry_block_decides_first_passes_like_the_exact_pass(Index, metric, monkeypatch):
-    """The queries' shared first hop -- entry point + its top-layer edges against the whole batch -- as one dense MFMA block
-    (entry_block_kernel, csrc/dk_entry_block.h): a prefilter whose verdicts must be the exact pass's.  Same ids and distance
-    bits with it on and off and from the oracle; fewer rows measured with it on."""
-    n, dim = 40000, 64
-    x, q = uniform(n, dim, 301), uniform(3000, dim, 302)
+@pytest.mark.parametrize("metric", ["sq_euclid", "ucosine", "sq_euclid_i8"])
+@pytest.mark.parametrize("hooks", [dict(lat=0), dict(lat=2), dict(novis_insert=0), dict(lat=2, novis_insert=0), dict(novis=0, lat=2)])
+def test_forced_traversal_forms_build_and_answer_like_the_oracle(Index, monkeypatch, metric, hooks):
+    """The switches that pick a traversal form -- the latency variants never / whenever possible, Add's searches with their visited
+    sets kept, the search launches with theirs -- set IN the suite (they are read on every call): graph hash and answers must be
+    the oracle's under each of them, for batches small enough for the latency variants and for a batch that fills the chip."""
+    set_diag(monkeypatch, **hooks)
+    n, dim = 5000, 48
+    x, q = uniform(n, dim, 321), uniform(700, dim, 322)
     if metric == "ucosine":
         x, q = normalize_f32(x), normalize_f32(q)
-    ix = Index(dim, metric); ix.set_collection_size(n); ix.set_min_nn(32)
-    ix.add(x)
-    top = int(ix.levels().max())
-    assert top >= 1 and len(ix.edges(ix.entry_point, top)) >= 2, "the data must give the entry point neighbours on its top layer"
-    out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("HNSW_MI355X_MFMA_ENTRY", mode)
-        ix.reset_stats()
-        out[mode] = ix.knn_query(q, 10) + (ix.stats(),)
-    assert out["0"][2]["entry_block_launches"] == 0 and out["1"][2]["entry_block_launches"] >= 1
-    assert (out["0"][0] == out["1"][0]).all() and out["0"][1].tobytes() == out["1"][1].tobytes()
-    assert out["1"][2]["search_evals"] < out["0"][2]["search_evals"]          # first passes were decided without their rows
-    ref = oracle.OracleIndex(dim, metric, min_nn=32, collection_size=n)
-    ref.import_graph(x, ix.levels(), ix.entry_point, [ix.export_edges(l, 34 if l == 0 else 18) for l in range(top + 1)])
-    rids, rd = ref.knn_query(q, 10)
-    assert (out["1"][0] == rids).all() and out["1"][1].tobytes() == rd.tobytes()
+    ix = Index(dim, metric); ix.set_collection_size(n); ix.set_max_candidates(70); ix.set_min_nn(48); ix.set_insert_batch(4096)
+    ref = oracle.OracleIndex(dim, metric, max_candidates=70, min_nn=48, collection_size=n)
+    ix.add(x[:4000]); ref.add_batched(x[:4000], 4096)
+    for i in range(4000, n, 40):                                  # small calls: the latency variants' launches (when allowed)
+        ix.add(x[i:i + 40]); ref.add_batched(x[i:i + 40], 4096)
+    assert ix.graph_hash() == ref.graph_hash()
+    for qs in (q, q[:9]):
+        a, b = ix.knn_query(qs, 10), ref.knn_query(qs, 10)
+        assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
+    st = ix.stats()
+    if hooks.get("lat") == 0:
+        assert st["lat_launches"] == 0
+    if hooks.get("lat") == 2:
+        assert st["lat_launches"] > 0
+

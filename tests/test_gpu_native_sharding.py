@@ -105,7 +105,12 @@ def test_eight_contexts_and_how_the_replicas_travelled(Index):
     assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
     direct = sum(eight.stats_at(g)["peer_direct_copies"] for g in range(1, 8))
     staged = sum(eight.stats_at(g)["peer_staged_copies"] for g in range(1, 8))
-    assert direct >= 7 and staged == 0, (direct, staged)
+    # how a replica travelled is a property of the machine: a refused peer access is counted, not an error.  Every copy is one
+    # or the other; `staged` must be zero only where all contexts share one device (this pool's one-GPU boxes)
+    assert direct + staged >= 7, (direct, staged)
+    import hnswindex
+    if hnswindex.net_amd.lib.hnswdev_device_count() == 1:
+        assert staged == 0, (direct, staged)
     for g in range(1, 8):
         st = eight.stats_at(g)
         assert st["replica_bytes"] > 0 and st["search_launches"] >= 1

@@ -48,9 +48,9 @@ def _run(tmp_path, dim, nq, env_extra, tag):
 
 @pytest.mark.parametrize("dim,nq", [(128, 40000), (512, 33000)])
 def test_streamed_upload_answers_like_the_plain_one_and_the_oracle(tmp_path, dim, nq):
-    plain, s_plain = _run(tmp_path, dim, nq, {"HNSW_MI355X_STREAM_QUERIES": "0"}, "plain")
+    plain, s_plain = _run(tmp_path, dim, nq, {"HNSW_MI355X_DIAG": "stream_queries=0"}, "plain")
     for shadow in ("1", "0"):
-        got, s_got = _run(tmp_path, dim, nq, {"HNSW_MI355X_STREAM_QUERIES": "1", "HNSW_MI355X_SHADOW": shadow}, "s" + shadow)
+        got, s_got = _run(tmp_path, dim, nq, {"HNSW_MI355X_DIAG": "stream_queries=1,shadow=" + shadow}, "s" + shadow)
         assert got["graph_hash"] == plain["graph_hash"]
         assert got["digests"] == plain["digests"], f"streamed upload (shadows {shadow}) answered differently"
         assert s_got.tobytes() == s_plain.tobytes()

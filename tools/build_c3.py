@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("HNSW_MI355X_TRACE", "1")
+os.environ.setdefault("HNSW_MI355X_DIAG", "trace=1")
 sys.path.insert(0, ".")
 import hnswindex  # noqa: E402
 

@@ -1,11 +1,11 @@
-"""Build the C2 index once with the host-side phase timers on (HNSW_MI355X_TRACE=1)."""
+"""Build the C2 index once with the host-side phase timers on (HNSW_MI355X_DIAG=trace=1)."""
 import os
 import sys
 import time
 
 import numpy as np
 
-os.environ.setdefault("HNSW_MI355X_TRACE", "1")
+os.environ.setdefault("HNSW_MI355X_DIAG", "trace=1")
 sys.path.insert(0, ".")
 import hnswindex  # noqa: E402
 

@@ -40,6 +40,12 @@ def cases():
     out.append((dict(name="removals", n=500, dim=24, metric="cosine", nq=32, k=8, max_edges=8, max_candidates=60, min_nn=8,
                      collection_size=512, random_seed=99, remove=[int(i) for i in np.random.default_rng(5).permutation(500)[:120]]),
                 data(500, 24, "cosine", 31), data(32, 24, "cosine", 32)))
+    # C2-shaped (BASELINE configs[1] at a size one core builds in seconds): i.i.d. uniform 128-d rows, M = 16, efConstruction = 200,
+    # ef = 128.  At this beam width ~2 % of the inserts find two EQUAL float distances among their 200 candidates, and for ~0.3 % the
+    # selection depends on the order Span.Sort leaves equal keys in (Heuristic.cs:22; DESIGN.md 4.2 rule 3): 20 000 sequential inserts
+    # exercise a few dozen of those -- the BCL behaviour the oracle restates from memory.  (Its snapshot is ~12 MB: rows included.)
+    out.append((dict(name="c2_shape_20k", n=20000, dim=128, metric="sq_euclid", nq=64, k=10, max_edges=16, max_candidates=200, min_nn=128,
+                     collection_size=20000, random_seed=31337, allow_removals=False), data(20000, 128, "sq_euclid", 65537), data(64, 128, "sq_euclid", 65538)))
     return out
 
 

@@ -1,4 +1,4 @@
-"""B = 1 adds with the host phase timers on (HNSW_MI355X_TRACE=1) and HIP events around the kernels: where a 1.1-ms add goes."""
+"""B = 1 adds with the host phase timers on (HNSW_MI355X_DIAG=trace=1) and HIP events around the kernels: where a 1.1-ms add goes."""
 import json, sys, time
 from pathlib import Path
 import numpy as np
