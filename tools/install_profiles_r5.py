@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
-"""Copies the summaries produced by tools/run_profiles_r4.sh (gpurun_out/profiles4/) into profiles/ under the r4 prefix and
+"""Copies the summaries produced by tools/run_profiles_r5.sh (gpurun_out/profiles5/) into profiles/ under the r5 prefix and
 derives
-  r4_gather_ceilings.json   what random row gathers reach on this chip per row size (tools/gather_bench) and the FETCH_SIZE
-                            calibration factor for each (known bytes / counter bytes)
-  r4_pmc_traffic.json       per configuration: PMC traffic per launch of graph_search_kernel (and over the whole build for the
-                            two Add kernels) against the algorithmic bytes -- bench.py quotes these as roofline.traffic
-  r4_mfma_utilisation.json  C3 insert kernel: MFMA flop/s against the fp32 matrix peak
-python tools/install_profiles_r4.py"""
+  r5_gather_ceilings.json   what random row gathers reach on this chip per row size (tools/gather_bench): from a table far beyond the
+                            Infinity Cache ("rows", with the FETCH_SIZE calibration factor: known bytes / counter bytes) AND from a table
+                            of each configuration's own size ("by_table": what bench.py prices frac_of_measured_gather against)
+  r5_pmc_traffic.json       per configuration: PMC traffic per launch of graph_search_kernel (and over the whole build for the
+                            two Add kernels) against the algorithmic bytes, stamped with the build id of the library that was measured --
+                            bench.py quotes roofline.traffic only when that id is the running library's
+  r5_issue_counters.json    instruction-issue counters of the product search kernels (C5-size at 12 500 and 65 536 per call, C4-size, C2)
+  r5_mfma_utilisation.json  C3 insert kernel: MFMA flop/s against the fp32 matrix peak
+python tools/install_profiles_r5.py"""
 import json
 import re
 import shutil
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-src, dst, r = ROOT / "gpurun_out" / "profiles4", ROOT / "profiles", "r4"
+src, dst, r = ROOT / "gpurun_out" / "profiles5", ROOT / "profiles", "r5"
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 
@@ -55,6 +58,18 @@ for rb in (128, 512, 3072):
 v1 = src / "gather_128_v1.log"
 if v1.exists():
     ceil["rows"]["128"]["one_16_byte_load_per_lane_GBps"] = max(float(m.group(1)) for m in re.finditer(r"([0-9.]+) GB/s", v1.read_text()))
+ceil["by_table"] = []
+for cfg, rb, rows in (("c2", 512, 1_000_000), ("c3", 3072, 1_000_000), ("c4", 512, 10_000_000), ("c5", 128, 10_000_000)):
+    log = src / f"gather_own_{cfg}.log"
+    if log.exists():
+        best = max(float(m.group(1)) for m in re.finditer(r"([0-9.]+) GB/s", log.read_text()))
+        ceil["by_table"].append({"config": cfg, "row_bytes": rb, "table_bytes": rows * rb, "best_GBps": best, "rows_per_s": best * 1e9 / rb,
+                                 "note": "uniform random rows of a table of this configuration's own size (a table near the 256-MiB Infinity Cache is served partly from it)"})
+if not ceil["rows"]:  # the >> cache pass was not re-run this round: keep last round's figures
+    prev = dst / "r4_gather_ceilings.json"
+    if prev.exists():
+        ceil["rows"] = json.load(open(prev))["rows"]
+        ceil["rows_measured_in"] = "round 4 (profiles/r4_gather_ceilings.json)"
 json.dump(ceil, open(dst / f"{r}_gather_ceilings.json", "w"), indent=1)
 
 
@@ -74,20 +89,23 @@ def counter(path, cname, kernel):
     return tot
 
 
-traffic = {"round": 4, "note": "FETCH_SIZE (KB) x 1024 x calibration factor of that row size + WRITE_SIZE (KB) x 1024, per launch; the counters tally "
+traffic = {"round": 5, "build_id": None, "note": "FETCH_SIZE (KB) x 1024 x calibration factor of that row size + WRITE_SIZE (KB) x 1024, per launch; the counters tally "
                                 "memory-side requests of the L2s: Infinity-Cache hits are counted (guide, HBM section)", "configs": {}}
-for cfg, rb in (("c2", 512), ("c3", 3072), ("c4", 512), ("c5", 128)):
+for cfg, rb in (("c2", 512), ("c3", 3072), ("c4", 512), ("c5", 128), ("c5L", 128)):
     fj, wj, bl = src / f"{cfg}_fetch.json", src / f"{cfg}_write.json", src / f"bench_{cfg}_fetch.log"
     if not (fj.exists() and wj.exists() and bl.exists()):
         continue
     b = bench(bl)
     if not b:
         continue
+    if traffic["build_id"] not in (None, b.get("build_id")):
+        raise SystemExit(f"{cfg}: measured on build {b.get('build_id')}, the other passes on {traffic['build_id']}")
+    traffic["build_id"] = b.get("build_id")
     f = factor(rb)
     e = {"workload": {k: b["config"][k] for k in ("n", "dim", "queries_per_gpu_per_step", "ef_search", "k", "max_edges")}, "row_bytes_fetched": rb,
          "calibration_factor": f}
     fs, ws = counter(fj, "FETCH_SIZE", "graph_search_kernel"), counter(wj, "WRITE_SIZE", "graph_search_kernel")
-    alg = b["roofline"]["evals_per_launch"] * b["roofline"]["bytes_per_eval"]
+    alg = b["roofline"]["evals_per_launch"] * b["roofline"]["bytes_per_eval"]   # (no CPU leg under the profiler: rows measured by the device)
     t = fs["sum"] / fs["dispatches"] * 1024 * f + ws["sum"] / ws["dispatches"] * 1024
     e["graph_search_kernel"] = {"FETCH_SIZE_KB_per_launch": fs["sum"] / fs["dispatches"], "WRITE_SIZE_KB_per_launch": ws["sum"] / ws["dispatches"],
                                 "traffic_bytes_per_launch": t, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": t / alg}
@@ -103,6 +121,40 @@ for cfg, rb in (("c2", 512), ("c3", 3072), ("c4", 512), ("c5", 128)):
                        "traffic_over_algorithmic": ta / a}
     traffic["configs"][cfg] = e
 json.dump(traffic, open(dst / f"{r}_pmc_traffic.json", "w"), indent=1)
+
+# ---- instruction issue of the product search kernels ----
+issue = {"round": 5, "note": "rocprofv3 --pmc, one pass per counter group, bench.py --steps 2 (every dispatch of the search kernel in the run averaged: the timed steps, "
+                             "the resident and recall calls -- all of the same size); SQ_* cycle counters are in quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs. "
+                             "The launches run with shadow traversals (idle waves of a draining launch start exact traversals of the jobs still running): their instructions are in these counts",
+         "kernels": {}}
+for cfg, what in (("c5", "C5-size: 10M x 96 int8 records, 12 500 queries per call"), ("c5L", "C5-size, 65 536 queries per call"),
+                  ("c4", "C4-size: 10M x 128 f32, 12 500 queries per call"), ("c2", "C2: 1M x 128 f32, 65 536 queries per call")):
+    ja, jb = src / f"{cfg}_issue_a.json", src / f"{cfg}_issue_b.json"
+    if not (ja.exists() and jb.exists()):
+        continue
+    ca, cb = json.load(open(ja))["counters"], json.load(open(jb))["counters"]
+    ka = [k for k in ca if "graph_search_kernel" in k]
+    if not ka:
+        continue
+    k = max(ka, key=lambda x: ca[x]["SQ_WAVE_CYCLES"]["sum"])
+    A = {c: v["avg_per_dispatch"] for c, v in ca[k].items()}
+    B = {c: v["avg_per_dispatch"] for c, v in cb.get(k, {}).items()}
+    cyc = A["GRBM_GUI_ACTIVE"] / 8.0
+    wave_cycles = A["SQ_WAVE_CYCLES"] * 4.0
+    e = {"config": what, "kernel": k, "counters_per_launch": {**A, **B}, "kernel_cycles": cyc,
+         "avg_waves_per_simd": wave_cycles / cyc / 1024.0,
+         "valu_instructions_per_launch": A["SQ_INSTS_VALU"], "salu_instructions_per_launch": A["SQ_INSTS_SALU"],
+         "instructions_per_vmem_read": (A["SQ_INSTS_VALU"] + A["SQ_INSTS_SALU"] + A["SQ_INSTS_LDS"]) / max(1.0, A["SQ_INSTS_VMEM_RD"])}
+    if B:
+        e.update({"valu_pipe_busy_fraction": B["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0),
+                  "scalar_issue_fraction_per_cu": B["SQ_ACTIVE_INST_SCA"] * 4.0 / (cyc * 1024.0),
+                  "wave_time_executing": B["SQ_ACTIVE_INST_ANY"] / A["SQ_WAVE_CYCLES"],
+                  "wave_time_waiting_for_issue": B["SQ_WAIT_INST_ANY"] / A["SQ_WAVE_CYCLES"],
+                  "wave_time_waiting_on_memory_or_dependencies": 1.0 - (B["SQ_ACTIVE_INST_ANY"] + B["SQ_WAIT_INST_ANY"]) / A["SQ_WAVE_CYCLES"]})
+    issue["kernels"][cfg] = e
+if issue["kernels"]:
+    json.dump(issue, open(dst / f"{r}_issue_counters.json", "w"), indent=1)
+    print("issue", {k: (round(v["avg_waves_per_simd"], 2), round(v.get("valu_pipe_busy_fraction", 0), 3), round(v.get("wave_time_waiting_on_memory_or_dependencies", 0), 3)) for k, v in issue["kernels"].items()})
 
 # ---- MFMA utilisation of the C3 insert kernel ----
 mj, bl = src / "c3_mfma.json", src / "bench_c3_mfma.log"
