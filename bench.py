@@ -812,6 +812,12 @@ def main():
                     "schedule (add_modes.bounded, every rung). The reference DEFINES a graph only for HNSWIndex.Add(item) one item after the other (HNSWIndex.cs:55-65): "
                     "add_per_sec_reference_graph builds that one through exact windows (add_modes.exact_window), add_modes.sequential is the same graph one call per item. "
                     "add_modes.batched is the opt-in 65536-item snapshot of rounds 1-4 (hnsw_mi355x_set_insert_batch(65536)): ~10x the rate, outside any real host's outcome set",
+        "tie_order_exposure": {
+            "inserts_answered_by_the_exact_traversal": int(build_stats.get("insert_tie_reruns", 0)), "of_inserts": a.n,
+            "share": round(build_stats.get("insert_tie_reruns", 0) / max(1, a.n), 6),
+            "queries_answered_by_the_exact_traversal_per_step": round(sum(c["search_repeats"] for c in st_all) / max(1, a.steps), 2), "of_queries_per_step": per_gpu * ndev_native,
+            "note": "searches whose outcome rests on the order of EQUAL keys -- Span.Sort's (Heuristic.cs:22), the heaps' layout -- BCL behaviour the oracle and the product "
+                    "restate from memory: the part of 'parity unpinned' that real .NET fixtures would pin (tools/dotnet_fixture, case c2_shape_20k)"},
         "build_evals": build_stats["evals"] + build_stats["search_evals"],
         "build_launches": build_stats["launches"] + build_stats["search_launches"],
         "replicas_identical": replicas_identical,

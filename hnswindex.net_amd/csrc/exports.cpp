@@ -2,6 +2,7 @@
 // (/root/reference/bindings/HNSWIndex.Native/HNSWIndexExports.cs:27-273), same names,
 // signatures, return codes and padding, over the MI355X-backed HnswIndex.
 #include <algorithm>
+#include <chrono>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -145,6 +146,9 @@ API int hnsw_range_query(void *handle, const float *vectors, int count, int dim,
         LOCK_INDEX(handle);
         if (static_cast<HnswIndex *>(handle)->range_query(vectors, count, dim, range, res, err) < 0) { set_error(err); return -1; }
     }
+    const bool trace = hnsw::diag("trace", 0) != 0;
+    const auto t_out0 = std::chrono::steady_clock::now();
+    struct OutTimer { bool on; std::chrono::steady_clock::time_point t0; int count; ~OutTimer() { if (on) fprintf(stderr, "[hnsw trace] hnsw_range_query: handing out %d per-query arrays %.4fs\n", count, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); } } out_timer{trace, t_out0, count};
     for (int i = 0; i < count; ++i) { // callee-allocated per-query arrays (Marshal.AllocHGlobal :172-173), freed by hnsw_free_results
         const int n = (int)res[(size_t)i].size();
         if (n > 0) {

@@ -602,6 +602,7 @@ constexpr int kBatchGrowthDiv = 16, kEarlyGrowthDiv = 4, kEarlyLinked = 65536;
 struct PhaseTimers {
     double sync_graph = 0, search_half = 0, collect = 0, link_host = 0, link_dev = 0, post = 0, query_dev = 0, set_queries = 0;
     double add_nodes = 0, add_upload = 0, add_total = 0;
+    double rq_batch = 0, rq_sort = 0, rq_refresh = 0, rq_replay = 0; long rq_replayed = 0, rq_queries = 0; // RangeQuery on the device: launch + copies, host sort, list refresh, heap replays
     double xw_total = 0, xw_todo = 0, xw_launch = 0, xw_parse = 0, xw_pairs = 0, xw_valid = 0, xw_link = 0; // the exact window's rounds
     long xw_end[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // what ended a round's prefix: 0 window exhausted, 1 stale result (searched on an older graph, list written since), 2 second change of a list,
                                                // 3 change with unknown lost ids, 4 reader answered by the exact traversal, 5 expansion without a bound, 6 the change shows (pair distance), 7 upper layers / overflow
@@ -667,6 +668,9 @@ HnswIndex::~HnswIndex()
                         "reader took the exact traversal %ld, expansion without a bound %ld, the change shows %ld, upper layers / no read log %ld\n",
                 g_pt.xw_total, g_pt.xw_todo, g_pt.xw_launch, g_pt.xw_parse, g_pt.xw_pairs, g_pt.xw_valid, g_pt.xw_link,
                 g_pt.xw_end[0], g_pt.xw_end[1], g_pt.xw_end[2], g_pt.xw_end[3], g_pt.xw_end[4], g_pt.xw_end[5], g_pt.xw_end[6], g_pt.xw_end[7]);
+    if (g_pt.on && g_pt.rq_queries > 0)
+        fprintf(stderr, "[hnsw trace] range queries=%ld: device launch + copies %.4fs, host sort %.4fs, host list refresh %.4fs, heap replays %.4fs (%ld lists held equal distances)\n",
+                g_pt.rq_queries, g_pt.rq_batch, g_pt.rq_sort, g_pt.rq_refresh, g_pt.rq_replay, g_pt.rq_replayed);
     engine_.reset(); // before the device it allocates from
     for (auto &l : lanes_) l.reset();
     replicas_.clear();
@@ -1719,7 +1723,8 @@ int HnswIndex::range_query_device(int count, float range, std::vector<std::vecto
     const int ep = graph_.entry, top = graph_.top_layer();
     for (int i = 0; i < count; ++i) jobs[(size_t)i] = SearchJob{i, ep, top, 0, -1};
     Device::RangeResults r;
-    if (!dev_->range_batch(jobs.data(), count, range, &r)) { err = get_dev_error(); return -1; }
+    g_pt.rq_queries += count;
+    { Tick t(g_pt.rq_batch); if (!dev_->range_batch(jobs.data(), count, range, &r)) { err = get_dev_error(); return -1; } }
     // host threads over the queries: sort each result list; a list holding two equal distances is replayed instead
     auto parallel_for = [&](size_t n, size_t grain, const std::function<void(size_t, size_t)> &body) {
         std::atomic<size_t> next{0};
@@ -1733,6 +1738,7 @@ int HnswIndex::range_query_device(int count, float range, std::vector<std::vecto
         for (std::thread &t : pool) t.join();
     };
     std::vector<unsigned char> state((size_t)count, 0); // 1: hand-back (lock-step), 2: equal distances (replay)
+    double t_sort0 = g_pt.on ? now_s() : 0;
     parallel_for((size_t)count, 256, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             if (r.flag[i]) { state[i] = 1; continue; }
@@ -1746,13 +1752,16 @@ int HnswIndex::range_query_device(int count, float range, std::vector<std::vecto
             for (size_t a = 0; a < o.size(); ++a) o[a] = NodeDist{b[a].id, b[a].dist};
         }
     });
+    if (g_pt.on) g_pt.rq_sort += now_s() - t_sort0;
     std::vector<int> redo, replay;
     for (int i = 0; i < count; ++i) {
         if (state[(size_t)i] == 1) redo.push_back(i);
         else if (state[(size_t)i] == 2) replay.push_back(i);
     }
+    g_pt.rq_replayed += (long)replay.size();
     if (!replay.empty()) {
-        if (!refresh_host_lists(err)) return -1; // the replay walks the host's copy of the lists
+        { Tick t(g_pt.rq_refresh); if (!refresh_host_lists(err)) return -1; } // the replay walks the host's copy of the lists
+        Tick t_rep(g_pt.rq_replay);
         parallel_for(replay.size(), 1, [&](size_t lo, size_t hi) {
             for (size_t t = lo; t < hi; ++t) {
                 const int i = replay[t];
