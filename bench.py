@@ -764,7 +764,17 @@ def main():
                     f = (np.log(level) - np.log(r0)) / max(1e-9, np.log(r_) - np.log(r0))
                     return int(np.ceil(float(np.exp(np.log(b0) + f * (np.log(b) - np.log(b0))) - 1e-9)))  # the smallest call that wins
             return None
-        crossover = {"queries_per_call": sizes, "gpu_queries_per_sec": rates,
+        # where a ONE-query call's time goes: HIP events around its launch (a second pass, so that the events are not in the timed one)
+        ix.set_profiling(True); ix.reset_stats()
+        for r_ in range(40):
+            ix.knn_query(q_sets[r_ % R][r_:r_ + 1], a.k)
+        s1 = ix.stats(); ix.set_profiling(False)
+        k1 = s1["search_kernel_ms"] / max(1, s1["search_timed_launches"])
+        one_call = {"ms_per_call": round(1e3 / rates[0], 4), "kernel_ms": round(k1, 4), "fixed_ms": round(1e3 / rates[0] - k1, 4),
+                    "cpu_one_thread_ms_per_query": round(1e3 / cpu["single_thread_queries_per_s"], 4),
+                    "note": "fixed = job upload, launch, one result copy, the wait (five HIP calls); the kernel is ONE traversal on two waves (latency variant): "
+                            "a chain of ~150 dependent expansions, which alone is longer than the CPU's query out of its caches"}
+        crossover = {"queries_per_call": sizes, "gpu_queries_per_sec": rates, "one_query_call": one_call,
                      "cpu_one_thread_queries_per_sec": cpu["single_thread_queries_per_s"], f"cpu_{cores}_threads_queries_per_sec": cpu["value"],
                      "crossover_vs_one_cpu_thread": first_above(cpu["single_thread_queries_per_s"]),
                      f"crossover_vs_{cores}_cpu_threads": first_above(cpu["value"]),

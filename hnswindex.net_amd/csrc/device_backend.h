@@ -61,6 +61,11 @@ struct SearchJob {
     int stop_layer;   // insert search: the last layer this job searches (0 = all the way down; the exact-window Add
                       // runs the upper layers of a multi-layer item ahead of time, and its layer 0 as a job of its own)
 };
+// RangeQuery: state of a job's result list after the finishing kernels (dk_range_finish.h).  The list in the arena is ...
+constexpr int kRangeFinal = 0;    // ... in the reference's order
+constexpr int kRangeTied = 2;     // ... ascending, with equal distances in it: to be replayed (range_replay_kernel did not: the host does)
+constexpr int kRangeHostSort = 5; // ... as found: too long for the device ranking, or a -0 distance (host: sort, replay if tied)
+
 struct SearchHit {
     int id;
     float dist;
@@ -231,7 +236,9 @@ public:
     struct RangeResults {
         std::vector<unsigned long long> off;
         std::vector<int> cnt, flag, entry; // entry[i]: the layer-0 entry node FindEntryPointQuery reached
-        std::vector<SearchHit> found;
+        std::vector<int> state;            // kRangeFinal: found[] holds the reference's order; kRangeTied: ascending, equal distances to replay; kRangeHostSort: as found
+        SearchHit *found = nullptr;        // the lists, in pinned memory the context owns: valid until its next range_batch
+        size_t found_n = 0;
     };
     bool range_batch(const SearchJob *jobs, int njobs, float range, RangeResults *res);
     // the C ABI's form: sorted per query, equal distances handed back; results kept until the next call
@@ -328,6 +335,10 @@ private:
     size_t s_arena_cap_ = 0;
     unsigned long long *s_roff_ = nullptr, *s_arena_used_ = nullptr;
     int *s_rentry_ = nullptr;
+    SearchHit *h_range_ = nullptr;     // RangeQuery results on the host (pinned, grown on demand, filled by ONE device-to-host copy per launch)
+    size_t h_range_cap_ = 0;
+    bool range_host_room(size_t entries, size_t keep);
+    int *s_rstate_ = nullptr, *s_rtied_ = nullptr, *s_rfin_ctr_ = nullptr; // RangeQuery's finishing kernels: per-job state, the tied jobs, two job counters
     SearchHit *s_rlists_ = nullptr; // range search: long per-wave result lists for the few jobs that outgrow s_spill_'s
     size_t s_rlists_cap_ = 0;
     double range_hint_ = 48.0;      // results per query of the last range search (sizes the next arena)

@@ -281,13 +281,14 @@ Device::~Device()
     phase_report("teardown");
 #endif
     for (void *p : {(void *)g_adj0_, (void *)g_level_, (void *)g_upper_, (void *)g_pool_, (void *)g_tested0_, (void *)g_testedU_, (void *)s_visited_, (void *)s_jobs_,
-                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_rlog_, (void *)s_dry_, (void *)s_wdry_, (void *)s_win_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_})
+                    (void *)s_hits_, (void *)s_cnt_, (void *)s_flag_, (void *)s_jobctr_, (void *)s_vistab_, (void *)lp_slot_[0], (void *)lp_slot_[1], (void *)lp_slot_[2], (void *)lp_grp_[0], (void *)lp_grp_[1], (void *)lp_grp_[2], (void *)lp_grp_[3], (void *)lp_grp_[4], (void *)lp_grp_[5], (void *)lp_counters_, (void *)s_evals_, (void *)s_sel_, (void *)s_lcnt_, (void *)s_selU_, (void *)s_cntU_, (void *)s_iflag_, (void *)s_lk_[0], (void *)s_lk_[1], (void *)s_lk_[2], (void *)s_lk_[3], (void *)s_lk_[4], (void *)s_spill_, (void *)s_order_, (void *)s_rlog_, (void *)s_dry_, (void *)s_wdry_, (void *)s_win_, (void *)s_arena_, (void *)s_roff_, (void *)s_arena_used_, (void *)s_rentry_, (void *)s_rlists_, (void *)s_rl_, (void *)s_rstate_, (void *)s_rtied_, (void *)s_rfin_ctr_})
         if (p) (void)hipFree(p);
     if (ev0_) (void)hipEventDestroy((hipEvent_t)ev0_);
     if (ev1_) (void)hipEventDestroy((hipEvent_t)ev1_);
     if (ev2_) (void)hipEventDestroy((hipEvent_t)ev2_);
     if (h_stage_) (void)hipHostFree(h_stage_);
     if (h_res_) (void)hipHostFree(h_res_);
+    if (h_range_) (void)hipHostFree(h_range_);
     for (LinkSet &ls : lset_) {
         if (ls.h_in) (void)hipHostFree(ls.h_in);
         if (ls.h_out) (void)hipHostFree(ls.h_out);
@@ -1920,13 +1921,31 @@ bool Device::patch_lists(const int *recs, int nrows, int row_stride)
 // call's results per query (at least 1M entries); the jobs that did not fit run once more in an arena of exactly
 // the size they asked for.  Jobs whose result set outgrew a wave's list (kSpillCap entries) run again, few at a
 // time, with lists as long as the graph.
+// Room for `entries` results in the pinned host buffer, the first `keep` of which survive a reallocation.
+bool Device::range_host_room(size_t entries, size_t keep)
+{
+    if (entries <= h_range_cap_) return true;
+    const size_t cap = std::max(entries + entries / 2, (size_t)1 << 20);
+    SearchHit *p = nullptr;
+    if (hipHostMalloc((void **)&p, sizeof(SearchHit) * cap, hipHostMallocDefault) != hipSuccess) { set_dev_error("range_batch: pinned allocation failed"); return false; }
+    if (h_range_) {
+        if (keep) memcpy(p, h_range_, sizeof(SearchHit) * keep);
+        (void)hipHostFree(h_range_);
+    }
+    h_range_ = p;
+    h_range_cap_ = cap;
+    return true;
+}
+
 bool Device::range_batch(const SearchJob *jobs, int njobs, float range, RangeResults *res)
 {
     res->off.assign((size_t)std::max(njobs, 0), 0ull);
     res->cnt.assign((size_t)std::max(njobs, 0), 0);
     res->flag.assign((size_t)std::max(njobs, 0), 0);
     res->entry.assign((size_t)std::max(njobs, 0), -1);
-    res->found.clear();
+    res->state.assign((size_t)std::max(njobs, 0), kRangeHostSort);
+    res->found = nullptr;
+    res->found_n = 0;
     if (njobs <= 0) return true;
     if (!jobs) { set_dev_error("range_batch: bad argument"); return false; }
     if (g_n_ <= 0) { set_dev_error("range_batch: no graph uploaded"); return false; }
@@ -1953,9 +1972,15 @@ bool Device::range_batch(const SearchJob *jobs, int njobs, float range, RangeRes
         s_roff_ = nullptr; s_rentry_ = nullptr; s_roff_cap_ = 0;
         HIP_OK(hipMalloc(&s_roff_, sizeof(unsigned long long) * (size_t)chunk));
         HIP_OK(hipMalloc(&s_rentry_, sizeof(int) * (size_t)chunk));
+        if (s_rstate_) HIP_OK(hipFree(s_rstate_));
+        if (s_rtied_) HIP_OK(hipFree(s_rtied_));
+        s_rstate_ = nullptr; s_rtied_ = nullptr;
+        HIP_OK(hipMalloc(&s_rstate_, sizeof(int) * (size_t)chunk));
+        HIP_OK(hipMalloc(&s_rtied_, sizeof(int) * ((size_t)chunk + 1)));
         s_roff_cap_ = (size_t)chunk;
     }
     if (!s_arena_used_) HIP_OK(hipMalloc(&s_arena_used_, sizeof(unsigned long long)));
+    if (!s_rfin_ctr_) HIP_OK(hipMalloc(&s_rfin_ctr_, sizeof(int) * 2));
     constexpr size_t kArenaMax = (size_t)1 << 27; // 1 GB of results per launch; what does not fit then is handed back
 
     // One launch over the jobs listed in `todo` (at most `chunk`): results appended to res->found; jobs that found
@@ -1965,7 +1990,7 @@ bool Device::range_batch(const SearchJob *jobs, int njobs, float range, RangeRes
         if (!grow_dev(&s_arena_, &s_arena_cap_, arena_cap)) return false;
         // pinned layout: [evals, used (16 B) | jobs | offsets | counts | flags | entries]; then reused for the results
         const size_t b_jobs = sizeof(SearchJob) * (size_t)nj, b_off = 8u * (size_t)nj, b_i = 4u * (size_t)nj;
-        char *hs = static_cast<char *>(pinned_stage(16 + b_jobs + b_off + 3 * b_i));
+        char *hs = static_cast<char *>(pinned_stage(16 + b_jobs + b_off + 4 * b_i));
         if (!hs) return false;
         SearchJob *h_jobs = reinterpret_cast<SearchJob *>(hs + 16);
         for (int i = 0; i < nj; ++i) h_jobs[i] = jobs[todo[i]];
@@ -1993,11 +2018,29 @@ bool Device::range_batch(const SearchJob *jobs, int njobs, float range, RangeRes
 #undef LAUNCH_RANGE
 #undef LAUNCH_RANGE2
         HIP_OK(hipGetLastError());
+        // the ORDER, still on the device (dk_range_finish.h): every finished list ranked ascending in place; the lists that hold equal
+        // distances replayed -- the reference's two heaps on the distances just found -- and ranked in heap-array order.  What these
+        // hand back (lists beyond kRangeSortMax entries, -0 distances) the callers sort and replay on the host as before.
+        const int finish = diag("range_finish", 2); // 0: order left to the host (as until round 5), 1: ranking only, 2: ranking and replays
+        HIP_OK(hipMemsetAsync(s_rfin_ctr_, 0, sizeof(int) * 2, st));
+        HIP_OK(hipMemsetAsync(s_rtied_, 0, sizeof(int), st));
+        HIP_OK(hipMemsetAsync(s_rstate_, 0, sizeof(int) * (size_t)nj, st));
+        if (finish >= 1) {
+            hipLaunchKernelGGL(range_sort_kernel, dim3(std::min(nj, 8 * std::max(1, num_cu_))), dim3(64), 0, st, reinterpret_cast<ND *>(s_arena_), s_roff_, s_cnt_, s_flag_, nj,
+                               s_rstate_, s_rtied_, s_rfin_ctr_);
+            HIP_OK(hipGetLastError());
+        }
+        if (finish >= 2) {
+            hipLaunchKernelGGL(range_replay_kernel, dim3(std::min(nj, 2 * std::max(1, num_cu_))), dim3(64), sizeof(RangeReplayLds) + 64, st, reinterpret_cast<ND *>(s_arena_), s_roff_,
+                               s_cnt_, s_rentry_, g_adj0_, g_stride0_, g_n_, range, s_rstate_, s_rtied_, s_rfin_ctr_ + 1);
+            HIP_OK(hipGetLastError());
+        }
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev1_, st));
         unsigned long long *h_hdr = reinterpret_cast<unsigned long long *>(hs);
         unsigned long long *h_off = reinterpret_cast<unsigned long long *>(hs + 16 + b_jobs);
         int *h_cnt = reinterpret_cast<int *>(hs + 16 + b_jobs + b_off);
-        int *h_flag = h_cnt + nj, *h_entry = h_flag + nj;
+        int *h_flag = h_cnt + nj, *h_entry = h_flag + nj, *h_state = h_entry + nj;
+        HIP_OK(hipMemcpyAsync(h_state, s_rstate_, b_i, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(h_hdr, s_evals_, 8, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(h_hdr + 1, s_arena_used_, 8, hipMemcpyDeviceToHost, st));
         HIP_OK(hipMemcpyAsync(h_off, s_roff_, b_off, hipMemcpyDeviceToHost, st));
@@ -2009,7 +2052,7 @@ bool Device::range_batch(const SearchJob *jobs, int njobs, float range, RangeRes
         // entries claimed beyond arena_cap belong to the jobs flagged 3 and were never written; the claims of the
         // finished jobs all lie below it, though not contiguously: the span they cover is copied back
         unsigned long long span = 0, finished = 0;
-        const size_t base = res->found.size();
+        const size_t base = res->found_n;
         for (int i = 0; i < nj; ++i) {
             const int j = todo[i];
             res->entry[(size_t)j] = h_entry[i];
@@ -2017,24 +2060,21 @@ bool Device::range_batch(const SearchJob *jobs, int njobs, float range, RangeRes
             if (h_flag[i] == 0) {
                 res->off[(size_t)j] = base + h_off[i];
                 res->cnt[(size_t)j] = h_cnt[i];
+                res->state[(size_t)j] = finish >= 1 ? h_state[i] : kRangeHostSort;
+                if (h_cnt[i] >= 2) { if (res->state[(size_t)j] == kRangeFinal) stats_.range_device_ordered++; else stats_.range_host_ordered++; }
                 finished += (unsigned long long)h_cnt[i];
                 if (h_cnt[i] > 0) span = std::max(span, h_off[i] + (unsigned long long)h_cnt[i]);
             } else if (h_flag[i] == 3) again.push_back(j);
             else { res->flag[(size_t)j] = 1; handed.push_back(j); }
         }
         *need = used - finished;
-        if (span > 0) { // (the stage is reused from here on: everything above has been consumed)
-            res->found.resize(base + (size_t)span);
-            const size_t piece = (size_t)8 << 20; // entries per copy (64 MB)
-            for (size_t o = 0; o < (size_t)span; o += piece) {
-                const size_t nn = std::min(piece, (size_t)span - o);
-                char *hr = static_cast<char *>(pinned_stage(sizeof(SearchHit) * nn));
-                if (!hr) return false;
-                HIP_OK(hipMemcpyAsync(hr, s_arena_ + o, sizeof(SearchHit) * nn, hipMemcpyDeviceToHost, st));
-                HIP_OK(hipStreamSynchronize(st));
-                memcpy(res->found.data() + base + o, hr, sizeof(SearchHit) * nn);
-            }
+        if (span > 0) { // one copy, straight into the context's pinned result buffer (no staging hop, nothing zero-filled first)
+            if (!range_host_room(base + (size_t)span, base)) return false;
+            HIP_OK(hipMemcpyAsync(h_range_ + base, s_arena_, sizeof(SearchHit) * (size_t)span, hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            res->found_n = base + (size_t)span;
         }
+        res->found = h_range_;
         if (vis_tab) stats_.visited_hash_launches++;
         stats_.search_launches++;
         stats_.search_evals += ev;
@@ -2110,10 +2150,12 @@ bool Device::range_search(const float *queries, int nq, int entry_point, float r
         out_counts[i] = 0;
         out_flags[i] = r.flag[(size_t)i];
         if (out_flags[i]) continue;
-        SearchHit *b = r.found.data() + r.off[(size_t)i], *e = b + r.cnt[(size_t)i];
-        std::sort(b, e, range_hit_less);
-        bool tie = false;
-        for (SearchHit *p = b; p + 1 < e; ++p) tie |= p[0].dist == p[1].dist; // also -0 next to +0
+        SearchHit *b = r.found + r.off[(size_t)i], *e = b + r.cnt[(size_t)i];
+        bool tie = r.state[(size_t)i] == kRangeTied; // (the device replays what it can: this is what it handed back)
+        if (r.state[(size_t)i] == kRangeHostSort) {
+            std::sort(b, e, range_hit_less);
+            for (SearchHit *p = b; p + 1 < e; ++p) tie |= p[0].dist == p[1].dist; // also -0 next to +0
+        }
         out_counts[i] = r.cnt[(size_t)i];
         if (tie) { // OrderBy keeps the heap array's order there (HNSWIndex.cs:155): replay the heaps on the committed graph
             std::vector<NodeDist> ordered;

@@ -11,6 +11,7 @@
 //   dk_pool_top.h        SearchLayer on an unsorted register pool (the latency variants' logic wave)
 //   dk_traverse_exact.h  the exact two-heap traversal
 //   dk_heuristic.h       RelativeNeighborPruning (with its MFMA Gram-block prefilter)
+//   dk_range_finish.h   RangeQuery's order on the device: ranking by counting, the heaps replayed on known distances
 //   dk_search_kernels.h  graph_search_kernel, graph_range_kernel
 //   dk_insert_kernels.h  graph_insert_search_kernel
 //   dk_link.h            the link half of Add, Remove's re-link
@@ -28,6 +29,7 @@
 #include "dk_traverse_exact.h"
 #include "dk_heuristic.h"
 #include "dk_search_kernels.h"
+#include "dk_range_finish.h"
 #include "dk_insert_kernels.h"
 #include "dk_link.h"
 #include "dk_misc_kernels.h"

@@ -2,6 +2,8 @@
 // (/root/reference/bindings/HNSWIndex.Native/HNSWIndexExports.cs:27-273), same names,
 // signatures, return codes and padding, over the MI355X-backed HnswIndex.
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <chrono>
 #include <cstddef>
 #include <cstdio>
@@ -149,23 +151,37 @@ API int hnsw_range_query(void *handle, const float *vectors, int count, int dim,
     const bool trace = hnsw::diag("trace", 0) != 0;
     const auto t_out0 = std::chrono::steady_clock::now();
     struct OutTimer { bool on; std::chrono::steady_clock::time_point t0; int count; ~OutTimer() { if (on) fprintf(stderr, "[hnsw trace] hnsw_range_query: handing out %d per-query arrays %.4fs\n", count, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); } } out_timer{trace, t_out0, count};
-    for (int i = 0; i < count; ++i) { // callee-allocated per-query arrays (Marshal.AllocHGlobal :172-173), freed by hnsw_free_results
-        const int n = (int)res[(size_t)i].size();
-        if (n > 0) {
-            int *ids = static_cast<int *>(std::malloc(sizeof(int) * (size_t)n));
-            float *ds = static_cast<float *>(std::malloc(sizeof(float) * (size_t)n));
-            if (!ids || !ds) {
-                std::free(ids); std::free(ds);
-                hnsw_free_results(out_ids, out_dists, count);
-                for (int j = 0; j < count; ++j) counts[j] = 0;
-                set_error("System.OutOfMemoryException: hnsw_range_query");
-                return -1;
+    // callee-allocated per-query arrays (Marshal.AllocHGlobal :172-173), freed by hnsw_free_results: a call of thousands of queries hands out
+    // millions of results, so the copies are spread over host threads (malloc is thread-safe; a failed allocation fails the call as before)
+    std::atomic<int> next{0};
+    std::atomic<bool> oom{false};
+    auto work = [&]() {
+        for (int i0; (i0 = next.fetch_add(256, std::memory_order_relaxed)) < count;)
+            for (int i = i0, e = std::min(count, i0 + 256); i < e; ++i) {
+                const int n = (int)res[(size_t)i].size();
+                if (n > 0) {
+                    int *ids = static_cast<int *>(std::malloc(sizeof(int) * (size_t)n));
+                    float *ds = static_cast<float *>(std::malloc(sizeof(float) * (size_t)n));
+                    if (!ids || !ds) { std::free(ids); std::free(ds); oom.store(true); continue; }
+                    for (int j = 0; j < n; ++j) { ids[j] = res[(size_t)i][(size_t)j].id; ds[j] = res[(size_t)i][(size_t)j].dist; }
+                    out_ids[i] = ids;
+                    out_dists[i] = ds;
+                    counts[i] = n;
+                }
             }
-            for (int j = 0; j < n; ++j) { ids[j] = res[(size_t)i][(size_t)j].id; ds[j] = res[(size_t)i][(size_t)j].dist; }
-            out_ids[i] = ids;
-            out_dists[i] = ds;
-        }
-        counts[i] = n;
+    };
+    {
+        const int nth = count >= 2048 ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u) : 1;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nth; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+    }
+    if (oom.load()) {
+        hnsw_free_results(out_ids, out_dists, count);
+        for (int j = 0; j < count; ++j) counts[j] = 0;
+        set_error("System.OutOfMemoryException: hnsw_range_query");
+        return -1;
     }
     return 0;
 }

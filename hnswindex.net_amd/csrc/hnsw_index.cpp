@@ -1598,7 +1598,7 @@ void HnswIndex::collect_stats(hnswdev_stats *out)
         out->search_launches += s.search_launches; out->search_evals += s.search_evals; out->search_timed_launches += s.search_timed_launches;
         out->search_timed_evals += s.search_timed_evals; out->search_kernel_ms += s.search_kernel_ms; out->search_overflows += s.search_overflows;
         out->search_repeats += s.search_repeats; out->visited_hash_launches += s.visited_hash_launches;
-        out->tie_windows += s.tie_windows; out->lat_launches += s.lat_launches; out->peer_direct_copies += s.peer_direct_copies; out->peer_staged_copies += s.peer_staged_copies; out->insert_tie_reruns += s.insert_tie_reruns;
+        out->tie_windows += s.tie_windows; out->lat_launches += s.lat_launches; out->peer_direct_copies += s.peer_direct_copies; out->peer_staged_copies += s.peer_staged_copies; out->insert_tie_reruns += s.insert_tie_reruns; out->range_device_ordered += s.range_device_ordered; out->range_host_ordered += s.range_host_ordered;
     }
 }
 
@@ -1742,10 +1742,12 @@ int HnswIndex::range_query_device(int count, float range, std::vector<std::vecto
     parallel_for((size_t)count, 256, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             if (r.flag[i]) { state[i] = 1; continue; }
-            SearchHit *b = r.found.data() + r.off[i], *e = b + r.cnt[i];
-            std::sort(b, e, [](const SearchHit &x, const SearchHit &y) { return x.dist < y.dist; }); // no NaN: d <= range held
-            bool tie = false;
-            for (SearchHit *p = b; p + 1 < e; ++p) tie |= p[0].dist == p[1].dist; // also -0 next to +0
+            SearchHit *b = r.found + r.off[i], *e = b + r.cnt[i];
+            bool tie = r.state[i] == kRangeTied; // ascending, equal distances in it, and the device did not replay it
+            if (r.state[i] == kRangeHostSort) {  // beyond the device ranking's reach (length, a -0 distance): as until round 5
+                std::sort(b, e, [](const SearchHit &x, const SearchHit &y) { return x.dist < y.dist; }); // no NaN: d <= range held
+                for (SearchHit *p = b; p + 1 < e; ++p) tie |= p[0].dist == p[1].dist; // also -0 next to +0
+            }
             if (tie) { state[i] = 2; continue; }
             std::vector<NodeDist> &o = out[i];
             o.resize((size_t)(e - b));
@@ -1766,7 +1768,7 @@ int HnswIndex::range_query_device(int count, float range, std::vector<std::vecto
             for (size_t t = lo; t < hi; ++t) {
                 const int i = replay[t];
                 replay_range_heaps([&](int id) { return graph_.list(id, 0); }, graph_.max_edges_at(0), r.entry[(size_t)i], range,
-                                   r.found.data() + r.off[(size_t)i], r.cnt[(size_t)i], out[(size_t)i]);
+                                   r.found + r.off[(size_t)i], r.cnt[(size_t)i], out[(size_t)i]);
             }
         });
     }

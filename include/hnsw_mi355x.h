@@ -272,6 +272,8 @@ typedef struct hnswdev_stats {
     uint64_t peer_direct_copies;    /* replica / query-set copies between contexts whose devices have peer access enabled (one device: counted here) */
     uint64_t peer_staged_copies;    /* ... and those the runtime had to stage through host memory (no peer access between the two devices) */
     uint64_t lat_launches;          /* traversal launches that ran the latency variant of their kernel (fewer jobs than its resident waves) */
+    uint64_t range_device_ordered;  /* RangeQuery result lists (of two or more entries) whose ORDER the device completed: ranked, and replayed where distances tie */
+    uint64_t range_host_ordered;    /* ... and those handed to the host for it (beyond 2 048 entries, a -0 distance, a replay the device gave up) */
     uint64_t insert_tie_reruns;     /* Add searches answered by the exact two-heap traversal because equal distances could show in what the insert
                                      * consumes in order (Span.Sort among equal keys, Heuristic.cs:22; heap layout at the far end of the list): the inserts
                                      * whose outcome rests on BCL tie behaviour this build restates from memory -- the "parity unpinned" exposure as a number

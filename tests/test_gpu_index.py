@@ -560,3 +560,40 @@ def test_forced_traversal_forms_build_and_answer_like_the_oracle(Index, monkeypa
     if hooks.get("lat") == 2:
         assert st["lat_launches"] > 0
 
+
+@pytest.mark.parametrize("metric", ["sq_euclid", "ucosine", "sq_euclid_i8"])
+def test_range_order_is_completed_on_the_device(Index, metric):
+    """RangeQuery's ORDER on the device (csrc/dk_range_finish.h): lists of distinct distances are ranked by counting, lists that hold
+    equal distances are replayed -- the reference's two heaps on the distances already found -- and ranked in heap-array order.
+    Coordinates on a coarse grid: nearly every result list holds ties, several hundred entries long; every id and distance bit
+    must be the oracle's, and the host must have been left only what the kernels hand back by design (lists beyond 2 048 entries)."""
+    n, dim = 9000, 8
+    rng = np.random.default_rng(77)
+    x = (rng.integers(0, 6, (n, dim)) / 4).astype(np.float32)
+    x += (rng.random((n, dim), dtype=np.float32) * np.float32(1e-3)) * (rng.random((n, 1)) < 0.5)   # half the rows off the grid
+    q = (rng.integers(0, 6, (600, dim)) / 4).astype(np.float32)
+    if metric == "ucosine":
+        x, q = normalize_f32(x + 0.25), normalize_f32(q + 0.25)
+    ix = Index(dim, metric); ix.set_collection_size(n); ix.set_max_edges(12); ix.set_insert_batch(2048)
+    ix.add(x)
+    ref = oracle.OracleIndex(dim, metric, max_edges=12, collection_size=n); ref.add_batched(x, 2048)
+    assert ix.graph_hash() == ref.graph_hash()
+    radii = {"sq_euclid": (0.8, 1.6, 3.0), "sq_euclid_i8": (0.8, 1.6, 3.0), "ucosine": (0.02, 0.05, 0.12)}[metric]
+    for radius in radii:
+        ix.reset_stats()
+        a_ids, a_d = ix.range_query(q, radius)
+        tied = longest = 0
+        for lo in range(0, len(q), 200):
+            b_ids, b_d = ref.range_query(q[lo:lo + 200], radius, cap=n)
+            for a, b, c, d in zip(a_ids[lo:lo + 200], a_d[lo:lo + 200], b_ids, b_d):
+                assert a.tolist() == c.tolist() and b.tobytes() == d.tobytes(), (metric, radius)
+                tied += int(len(b) > 1 and (np.diff(b) == 0).any())
+                longest = max(longest, len(b))
+        st = ix.stats()
+        assert st["range_handbacks"] == 0
+        lists = sum(1 for b in a_d if len(b) >= 2)
+        big = sum(1 for b in a_d if len(b) > 2048)
+        assert st["range_device_ordered"] + st["range_host_ordered"] == lists
+        assert st["range_host_ordered"] <= big + sum(1 for b in a_d if (b == 0).any()), (st["range_host_ordered"], big)   # (a -0 distance sends a list to the host)
+    assert tied > 100 and longest > 300, (tied, longest)
+

@@ -13,7 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 x = np.random.default_rng(65537).random((n, 768), dtype=np.float32)
 x /= np.sqrt((x * x).sum(axis=1, dtype=np.float32, keepdims=True))
 ix = hnswindex.Index(768, "ucosine")
-ix.set_collection_size(n); ix.set_max_edges(32); ix.set_max_candidates(400); ix.set_min_nn(128)
+ix.set_collection_size(n); ix.set_max_edges(32); ix.set_max_candidates(400); ix.set_min_nn(128); ix.set_insert_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 65536)
 ix.set_profiling(True)
 t = time.time(); ix.add(x); dt = time.time() - t
 s = ix.stats()

@@ -25,7 +25,7 @@ def main():
     legs = len(Ws) + 1
     x = np.random.default_rng(65537).random((N + legs * T, dim), dtype=np.float32)
     ix = hnswindex.Index(dim)
-    ix.set_collection_size(N + legs * T); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_allow_removals(False)
+    ix.set_collection_size(N + legs * T); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_allow_removals(False); ix.set_insert_batch(65536)
     t0 = time.time(); ix.add(x[:N]); t_build = time.time() - t0
     ref = None
     if cpu:

@@ -10,7 +10,7 @@ import hnswindex  # noqa: E402
 n, dim = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 128
 x = np.random.default_rng(65537).random((n, dim), dtype=np.float32)
 ix = hnswindex.Index(dim)
-ix.set_collection_size(n); ix.set_max_edges(16); ix.set_max_candidates(200); ix.set_min_nn(128)
+ix.set_collection_size(n); ix.set_max_edges(16); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_insert_batch(65536)
 t = time.time(); ix.add(x); print(f"build {n / (time.time() - t):.0f} adds/s", flush=True)
 ix.set_profiling(True)
 for nq in [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else (10_000, 12_288, 16_384, 24_576, 32_768, 65_536, 131_072):

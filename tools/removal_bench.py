@@ -16,8 +16,7 @@ hashes = {}
 for mode in (("device", "host") if n <= 200_000 else ("device",)):   # the lock-step mode builds at 5 k adds/s: small indexes only
     ix = Index(dim); ix.set_collection_size(n); ix.set_max_candidates(200); ix.set_min_nn(128)
     ix.set_device_traversal(mode == "device")
-    if mode == "host":
-        ix.set_insert_batch(65536)
+    ix.set_insert_batch(65536)               # the large snapshots (opt-in since round 5): the oracle below builds under the same cap
     ix.add(x)
     ix.remove(ids[:50])                      # warm (graph fetch, kernels)
     mm = m if n <= 200_000 else min(m, 3000)  # the sequential legs on a bounded sample
@@ -30,7 +29,7 @@ for mode in (("device", "host") if n <= 200_000 else ("device",)):   # the lock-
         got = ix.knn_query(q, 10)
 # the batched schedule (hnsw_mi355x_set_remove_batch): removals with disjoint neighbourhoods together
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-ix = Index(dim); ix.set_collection_size(n); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_remove_batch(B)
+ix = Index(dim); ix.set_collection_size(n); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_remove_batch(B); ix.set_insert_batch(65536)
 ix.add(x)
 ix.remove(ids[:50])
 ix.reset_stats()

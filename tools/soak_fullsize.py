@@ -23,6 +23,7 @@ rng = np.random.default_rng(65537)
 x = rng.random((n, dim), dtype=np.float32)
 ix = hnswindex.Index(dim, metric)
 ix.set_collection_size(n); ix.set_max_edges(M); ix.set_max_candidates(efc); ix.set_min_nn(ef); ix.set_allow_removals(False)
+ix.set_insert_batch(65536)   # the opt-in large snapshots: a 10M build in seconds (the graph is imported into the oracle below whatever the schedule)
 t = time.time(); ix.add(x); tb = time.time() - t
 lv = ix.levels()
 ref = oracle.OracleIndex(dim, metric, max_edges=M, max_candidates=efc, min_nn=ef, collection_size=n, allow_removals=False)
