@@ -54,6 +54,16 @@ def test_quantiser_and_distance_follow_the_stated_definition(dim):
     assert oracle.metric("sq_euclid_i8", x[9], x[9]) == 0    # identical records: exactly zero
 
 
+@pytest.mark.parametrize("dim", DIMS)
+def test_the_avx2_form_of_the_int8_distance_is_the_scalar_one_bit_for_bit(dim):
+    # the CPU baselines time the AVX2 form (bench.py: use_avx=True); it must be the spec's scalar byte loop to the bit
+    rng = np.random.default_rng(1000 + dim)
+    x = np.concatenate([uniform(64, dim, 3), (uniform(64, dim, 4) - 0.5) * np.float32(5.0), rng.standard_normal((16, dim)).astype(np.float32)])
+    x[3] = 0.0
+    for a, b in [(0, 1), (2, 100), (3, 7), (64, 65), (130, 9), (143, 143)] + [tuple(rng.integers(0, 144, 2)) for _ in range(40)]:
+        assert oracle.metric("sq_euclid_i8", x[a], x[b], use_avx=True).tobytes() == oracle.metric("sq_euclid_i8", x[a], x[b], use_avx=False).tobytes()
+
+
 def test_int8_index_on_the_oracle():
     x = uniform(3000, 96, 11)
     ix = oracle.OracleIndex(96, "sq_euclid_i8", collection_size=3000)

@@ -58,6 +58,11 @@ for rb in (128, 512, 3072):
 v1 = src / "gather_128_v1.log"
 if v1.exists():
     ceil["rows"]["128"]["one_16_byte_load_per_lane_GBps"] = max(float(m.group(1)) for m in re.finditer(r"([0-9.]+) GB/s", v1.read_text()))
+prev_r5 = {}
+if (dst / f"{r}_gather_ceilings.json").exists():   # a partial re-run (one configuration's passes) must not drop what an earlier run measured
+    prev_r5 = json.load(open(dst / f"{r}_gather_ceilings.json"))
+for k, v in prev_r5.get("rows", {}).items():
+    ceil["rows"].setdefault(k, v)
 ceil["by_table"] = []
 for cfg, rb, rows in (("c2", 512, 1_000_000), ("c3", 3072, 1_000_000), ("c4", 512, 10_000_000), ("c5", 128, 10_000_000)):
     log = src / f"gather_own_{cfg}.log"
@@ -65,6 +70,8 @@ for cfg, rb, rows in (("c2", 512, 1_000_000), ("c3", 3072, 1_000_000), ("c4", 51
         best = max(float(m.group(1)) for m in re.finditer(r"([0-9.]+) GB/s", log.read_text()))
         ceil["by_table"].append({"config": cfg, "row_bytes": rb, "table_bytes": rows * rb, "best_GBps": best, "rows_per_s": best * 1e9 / rb,
                                  "note": "uniform random rows of a table of this configuration's own size (a table near the 256-MiB Infinity Cache is served partly from it)"})
+have = {e["config"] for e in ceil["by_table"]}
+ceil["by_table"] += [e for e in prev_r5.get("by_table", []) if e["config"] not in have]
 if not ceil["rows"]:  # the >> cache pass was not re-run this round: keep last round's figures
     prev = dst / "r4_gather_ceilings.json"
     if prev.exists():

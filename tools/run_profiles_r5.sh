@@ -83,6 +83,14 @@ for cfg in ${ISSUE_CFGS:-c5 c5L c4 c2}; do
   if [ $cfg = c5L ]; then pmc c5L_fetch FETCH_SIZE $A; pmc c5L_write WRITE_SIZE $A; fi
 done
 fi
+if [ $WHAT = pmc_rest ]; then # only the PMC traffic passes of the 10M / 768-d configurations (after a change of the library: bench.py quotes traffic per build id)
+pmc c4_fetch FETCH_SIZE $C4
+pmc c4_write WRITE_SIZE $C4
+pmc c5_fetch FETCH_SIZE $C5
+pmc c5_write WRITE_SIZE $C5
+pmc c3_fetch FETCH_SIZE $C3
+pmc c3_write WRITE_SIZE $C3
+fi
 if [ $WHAT = icache ]; then # instruction-cache behaviour of the two big kernels (search launches and the 1M build)
 pmc c2_icache "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"
 pmc c5_icache "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" $C5
