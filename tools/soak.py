@@ -18,6 +18,7 @@ dim = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
 clustered = len(sys.argv) > 4 and sys.argv[4] == "clustered"  # Gaussian mixture: the heuristic rejects far more than on uniform data
 metric = sys.argv[5] if len(sys.argv) > 5 else "sq_euclid"
+CAP = int(__import__('os').environ.get('SOAK_CAP', 16384))  # Add's snapshot cap, product and oracle alike (256: what the library defaults to on a 256-thread host)
 fails = 0
 for seed, (M, efc, ef, k) in enumerate([(16, 200, 128, 10), (8, 100, 64, 5), (24, 300, 256, 20)]):
     rng = np.random.default_rng(900 + seed)
@@ -33,10 +34,10 @@ for seed, (M, efc, ef, k) in enumerate([(16, 200, 128, 10), (8, 100, 64, 5), (24
         q = (q / np.sqrt((q * q).sum(axis=1, dtype=np.float32, keepdims=True))).astype(np.float32)
     ix = hnswindex.Index(dim, metric)
     ix.set_collection_size(n); ix.set_max_edges(M); ix.set_max_candidates(efc); ix.set_min_nn(ef)
-    ix.set_insert_batch(16384); ix.set_allow_removals(False)
+    ix.set_insert_batch(CAP); ix.set_allow_removals(False)
     t = time.time(); ix.add(x); tb = time.time() - t
     ref = oracle.OracleIndex(dim, metric, max_edges=M, max_candidates=efc, min_nn=ef, collection_size=n, allow_removals=False)
-    t = time.time(); ref.add_batched(x, 16384, threads=16); tr = time.time() - t
+    t = time.time(); ref.add_batched(x, CAP, threads=16); tr = time.time() - t
     same_graph = ix.graph_hash() == ref.graph_hash()
     s0 = ix.stats()
     got = ix.knn_query(q, k)
