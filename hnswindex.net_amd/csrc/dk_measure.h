@@ -82,6 +82,22 @@ __device__ __forceinline__ void measure_pass(const float *__restrict__ rows, con
     }
 }
 
+// lane P of each 8-lane group takes candidate P's dot sum, scale and sumsq (see the end of measure_pass_i8)
+template <int P, int NP>
+__device__ __forceinline__ void i8_gather_lane(const int (&acc)[NP], const int (&tr)[NP], int j, int &dj, int &saj, int &naj)
+{
+    if constexpr (P < NP) {
+        const int dot = group_sum_i32(acc[P]);
+        const int sa = __builtin_amdgcn_mov_dpp(tr[P], 0x100 + (6 - P) /* row_shl: lane P reads the group's lane 6 */, 0xf, 0xf, true);
+        const int na = __builtin_amdgcn_mov_dpp(tr[P], 0x100 + (7 - P) /* lane 7 */, 0xf, 0xf, true);
+        const bool mine = (j == P);
+        dj = mine ? dot : dj;
+        saj = mine ? sa : saj;
+        naj = mine ? na : naj;
+        i8_gather_lane<P + 1, NP>(acc, tr, j, dj, saj, naj);
+    }
+}
+
 // int8 records: NP candidates per lane group, every load of the pass issued before any arithmetic (one
 // memory round trip for up to 8 * NP records); qs = the query's record staged in LDS.
 template <int NP, int NB>
@@ -90,11 +106,9 @@ __device__ __forceinline__ void measure_pass_i8(const float *__restrict__ rows, 
 {
     const int grp = lane >> 3, j = lane & 7;
     const int *a[NP];
-    int cidx[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int c = p0 + grp + 8 * p;
-        cidx[p] = c;
         const int id = nbuf[c < m ? c : p0]; // idle groups shadow a valid record
         a[p] = reinterpret_cast<const int *>(rows + (size_t)id * pitch);
     }
@@ -132,15 +146,17 @@ __device__ __forceinline__ void measure_pass_i8(const float *__restrict__ rows, 
     }
     const float sq = __int_as_float(iq[pitch - 2]);
     const int nq = iq[pitch - 1];
-    const int g6 = (lane & ~7) | 6, g7 = (lane & ~7) | 7;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int dot = group_sum_i32(acc[p]);
-        const float sa = __int_as_float(__shfl(tr[p], g6, 64));
-        const int na = __shfl(tr[p], g7, 64);
-        const float r = i8_epilogue(sa, na, sq, nq, dot);
-        if (j == 0 && cidx[p] < m) dbuf[cidx[p]] = r;
-    }
+    // ONE epilogue per pass: lane p of a group finishes the group's candidate p (the double arithmetic of i8_epilogue is ~20
+    // instructions; run once per candidate register it was half of the pass's instruction count, and the int8 traversal is bound
+    // by instruction issue).  Every lane of a group holds the group's dot sums; the scale and sumsq of candidate p
+    // sit in lanes 6 / 7 of the group and reach lane p by row_shl:(6-p) / (7-p).
+    int dj = group_sum_i32(acc[0]);
+    int saj = group_lane_to_first<6>(tr[0]);
+    int naj = group_lane_to_first<7>(tr[0]);
+    i8_gather_lane<1, NP>(acc, tr, j, dj, saj, naj);
+    const float r = i8_epilogue(__int_as_float(saj), naj, sq, nq, dj);
+    const int c = p0 + grp + 8 * j;
+    if (j < NP && c < m) dbuf[c] = r;
 }
 template <int NP>
 __device__ __forceinline__ void measure_pass_i8_any(const float *rows, int pitch, const float *qs, const int *nbuf, float *dbuf, int p0, int m, int lane)

@@ -29,30 +29,59 @@ __device__ __forceinline__ float i8_epilogue(float sa, int na, float sb, int nb,
 }
 __device__ __forceinline__ int dot4_i8(int a, int b, int acc) { return __builtin_amdgcn_sdot4(a, b, acc, false); }
 // sum of an int over the 8 lanes of a group (every lane gets it)
+// (DPP, no LDS crossbar: lane ^ 1 and lane ^ 2 are quad permutations; after them the four lanes of a quad hold the same sum, so
+// the mirror inside the half row -- lane i <-> 7 - i, a lane of the group's OTHER quad -- completes it.  Exact integers: any
+// pairing gives the same sum.  Until round 5 these were three ds_bpermute with their address arithmetic: the int8 search
+// kernel issued 1 276 of them, and that kernel is bound by instruction issue)
 __device__ __forceinline__ int group_sum_i32(int v)
 {
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 1, 64);
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x141 /* row_half_mirror */, 0xf, 0xf, true);
     return v;
 }
+// what lane 8g + k of a group holds, brought to the group's lane 0 (the other lanes get whatever lies k lanes up their row of 16:
+// only lane 0 of a group uses the result)
+template <int K>
+__device__ __forceinline__ int group_lane_to_first(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, 0x100 + K /* row_shl:K */, 0xf, 0xf, true);
+}
 
-__device__ __forceinline__ float lane_xor_add(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
+// v + (the same register of lane ^ MASK), MASK in {1, 2, 4}, as DPP moves inside the row of 16 lanes -- no LDS crossbar (until round 5
+// these were __shfl_xor = ds_bpermute with its address arithmetic and an LDS round trip in every collapse; the pairings, and with them
+// every rounding, are the same: a + b is commutative, the TREE is what the reference fixes).  lane ^ 1 / ^ 2: quad permutations.
+// lane ^ 4: lane + 4 for the lower half of an 8-lane group (row_shl:4, written to banks 0 and 2 of the row = lanes 0-3, 8-11),
+// lane - 4 for the upper half (row_shr:4, banks 1 and 3).
+template <int MASK>
+__device__ __forceinline__ float lane_xor_add(float v)
+{
+    const int x = __float_as_int(v);
+    int o;
+    if constexpr (MASK == 1) o = __builtin_amdgcn_mov_dpp(x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
+    else if constexpr (MASK == 2) o = __builtin_amdgcn_mov_dpp(x, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
+    else {
+        static_assert(MASK == 4, "lane_xor_add: 1, 2 or 4");
+        o = __builtin_amdgcn_update_dpp(0, x, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+        o = __builtin_amdgcn_update_dpp(o, x, 0x114 /* row_shr:4 */, 0xf, 0xa, false);
+    }
+    return v + __int_as_float(o);
+}
 
 // Collapse of the eight lane partials, L2 order: EuclideanMetric.cs:45-50.
 __device__ __forceinline__ float collapse_l2(float p)
 {
-    float t = lane_xor_add(p, 4); // p_j + p_{j+4}
-    t = lane_xor_add(t, 1);       // (t0+t1), (t2+t3)
-    t = lane_xor_add(t, 2);       // (t0+t1)+(t2+t3)
+    float t = lane_xor_add<4>(p); // p_j + p_{j+4}
+    t = lane_xor_add<1>(t);       // (t0+t1), (t2+t3)
+    t = lane_xor_add<2>(t);       // (t0+t1)+(t2+t3)
     return t;
 }
 // Collapse, cosine-family order: CosineMetric.cs:145-171.
 __device__ __forceinline__ float collapse_cos(float p)
 {
-    float u = lane_xor_add(p, 4); // p_j + p_{j+4}
-    u = lane_xor_add(u, 2);       // (u0+u2), (u1+u3)
-    u = lane_xor_add(u, 1);       // (u0+u2)+(u1+u3)
+    float u = lane_xor_add<4>(p); // p_j + p_{j+4}
+    u = lane_xor_add<2>(u);       // (u0+u2), (u1+u3)
+    u = lane_xor_add<1>(u);       // (u0+u2)+(u1+u3)
     return u;
 }
 

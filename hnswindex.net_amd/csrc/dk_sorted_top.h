@@ -361,8 +361,10 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                     pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
                 }
             }
+            PHX(0);
             if (n > 0) measure_all<METRIC>(rows, row_sn, dim, qs, sb, nbuf, dbuf, n, lane); // :163 (and the visited ones)
             wave_sync();
+            PHX(1);
             lane_d = in ? dbuf[lane] : 0.0f;
             lane_id = nb_a;
             if (novis) {
@@ -372,6 +374,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                     have = in;
                     const unsigned kq = f2key(lane_d);
                     unsigned long long look = __ballot(in && (top_n < k || kq <= far_key));
+                    PHX_COUNT(3, __popcll(look));
                     unsigned long long listed = 0ull;
                     for (unsigned long long mm = look; mm; mm &= mm - 1) {
                         const int sl = (int)__builtin_ctzll(mm);
@@ -398,7 +401,8 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 V.seen += m;
                 if (V.crowded()) { hash_full = true; break; }
             }
-            PH(4);
+            PHX(2);
+            PHX_COUNT(4, m);
             if (m == 0) continue;
             evals += (unsigned long long)m;
         } else {
@@ -452,6 +456,8 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
             if (__ballot(valid && key_unsafe(my_d))) { unsafe = true; break; }
             if (grp_cnt > 0 && __ballot(valid && (my_key == grp_key || (top_n >= k && my_key == far_key)))) { tie = true; break; } // (a), (b)
             unsigned long long maybe = __ballot(valid && (top_n < k || my_key < far_key));
+            PHX_COUNT(5, __popcll(maybe));
+            PHY(8);
             if (rounds == 1 && maybe) {
                 // What the next pop returns is known before the insertions: the closest open entry, or a neighbour of this
                 // expansion that is closer.  In the second case the list prefetched above is the wrong one: request the
@@ -470,6 +476,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                     pre_b = lane + 64 < lstride ? pl[lane + 64] : 0;
                 }
             }
+            PHY(9);
 #ifndef HNSW_NO_BATCH_MERGE
             if (maybe & (maybe - 1)) { // two or more: one counting merge instead of as many list shifts
                 unsigned last = 0u;
@@ -487,6 +494,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                 maybe = 0ull;
             }
 #endif
+            PHY(10);
             while (maybe) {
                 const int src = __builtin_ctzll(maybe);
                 maybe &= maybe - 1;
@@ -507,6 +515,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
                     }
                 } else if (grp_cnt > 0 && dk == far_key) tie = true; // (b): turned away by equality
             }
+            PHY(11);
         }
         PH(5);
     }

@@ -1,7 +1,8 @@
-"""Does the default (snapshot-batched) Add schedule cost graph quality against the reference's own sequential graph?
-Builds the same n x dim set twice -- default schedule, and the SEQUENTIAL graph (HNSWIndex.Add(item) per item,
-HNSWIndex.cs:55-65) through the exact window -- and compares recall@10 (exact brute-force ground truth), the mean
-layer-0 out-degree and the build time.   usage: python tools/recall_study.py [n=1000000] [nq=2000] [window=64]"""
+"""Does the Add schedule cost graph quality against the reference's own sequential graph?
+Builds the same n x dim set under the library's DEFAULT (snapshot batches capped at the host's hardware threads: inside the reference's
+Parallel.For outcome set), under the opt-in 65 536-item snapshots of rounds 1-4, and as the SEQUENTIAL graph (HNSWIndex.Add(item) per item,
+HNSWIndex.cs:55-65) through the exact window -- and compares recall@10 (exact brute-force ground truth), the mean layer-0 out-degree and
+the build time.   usage: python tools/recall_study.py [n=1000000] [nq=2000] [window=256]"""
 import json
 import sys
 import time
@@ -15,7 +16,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     nq = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-    W = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+    W = int(sys.argv[3]) if len(sys.argv) > 3 else 256
     dim = 128
     import torch
     import hnswindex
@@ -39,7 +40,8 @@ def main():
         del xt, qt
         torch.cuda.empty_cache()
         res = {}
-        for label, batch in (("default_schedule", 65536), ("sequential_graph_exact_window", -W)):
+        cap = hnswindex.net_amd.host_parallelism()
+        for label, batch in ((f"default_schedule_cap_{cap}", 0), ("opt_in_snapshots_65536", 65536), ("sequential_graph_exact_window", -W)):
             ix = hnswindex.Index(dim)
             ix.set_collection_size(n); ix.set_max_candidates(200); ix.set_min_nn(128); ix.set_allow_removals(False); ix.set_insert_batch(batch)
             t0 = time.time(); ix.add(x); tb = time.time() - t0
