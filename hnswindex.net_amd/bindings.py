@@ -55,7 +55,7 @@ class Stats(ct.Structure):
                 ("range_timed_evals", ct.c_uint64), ("range_kernel_ms", ct.c_double), ("range_handbacks", ct.c_uint64),
                 ("replica_bytes", ct.c_uint64),
                 ("tie_windows", ct.c_uint64), ("peer_direct_copies", ct.c_uint64), ("peer_staged_copies", ct.c_uint64), ("lat_launches", ct.c_uint64),
-                ("range_device_ordered", ct.c_uint64), ("range_host_ordered", ct.c_uint64), ("insert_tie_reruns", ct.c_uint64)]
+                ("range_device_ordered", ct.c_uint64), ("range_host_ordered", ct.c_uint64), ("insert_tie_reruns", ct.c_uint64), ("lean_launches", ct.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

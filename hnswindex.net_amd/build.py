@@ -13,6 +13,7 @@ LIB = PKG / "artifacts" / "native" / "linux-x64" / "HNSWIndex.Native.so"
 # big traversal kernel templates (device code in device_kernels.h) -- separate units so that they
 # compile in parallel (one unit took two minutes).
 SOURCES = ["device_backend.hip", *[f"traverse_{m}_{k}{v}.hip" for m in ("sq", "cos", "ucos", "i8") for k in ("insert", "search") for v in ("", "_lat")],
+           *[f"traverse_{m}_search_lean.hip" for m in ("sq", "cos", "ucos", "i8")],
            "search_engine.cpp", "hnsw_index.cpp", "exports.cpp"]
 # -ffp-contract=off: the kernels fuse a*b+c only where __builtin_fmaf is written -- the
 # reference's AVX path fuses in sq_euclid (Fma.MultiplyAdd) and nowhere else.

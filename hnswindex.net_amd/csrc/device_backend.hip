@@ -102,6 +102,10 @@ hipError_t hnsw_phase_bind_sq_insert_lat(unsigned long long *); hipError_t hnsw_
 hipError_t hnsw_phase_bind_cos_insert_lat(unsigned long long *); hipError_t hnsw_phase_bind_cos_search_lat(unsigned long long *);
 hipError_t hnsw_phase_bind_ucos_insert_lat(unsigned long long *); hipError_t hnsw_phase_bind_ucos_search_lat(unsigned long long *);
 hipError_t hnsw_phase_bind_i8_insert_lat(unsigned long long *); hipError_t hnsw_phase_bind_i8_search_lat(unsigned long long *);
+hipError_t hnsw_phase_bind_sq_search_lean(unsigned long long *);
+hipError_t hnsw_phase_bind_cos_search_lean(unsigned long long *);
+hipError_t hnsw_phase_bind_ucos_search_lean(unsigned long long *);
+hipError_t hnsw_phase_bind_i8_search_lean(unsigned long long *);
 }
 static unsigned long long *g_phase_buf = nullptr; // one buffer per process (diagnostic builds run one index at a time)
 static bool phase_bind_all()
@@ -118,7 +122,11 @@ static bool phase_bind_all()
          hnsw_phase_bind_sq_insert_lat(g_phase_buf) == hipSuccess && hnsw_phase_bind_sq_search_lat(g_phase_buf) == hipSuccess &&
          hnsw_phase_bind_cos_insert_lat(g_phase_buf) == hipSuccess && hnsw_phase_bind_cos_search_lat(g_phase_buf) == hipSuccess &&
          hnsw_phase_bind_ucos_insert_lat(g_phase_buf) == hipSuccess && hnsw_phase_bind_ucos_search_lat(g_phase_buf) == hipSuccess &&
-         hnsw_phase_bind_i8_insert_lat(g_phase_buf) == hipSuccess && hnsw_phase_bind_i8_search_lat(g_phase_buf) == hipSuccess;
+         hnsw_phase_bind_i8_insert_lat(g_phase_buf) == hipSuccess && hnsw_phase_bind_i8_search_lat(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_sq_search_lean(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_cos_search_lean(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_ucos_search_lean(g_phase_buf) == hipSuccess &&
+         hnsw_phase_bind_i8_search_lean(g_phase_buf) == hipSuccess;
 #endif
     return ok;
 }
@@ -157,6 +165,10 @@ HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DEFINE_TRAVERSAL, M_SQ)
 HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DEFINE_TRAVERSAL, M_COS)
 HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DEFINE_TRAVERSAL, M_UCOS)
 HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DEFINE_TRAVERSAL, M_I8)
+HNSW_FOR_EACH_TRAVERSAL_LEAN(HNSW_DEFINE_SEARCH, M_SQ)
+HNSW_FOR_EACH_TRAVERSAL_LEAN(HNSW_DEFINE_SEARCH, M_COS)
+HNSW_FOR_EACH_TRAVERSAL_LEAN(HNSW_DEFINE_SEARCH, M_UCOS)
+HNSW_FOR_EACH_TRAVERSAL_LEAN(HNSW_DEFINE_SEARCH, M_I8)
 #else
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DECLARE_TRAVERSAL, M_SQ)
 HNSW_FOR_EACH_TRAVERSAL(HNSW_DECLARE_TRAVERSAL, M_COS)
@@ -166,6 +178,10 @@ HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DECLARE_TRAVERSAL, M_SQ)
 HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DECLARE_TRAVERSAL, M_COS)
 HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DECLARE_TRAVERSAL, M_UCOS)
 HNSW_FOR_EACH_TRAVERSAL_LAT(HNSW_DECLARE_TRAVERSAL, M_I8)
+HNSW_FOR_EACH_TRAVERSAL_LEAN(HNSW_DECLARE_SEARCH, M_SQ)
+HNSW_FOR_EACH_TRAVERSAL_LEAN(HNSW_DECLARE_SEARCH, M_COS)
+HNSW_FOR_EACH_TRAVERSAL_LEAN(HNSW_DECLARE_SEARCH, M_UCOS)
+HNSW_FOR_EACH_TRAVERSAL_LEAN(HNSW_DECLARE_SEARCH, M_I8)
 #endif
 
 // ------------------------------------------------------------------------------------
@@ -1004,6 +1020,7 @@ static int overlap_mode()
 // graphs whose sets are hash tables (A/B runs; same answers either way).  Measured, same box: C2 (1M x 128, bitsets) 2.46-2.56
 // -> 3.07 M queries/s (25-26 -> 20.7 ms per 65 536-query launch, +2.5 % rows measured), 12 500-query calls 2.0 -> 2.39 M; C4-size
 // 1.68 -> 2.03 M, C5-size 2.26 -> 2.70 M.
+static bool lean_mode() { return diag("lean", 1) != 0; } // launches with flags 9 on the lean kernel forms (0: the plain forms read the flags)
 static int novis_mode() // 0 never, 1 hash-table graphs only, 2 (default) every graph
 {
     return diag("novis", 2);
@@ -1201,18 +1218,18 @@ bool Device::insert_search_batch(const SearchJob *jobs, int njobs, int k, int ma
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
 #define LAUNCH2L(M, NS_, H_, LAT_, SLOTS, GRID, LDS, CAP) \
         hipLaunchKernelGGL((graph_insert_search_kernel<M, NS_, H_, LAT_>), dim3(std::min<int>(GRID, SLOTS)), \
-                       dim3(LAT_ ? 128 : 64), (LDS) + (LAT_ ? kTeamLds : 0), st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
+                       dim3(LAT_ == kFormLat ? 128 : 64), (LDS) + (LAT_ == kFormLat ? kTeamLds : 0), st, d_rows_, d_row_sn_, pitch_, g_adj0_, g_stride0_, \
                        g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), spill_cap_for_tests(),  \
                        max_edges0, s_visited_, vis_words, vis_tab, vis_tab_cap, p_sel0 + (size_t)off * sel_stride, p_cnt0 + off, p_selU, p_cntU,        \
                        sel_stride, p_flag + off, p_evals, nbcap(), GRID, s_jobctr_, (exact_only ? 0x200 : 0) | (novis_ins_ ? 9 : (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (mfma_heuristic() ? 2 : 0), d_order, \
                        windowed ? p_log : (int *)nullptr, read_log_cap)
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \
-        const int lslots_ = !exact_only && lat_mode() != 0 && g_stride0_ - 2 <= 64 && (LDS) + kTeamLds <= 64 * 1024 ? std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_, true>, (LDS) + kTeamLds, num_cu_, 128)) : 0; \
-        if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, NS_, H_, true, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
-        else { \
-            const int slots_ = std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_, false>, LDS, num_cu_)); \
-            LAUNCH2L(M, NS_, H_, false, slots_, GRID, LDS, CAP); \
+        const int lslots_ = !exact_only && lat_mode() != 0 && g_stride0_ - 2 <= 64 && (LDS) + kTeamLds <= 64 * 1024 ? std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_, kFormLat>, (LDS) + kTeamLds, num_cu_, 128)) : 0; \
+        if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, NS_, H_, kFormLat, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
+        else { /* (no lean form of this kernel: measured, the f32 insert search LOSES 6 % with it -- profiles/r5_lean_ab.log) */ \
+            const int slots_ = std::min(max_slots(), resident_blocks(graph_insert_search_kernel<M, NS_, H_, kFormPlain>, LDS, num_cu_)); \
+            LAUNCH2L(M, NS_, H_, kFormPlain, slots_, GRID, LDS, CAP); \
         } \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \
@@ -1748,17 +1765,20 @@ bool Device::search_batch_impl(const SearchJob *jobs, int njobs, int k, int k_ou
         if (timed) HIP_OK(hipEventRecord((hipEvent_t)ev0_, st));
 #define LAUNCH2L(M, NS_, H_, LAT_, SLOTS, GRID, LDS, CAP) \
         hipLaunchKernelGGL((graph_search_kernel<M, NS_, H_, LAT_>), dim3(std::min<int>(GRID, SLOTS)), \
-                       dim3(LAT_ ? 128 : 64), (LDS) + (LAT_ ? kTeamLds : 0), st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
+                       dim3(LAT_ == kFormLat ? 128 : 64), (LDS) + (LAT_ == kFormLat ? kTeamLds : 0), st, d_rows_, d_row_sn_, d_queries_, d_q_sn_, pitch_, \
                        g_adj0_, g_stride0_, g_upper_, g_pool_, g_strideU_, s_jobs_, k, CAP, reinterpret_cast<ND *>(s_spill_), \
                        spill_cap_for_tests(), s_visited_, vis_words, vis_tab, vis_tab_cap, k_out, d_ids, d_d, s_cnt_, d_flag, d_ev, nbcap(), GRID, s_jobctr_, (exact_only ? 0x200 : 0) | (novis_ ? 9 : (overlap_mode() == 2 || (overlap_mode() == 1 && (GRID <= SLOTS || vis_tab != nullptr))) ? 1 : 0) | (shadow_mode() && shadows_allowed_ ? 0x100 : 0), \
                        gate)
 #define LAUNCH2(M, NS_, H_, GRID, LDS, CAP) \
     do { \
-        const int lslots_ = !exact_only && lat_mode() != 0 && g_stride0_ - 2 <= 64 && (LDS) + kTeamLds <= 64 * 1024 ? std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_, true>, (LDS) + kTeamLds, num_cu_, 128)) : 0; \
-        if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, NS_, H_, true, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
-        else { \
-            const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_, false>, LDS, num_cu_)); \
-            LAUNCH2L(M, NS_, H_, false, slots_, GRID, LDS, CAP); \
+        const int lslots_ = !exact_only && lat_mode() != 0 && g_stride0_ - 2 <= 64 && (LDS) + kTeamLds <= 64 * 1024 ? std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_, kFormLat>, (LDS) + kTeamLds, num_cu_, 128)) : 0; \
+        if (lslots_ > 0 && (lat_mode() == 2 || GRID <= lslots_)) { LAUNCH2L(M, NS_, H_, kFormLat, lslots_, GRID, LDS, CAP); stats_.lat_launches++; } \
+        else if (novis_ && !exact_only && lean_mode() && NS_ <= 4) { /* flags 9: the lean form (kFormLean; NS = 8 has none) */ \
+            const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_, (NS_ <= 4 ? kFormLean : kFormPlain)>, LDS, num_cu_)); \
+            LAUNCH2L(M, NS_, H_, (NS_ <= 4 ? kFormLean : kFormPlain), slots_, GRID, LDS, CAP); stats_.lean_launches++; \
+        } else { \
+            const int slots_ = std::min(max_slots(), resident_blocks(graph_search_kernel<M, NS_, H_, kFormPlain>, LDS, num_cu_)); \
+            LAUNCH2L(M, NS_, H_, kFormPlain, slots_, GRID, LDS, CAP); \
         } \
     } while (0)
 #define LAUNCH3(NS_, H_, GRID, LDS, CAP)                                                                              \

@@ -38,17 +38,21 @@ namespace hnsw {
 
 // Explicit instantiations of the two traversal kernels live in traverse_<metric>_<search|insert>.hip;
 // every other unit only declares them.
-// Ten forms per metric and kernel (eighteen until round 5): register sets NS in {2, 4, 8} (beams up to 128 / 256 / 512; a beam of
+// Ten forms per metric and kernel (eighteen until round 5) plus four lean ones: register sets NS in {2, 4, 8} (beams up to 128 / 256 / 512; a beam of
 // up to 64 runs in the two-set form), the visited set as a bitset or (graphs above 4M nodes, NS <= 4) a per-wave hash table, and the
 // latency variant of each.  What used to be forms of their own: NS = 1 (same code with one register less), NS = 0 (the exact
 // two-heap traversal alone: now launch flag 0x200 of the two-set form), hash tables for NS = 8 (such launches keep bitsets).
 #define HNSW_FOR_EACH_TRAVERSAL(X, M) \
-    X(M, 2, false, false) X(M, 4, false, false) X(M, 8, false, false) \
-    X(M, 2, true, false) X(M, 4, true, false)
+    X(M, 2, false, kFormPlain) X(M, 4, false, kFormPlain) X(M, 8, false, kFormPlain) \
+    X(M, 2, true, kFormPlain) X(M, 4, true, kFormPlain)
 // the latency variants: units of their own
 #define HNSW_FOR_EACH_TRAVERSAL_LAT(X, M) \
-    X(M, 2, false, true) X(M, 4, false, true) X(M, 8, false, true) \
-    X(M, 2, true, true) X(M, 4, true, true)
+    X(M, 2, false, kFormLat) X(M, 4, false, kFormLat) X(M, 8, false, kFormLat) \
+    X(M, 2, true, kFormLat) X(M, 4, true, kFormLat)
+// the lean forms of graph_search_kernel (round 5; kFormLean in dk_base.h): beams up to 256 entries, launches without visited sets;
+// units of their own.  (The insert kernel has none: measured, its f32 form loses 6 % that way.)
+#define HNSW_FOR_EACH_TRAVERSAL_LEAN(X, M) \
+    X(M, 2, false, kFormLean) X(M, 4, false, kFormLean) X(M, 2, true, kFormLean) X(M, 4, true, kFormLean)
 #define HNSW_SEARCH_SIGNATURE(PREFIX, M, NS, H, LT)                                                                                  \
     PREFIX template __global__ void graph_search_kernel<M, NS, H, LT>(                                                              \
         const float *__restrict__, const double *__restrict__, const float *__restrict__, const double *__restrict__, int,      \
@@ -63,6 +67,7 @@ namespace hnsw {
         long long, int *__restrict__, int, int *__restrict__, int *__restrict__, int *__restrict__, int *__restrict__, int,      \
         int *__restrict__, unsigned long long *__restrict__, int, int, int *__restrict__, int, const int *__restrict__, int *__restrict__, int);
 #define HNSW_DECLARE_TRAVERSAL(M, NS, H, LT) HNSW_SEARCH_SIGNATURE(extern, M, NS, H, LT) HNSW_INSERT_SIGNATURE(extern, M, NS, H, LT)
+#define HNSW_DECLARE_SEARCH(M, NS, H, LT) HNSW_SEARCH_SIGNATURE(extern, M, NS, H, LT)
 #define HNSW_DEFINE_TRAVERSAL(M, NS, H, LT) HNSW_SEARCH_SIGNATURE(, M, NS, H, LT) HNSW_INSERT_SIGNATURE(, M, NS, H, LT)
 #define HNSW_DEFINE_SEARCH(M, NS, H, LT) HNSW_SEARCH_SIGNATURE(, M, NS, H, LT)
 #define HNSW_DEFINE_INSERT(M, NS, H, LT) HNSW_INSERT_SIGNATURE(, M, NS, H, LT)

@@ -9,7 +9,7 @@
 //   * names (defaults in brackets; DESIGN.md 4.1 says what each is for):
 //       lat [1]  novis [2]  novis_insert [1]  sorted_top [1]  shadow [1]  overlap [1]  mfma [1]  vis_hash [-1 = by graph size]
 //       vis_hash_cap [0]  cand_cap [0]  spill_cap [-1]  link_plan [1]  concurrent_queries [1]  stream_queries [1]
-//       xw_dry [1]  xw_stage [1]  trace [0]
+//       xw_dry [1]  xw_stage [1]  trace [0]  lean [1]
 #pragma once
 #include <cstdlib>
 #include <cstring>

@@ -43,6 +43,13 @@ __device__ __forceinline__ void wave_lds_sync()
 // ------------------------------------------------------------------------------------
 // device code
 // ------------------------------------------------------------------------------------
+// Forms of the two traversal kernels (their fourth template argument).  PLAIN: every launch flag is read at run time.  LAT: the
+// latency variant, two waves per job (dk_team.h, dk_pool_top.h).  LEAN: what a launch without visited sets (flags 9: the
+// default wherever every adjacency list has at most 64 entries and a row at most 1 KB) needs and nothing else -- "no visited
+// set" and "rows of all listed neighbours in one go" are compile-time facts, the code of the other two ways through an
+// expansion is not there: a third fewer spilled scalars and the loop's instructions closer together.  Measured (round 5,
+// profiles/r5_lean_ab.log): int8 records 12 500-query launches 3.73 -> 3.21 ms, 65 536-query launches 12.9 -> 9.4 ms.
+constexpr int kFormPlain = 0, kFormLat = 1, kFormLean = 2;
 enum { M_SQ = HNSWDEV_SQ_EUCLID, M_COS = HNSWDEV_COSINE, M_UCOS = HNSWDEV_UCOSINE, M_I8 = HNSWDEV_SQ_EUCLID_I8 };
 
 } // namespace hnsw

@@ -14,7 +14,7 @@ namespace hnsw {
 // clear their visited bitset between layers).  Output per (job, layer): the selected ids in
 // selection order (layer 0 -> slot `job`; layer L >= 1 -> upper slot jobs[].aux + L - 1).
 // jobs[].search_layer = the item's first layer min(level, top).
-template <int METRIC, int NS, bool HASHED, bool LAT = false>
+template <int METRIC, int NS, bool HASHED, int FORM = kFormPlain>
 __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
@@ -24,8 +24,9 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                            unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap_and_flags,
                            int *__restrict__ read_log, int read_log_cap, TeamPort *port = nullptr, bool *v_dirty_out = nullptr)
 {
+    constexpr bool LAT = FORM == kFormLat, LEAN = FORM == kFormLean;
     bool v_dirty = false; // the visited set has marks in it (the sorted traversal without a visited set -- oflags bit 3 -- leaves none)
-    const bool novis = !LAT && (overlap_and_flags & 8) != 0;
+    const bool novis = LEAN || (!LAT && (overlap_and_flags & 8) != 0);
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x & 63;
     const int overlap = overlap_and_flags & 1; // bit 0: overlapped form (bit 1: the MFMA-prefiltered heuristic is allowed)
@@ -56,7 +57,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         if (!exact_only) {
             bool tie = false;
             if constexpr (LAT) ok = traverse_pool<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, RL, &order_tie, nullptr, port);
-            else ok = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap_and_flags & 9, RL, &order_tie); // Span.Sort consumes all
+            else ok = traverse_sorted<METRIC, NS, HASHED, LEAN>(rows, row_sn, dim, sb, G, jb, k, k, V, L, lane, top_n, tie, evals, overlap_and_flags & 9, RL, &order_tie); // Span.Sort consumes all
             v_dirty = v_dirty || !novis;
             if (!ok) break;
             // equal distances where the heap layout shows, or fewer candidates than MaxEdges (the heuristic
@@ -133,8 +134,8 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
     }
 }
 
-template <int METRIC, int NS, bool HASHED, bool LAT = false>
-__global__ void __launch_bounds__(LAT ? 128 : 64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(LAT ? (NS <= 4 ? 2 : 1) : NS <= 4 ? 3 : 2)))) // up to 256 candidates: 168 VGPRs, three waves per SIMD (LAT: see graph_search_kernel)
+template <int METRIC, int NS, bool HASHED, int FORM = kFormPlain>
+__global__ void __launch_bounds__(FORM == kFormLat ? 128 : 64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(FORM == kFormLat ? (NS <= 4 ? 2 : 1) : NS <= 4 ? 3 : 2)))) // up to 256 candidates: 168 VGPRs, three waves per SIMD (LAT: see graph_search_kernel)
 graph_insert_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
                            const int *__restrict__ pool, int strideU, const SearchJob *__restrict__ jobs, int k,
@@ -144,6 +145,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
                            unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap,
                            const int *__restrict__ order, int *__restrict__ read_log, int read_log_cap)
 {
+    constexpr bool LAT = FORM == kFormLat;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
@@ -175,7 +177,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
         // longest; started last they would be the tail of the launch).  Results are filed by item, so the
         // order of processing changes nothing else.
         if (order) job = __builtin_amdgcn_readfirstlane(order[job]);
-        insert_job<METRIC, NS, HASHED, LAT>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
+        insert_job<METRIC, NS, HASHED, FORM>(rows, row_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap, max_edges0, V,
                                out_sel0, out_cnt0, out_selU, out_cntU, sel_stride, out_flag, eval_counter, nbcap, smem, job, overlap, read_log, read_log_cap, &port, &v_dirty);
         if (v_dirty) V.clear(lane);
     }

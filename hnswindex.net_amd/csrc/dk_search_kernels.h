@@ -15,7 +15,7 @@ namespace hnsw {
 // wave that owns the job met a tie, bit 2 a shadow traversal has been started for it.
 constexpr int kJobAnswered = 1, kJobTied = 2, kJobShadowed = 4;
 
-template <int METRIC, int NS, bool HASHED, bool LAT = false>
+template <int METRIC, int NS, bool HASHED, int FORM = kFormPlain>
 __device__ __forceinline__ void search_job(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
@@ -25,6 +25,7 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
                     unsigned long long *__restrict__ eval_counter, int nbcap, unsigned char *smem, int job, int overlap,
                     int *__restrict__ job_word = nullptr, bool shadow = false, TeamPort *port = nullptr, bool *v_untouched = nullptr)
 {
+    constexpr bool LAT = FORM == kFormLat, LEAN = FORM == kFormLean;
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x & 63;
     if (v_untouched) *v_untouched = false;
@@ -60,9 +61,9 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         bool window = false;
         bool ok1;
         if constexpr (LAT) ok1 = traverse_pool<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, RL, nullptr, &window, port);
-        else ok1 = traverse_sorted<METRIC, NS, HASHED>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL, nullptr, &window);
+        else ok1 = traverse_sorted<METRIC, NS, HASHED, LEAN>(rows, row_sn, dim, sb, G, jb, k, k_out + 1, V, L, lane, top_n, tie, evals, overlap, RL, nullptr, &window);
         if (!(ok1 && tie)) {
-            if (v_untouched) *v_untouched = !LAT && (overlap & 8) != 0; // the sorted traversal ran without a visited set: nothing to clear
+            if (v_untouched) *v_untouched = LEAN || (!LAT && (overlap & 8) != 0); // the sorted traversal ran without a visited set: nothing to clear
             if (!claim_answer()) return;
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
             // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
@@ -155,11 +156,11 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
 // shared counter until none are left.  A wave owns one visited bitset and one spill area for the
 // whole launch and leaves the bitset clean after every job, so the scratch is sized by the
 // resident waves (not by the batch) and nothing is memset between launches.
-template <int METRIC, int NS, bool HASHED, bool LAT = false>
+template <int METRIC, int NS, bool HASHED, int FORM = kFormPlain>
 // float rows: 168 VGPRs, three waves per SIMD; int8 records keep 16 registers of rows in flight, not 64: five waves.
 // LAT (launches that do not fill the chip): no occupancy to buy -- every spilled register is a memory round trip a lone wave
 // waits out in full -- so two waves per SIMD at most (256 VGPRs), one with eight register sets
-__global__ void __launch_bounds__(LAT ? 128 : 64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(LAT ? (NS <= 4 ? 2 : 1) : METRIC == M_I8 ? (NS <= 2 ? HNSW_I8_WAVES : 4) : (NS <= 4 ? 3 : 2)))))
+__global__ void __launch_bounds__(FORM == kFormLat ? 128 : 64) __attribute__((amdgpu_waves_per_eu(HNSW_WAVES(FORM == kFormLat ? (NS <= 4 ? 2 : 1) : METRIC == M_I8 ? (NS <= 2 ? HNSW_I8_WAVES : 4) : (NS <= 4 ? 3 : 2)))))
 graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
                     const int64_t *__restrict__ upper, const int *__restrict__ pool, int strideU,
@@ -169,6 +170,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
                     unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap,
                     const int *__restrict__ ready)
 {
+    constexpr bool LAT = FORM == kFormLat;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
@@ -266,7 +268,7 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
                 }
             }
         }
-        search_job<METRIC, NS, HASHED, LAT>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
+        search_job<METRIC, NS, HASHED, FORM>(rows, row_sn, queries, q_sn, dim, adj0, stride0, upper, pool, strideU, jobs, k, cand_cap, my_spill, spill_cap,
                                V, k_out, out_ids, out_d, out_cnt, out_flag, eval_counter, nbcap, smem, job, overlap, shadows ? job_words + job : nullptr,
                                shadow, &port, &v_clean);
         if (!v_clean) V.clear(lane);

@@ -248,7 +248,7 @@ struct SortedTop {
 
 // Returns false on a NaN / -0 distance (exact host re-run); `tie` asks for the exact two-heap
 // traversal.  Result: L.top[0..top_n) ascending by distance.  The query must be staged in L.qs.
-template <int METRIC, int NS, bool HASHED>
+template <int METRIC, int NS, bool HASHED, bool LEAN = false>
 __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim, double sb,
                                                 const GraphView &G, const SearchJob jb, int k, int ordered_prefix, VisitedSet<HASHED> &V,
                                                 const SearchLds &L, int lane, int &top_n_out, bool &tie_out, unsigned long long &evals,
@@ -276,7 +276,7 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
     // neighbour seen before is either still listed -- found by its id -- or it was turned away or pushed out at a farthest key
     // that has only shrunk since, and the push test (:165) turns it away again.  One CAS per evaluation was as much HBM traffic
     // as a 128-byte int8 record, and the 64-KB table was cleared after every job.
-    const bool novis = (oflags & 8) != 0;
+    const bool novis = LEAN || (oflags & 8) != 0; // (LEAN: launched with flags 9 only, see kFormLean)
     if (!novis) {
         if (lane == 0) (void)V.first_visit(best);                       // :140
         V.seen += 1;
@@ -328,7 +328,8 @@ __device__ __forceinline__ bool traverse_sorted(const float *__restrict__ rows, 
         bool have = false;     // this lane holds an unvisited neighbour
         float lane_d = 0.0f;
         int lane_id = 0;
-        const bool overlapped = (oflags & 1) != 0 && n <= 64; // oflags bit 0: rows requested with the visited atomics
+        if (LEAN && n > 64) { hash_full = true; break; } // (never: the host asks for this form only where no list is longer)
+        const bool overlapped = LEAN || ((oflags & 1) != 0 && n <= 64); // oflags bit 0: rows requested with the visited atomics
         if (overlapped) {
             // Latency-bound launch (fewer jobs than resident waves): the rows of ALL listed neighbours
             // are fetched together with the visited atomics instead of after them -- one dependent

@@ -1598,7 +1598,7 @@ void HnswIndex::collect_stats(hnswdev_stats *out)
         out->search_launches += s.search_launches; out->search_evals += s.search_evals; out->search_timed_launches += s.search_timed_launches;
         out->search_timed_evals += s.search_timed_evals; out->search_kernel_ms += s.search_kernel_ms; out->search_overflows += s.search_overflows;
         out->search_repeats += s.search_repeats; out->visited_hash_launches += s.visited_hash_launches;
-        out->tie_windows += s.tie_windows; out->lat_launches += s.lat_launches; out->peer_direct_copies += s.peer_direct_copies; out->peer_staged_copies += s.peer_staged_copies; out->insert_tie_reruns += s.insert_tie_reruns; out->range_device_ordered += s.range_device_ordered; out->range_host_ordered += s.range_host_ordered;
+        out->tie_windows += s.tie_windows; out->lat_launches += s.lat_launches; out->lean_launches += s.lean_launches; out->peer_direct_copies += s.peer_direct_copies; out->peer_staged_copies += s.peer_staged_copies; out->insert_tie_reruns += s.insert_tie_reruns; out->range_device_ordered += s.range_device_ordered; out->range_host_ordered += s.range_host_ordered;
     }
 }
 

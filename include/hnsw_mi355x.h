@@ -278,6 +278,7 @@ typedef struct hnswdev_stats {
                                      * consumes in order (Span.Sort among equal keys, Heuristic.cs:22; heap layout at the far end of the list): the inserts
                                      * whose outcome rests on BCL tie behaviour this build restates from memory -- the "parity unpinned" exposure as a number
                                      * (also counted in search_repeats) */
+    uint64_t lean_launches;         /* traversal launches that ran the lean form of their kernel (no visited sets: the default wherever lists hold <= 64 ids and rows <= 1 KB) */
 } hnswdev_stats;
 
 /* All return 0 on success, < 0 on error (message via hnswdev_ctx_last_error / hnswdev_last_error).

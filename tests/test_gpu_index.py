@@ -535,10 +535,10 @@ def test_batched_removal_matches_its_cpu_restatement(Index, metric, batch):
 
 
 @pytest.mark.parametrize("metric", ["sq_euclid", "ucosine", "sq_euclid_i8"])
-@pytest.mark.parametrize("hooks", [dict(lat=0), dict(lat=2), dict(novis_insert=0), dict(lat=2, novis_insert=0), dict(novis=0, lat=2)])
+@pytest.mark.parametrize("hooks", [dict(lat=0), dict(lat=2), dict(novis_insert=0), dict(lat=2, novis_insert=0), dict(novis=0, lat=2), dict(lean=0, lat=0)])
 def test_forced_traversal_forms_build_and_answer_like_the_oracle(Index, monkeypatch, metric, hooks):
     """The switches that pick a traversal form -- the latency variants never / whenever possible, Add's searches with their visited
-    sets kept, the search launches with theirs -- set IN the suite (they are read on every call): graph hash and answers must be
+    sets kept, the search launches with theirs, the flags-9 launches on the plain kernel forms instead of the lean ones -- set IN the suite (they are read on every call): graph hash and answers must be
     the oracle's under each of them, for batches small enough for the latency variants and for a batch that fills the chip."""
     set_diag(monkeypatch, **hooks)
     n, dim = 5000, 48
@@ -559,6 +559,10 @@ def test_forced_traversal_forms_build_and_answer_like_the_oracle(Index, monkeypa
         assert st["lat_launches"] == 0
     if hooks.get("lat") == 2:
         assert st["lat_launches"] > 0
+    if hooks.get("lean") == 0:
+        assert st["lean_launches"] == 0
+    elif hooks.get("lat") == 0:
+        assert st["lean_launches"] > 0                             # the default for launches without visited sets (kFormLean)
 
 
 @pytest.mark.parametrize("metric", ["sq_euclid", "ucosine", "sq_euclid_i8"])
