@@ -834,6 +834,7 @@ def main():
         "evals_per_query": round(sum(c["search_evals"] + c["evals"] for c in st_all) / max(1, per_gpu * ndev_native * a.steps), 1),
         "traversal": a.traversal, "search_overflows": sum(c["search_overflows"] for c in st_all), "search_repeats": sum(c["search_repeats"] for c in st_all),
         "search_tie_windows": sum(c.get("tie_windows", 0) for c in st_all),
+        "search_kernel_form": "lean (launches without visited sets: DESIGN.md 3.5)" if sum(c.get("lean_launches", 0) for c in st_all) > 0 else "plain",
         "small_batch": small, "crossover_batch_vs_cpu": crossover,
         "roofline": roofline, "roofline_add": roofline_add, "add_modes": add_modes, "cpu_baseline": cpu,
     }
