@@ -15,6 +15,17 @@ namespace hnsw {
 // wave that owns the job met a tie, bit 2 a shadow traversal has been started for it.
 constexpr int kJobAnswered = 1, kJobTied = 2, kJobShadowed = 4;
 
+// graph_search_kernel's parameter list as a struct (same order, same types: the kernarg segment's layout) -- see kernarg_load
+struct SearchKernArgs {
+    const float *rows; const double *row_sn; const float *queries; const double *q_sn; int dim; const int *adj0; int stride0;
+    const int64_t *upper; const int *pool; int strideU; const SearchJob *jobs; int k, cand_cap; ND *spill; int spill_cap;
+    unsigned *visited; long long vis_words; int *vis_tab; int vis_tab_cap, k_out; int *out_ids; float *out_d; int *out_cnt, *out_flag;
+    unsigned long long *eval_counter; int nbcap, njobs; int *job_counter; int overlap; const int *ready;
+};
+static_assert(offsetof(SearchKernArgs, jobs) == 80 && offsetof(SearchKernArgs, out_ids) == 144 && offsetof(SearchKernArgs, ready) == 208 && sizeof(SearchKernArgs) == 216,
+              "SearchKernArgs must mirror graph_search_kernel's parameter list (the explicit arguments start the kernarg segment, each at its natural alignment)");
+#define HNSW_KA(field) kernarg_load<decltype(SearchKernArgs::field)>((unsigned)offsetof(SearchKernArgs, field))
+
 template <int METRIC, int NS, bool HASHED, int FORM = kFormPlain>
 __device__ __forceinline__ void search_job(const float *__restrict__ rows, const double *__restrict__ row_sn, const float *__restrict__ queries,
                     const double *__restrict__ q_sn, int dim, const int *__restrict__ adj0, int stride0,
@@ -26,6 +37,9 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
                     int *__restrict__ job_word = nullptr, bool shadow = false, TeamPort *port = nullptr, bool *v_untouched = nullptr)
 {
     constexpr bool LAT = FORM == kFormLat, LEAN = FORM == kFormLean;
+    if constexpr (LEAN) { // (what only the start and the end of a job need is read where it is needed: kernarg_load)
+        cand_cap = HNSW_KA(cand_cap); nbcap = HNSW_KA(nbcap); jobs = HNSW_KA(jobs); queries = HNSW_KA(queries); q_sn = HNSW_KA(q_sn);
+    }
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
     const int lane = threadIdx.x & 63;
     if (v_untouched) *v_untouched = false;
@@ -65,6 +79,10 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
         if (!(ok1 && tie)) {
             if (v_untouched) *v_untouched = LEAN || (!LAT && (overlap & 8) != 0); // the sorted traversal ran without a visited set: nothing to clear
             if (!claim_answer()) return;
+            if constexpr (LEAN) {
+                k_out = HNSW_KA(k_out); out_ids = HNSW_KA(out_ids); out_d = HNSW_KA(out_d); out_cnt = HNSW_KA(out_cnt); out_flag = HNSW_KA(out_flag);
+                eval_counter = HNSW_KA(eval_counter);
+            }
             // KnnQuery's tail (HNSWIndex.cs:119-123): OrderBy(Dist).Take(k) of distinct distances is the
             // head of the ascending list; missing results are padded (HNSWIndexExports.cs:144)
             for (int r = lane; r < k_out; r += 64) {
@@ -86,14 +104,34 @@ __device__ __forceinline__ void search_job(const float *__restrict__ rows, const
             if (lane == 0) old = atomicOr(job_word, kJobTied);
             if (__builtin_amdgcn_readfirstlane(old) & (kJobShadowed | kJobAnswered)) return;
         }
-        V.clear(lane);
+        if constexpr (!LEAN) V.clear(lane); // (the lean form's sorted traversal has no visited set)
         evals = 0;
         top_n = 0;
         repeated = true;
         }
     }
     bool aborted = false;
-    const bool ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL,
+    bool ok;
+    if constexpr (LEAN) {
+        // the lean kernel carries neither its visited set nor its spill area from job to job: both are looked up here, for the one job
+        // in several hundred that takes this path, and the set is left clean again
+        cand_cap = HNSW_KA(cand_cap);
+        const int spill_cap_ = HNSW_KA(spill_cap);
+        const long long vis_words = HNSW_KA(vis_words);
+        int *const vis_tab = HNSW_KA(vis_tab);
+        const int vis_tab_cap = HNSW_KA(vis_tab_cap);
+        VisitedSet<HASHED> VE{HNSW_KA(visited) + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
+                              vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, (unsigned)(vis_tab_cap - 1), 0, vis_tab_cap / 4 * 3};
+        ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, HNSW_KA(spill) + (size_t)blockIdx.x * spill_cap_, spill_cap_, VE, L, lane, top_n, evals, RL,
+                                      shadow ? job_word : nullptr, &aborted, true);
+        VE.clear(lane);
+        if (v_untouched) *v_untouched = true;
+        if (!aborted) {
+            k_out = HNSW_KA(k_out); out_ids = HNSW_KA(out_ids); out_d = HNSW_KA(out_d); out_cnt = HNSW_KA(out_cnt); out_flag = HNSW_KA(out_flag);
+            eval_counter = HNSW_KA(eval_counter);
+        }
+    } else
+    ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL,
                                              shadow ? job_word : nullptr, &aborted, LAT || (overlap & 1) != 0 || repeated);
     if (aborted || !claim_answer()) return;
     if (jb.aux == -2) { // SearchLayer's own return value: topCandidates.ToArray(), the heap's array (BinaryHeap.cs:41-44)
@@ -170,12 +208,13 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
                     unsigned long long *__restrict__ eval_counter, int nbcap, int njobs, int *__restrict__ job_counter, int overlap,
                     const int *__restrict__ ready)
 {
-    constexpr bool LAT = FORM == kFormLat;
+    constexpr bool LAT = FORM == kFormLat, LEAN = FORM == kFormLean;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
-    VisitedSet<HASHED> V{visited + (size_t)blockIdx.x * (size_t)vis_words, vis_words,
-                 vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, (unsigned)(vis_tab_cap - 1), 0, vis_tab_cap / 4 * 3};
-    ND *my_spill = spill + (size_t)blockIdx.x * spill_cap;
+    // (the lean form looks its visited set and spill area up when a job takes the exact traversal: search_job)
+    VisitedSet<HASHED> V{LEAN ? nullptr : visited + (size_t)blockIdx.x * (size_t)vis_words, LEAN ? 0 : vis_words,
+                 !LEAN && vis_tab ? vis_tab + (size_t)blockIdx.x * (size_t)vis_tab_cap : nullptr, LEAN ? 0u : (unsigned)(vis_tab_cap - 1), 0, LEAN ? 0 : vis_tab_cap / 4 * 3};
+    ND *my_spill = LEAN ? nullptr : spill + (size_t)blockIdx.x * spill_cap;
 
     TeamPort port{nullptr, 0, 0};
     if constexpr (LAT) {
@@ -205,11 +244,17 @@ graph_search_kernel(const float *__restrict__ rows, const double *__restrict__ r
     // job soon after and the shadow stops at its next expansion; when the owner meets a tie it finds the exact
     // traversal already under way and leaves it to the shadow.  Results are written by whoever finishes first -- both
     // compute the reference's answer.
-    const bool shadows = (overlap & 0x100) != 0 && NS > 0 && !(overlap & 0x200);
+    bool shadows = (overlap & 0x100) != 0 && NS > 0 && !(overlap & 0x200);
     int *job_words = job_counter + 4;
     int known_ready = 0;
     bool v_clean = false;
     for (;;) {
+        if constexpr (LEAN) { // what the queue needs, read per job instead of carried through the traversal (kernarg_load)
+            job_counter = HNSW_KA(job_counter); njobs = HNSW_KA(njobs); ready = HNSW_KA(ready); jobs = HNSW_KA(jobs); overlap = HNSW_KA(overlap);
+            out_cnt = HNSW_KA(out_cnt); out_flag = HNSW_KA(out_flag);
+            job_words = job_counter + 4;
+            shadows = (overlap & 0x100) != 0 && !(overlap & 0x200);
+        }
         int job = 0;
         bool shadow = false;
         if (lane == 0) job = atomicAdd(job_counter, 1);
