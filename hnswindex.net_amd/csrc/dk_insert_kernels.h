@@ -14,6 +14,21 @@ namespace hnsw {
 // clear their visited bitset between layers).  Output per (job, layer): the selected ids in
 // selection order (layer 0 -> slot `job`; layer L >= 1 -> upper slot jobs[].aux + L - 1).
 // jobs[].search_layer = the item's first layer min(level, top).
+// graph_insert_search_kernel's parameter list as a struct (same order, same types: the kernarg segment's layout) -- see kernarg_load
+struct InsertKernArgs {
+    const float *rows; const double *row_sn; int dim; const int *adj0; int stride0; const int64_t *upper; const int *pool; int strideU;
+    const SearchJob *jobs; int k, cand_cap; ND *spill; int spill_cap, max_edges0; unsigned *visited; long long vis_words; int *vis_tab; int vis_tab_cap;
+    int *out_sel0, *out_cnt0, *out_selU, *out_cntU; int sel_stride; int *out_flag; unsigned long long *eval_counter; int nbcap, njobs; int *job_counter;
+    int overlap; const int *order; int *read_log; int read_log_cap;
+};
+static_assert(offsetof(InsertKernArgs, jobs) == 64 && offsetof(InsertKernArgs, out_sel0) == 128 && offsetof(InsertKernArgs, read_log) == 216 && sizeof(InsertKernArgs) == 232,
+              "InsertKernArgs must mirror graph_insert_search_kernel's parameter list");
+#define HNSW_KAI(field) kernarg_load<decltype(InsertKernArgs::field)>((unsigned)offsetof(InsertKernArgs, field))
+// The latency variant reads the arguments that only the start / the end of a job or of a layer use where they are used (kernarg_load) instead of
+// carrying them through the traversal: its logic wave is bound by its own instruction stream, and spilled SGPRs are instructions in it.
+// Measured (profiles/r5_lean_ab.log, 7): 1M build under the default cap 106.3 -> 110.1 k adds/s, B = 1 1 007 -> 1 031 adds/s, ladder +3-4 %; the plain
+// form (large snapshots) keeps its arguments in registers: 0.640 -> 0.630 of peak with the reloads, inside the noise on the wrong side.
+
 template <int METRIC, int NS, bool HASHED, int FORM = kFormPlain>
 __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const double *__restrict__ row_sn, int dim,
                            const int *__restrict__ adj0, int stride0, const int64_t *__restrict__ upper,
@@ -25,6 +40,8 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                            int *__restrict__ read_log, int read_log_cap, TeamPort *port = nullptr, bool *v_dirty_out = nullptr)
 {
     constexpr bool LAT = FORM == kFormLat, LEAN = FORM == kFormLean;
+    constexpr bool KA = LAT;
+    if constexpr (KA) { jobs = HNSW_KAI(jobs); cand_cap = HNSW_KAI(cand_cap); nbcap = HNSW_KAI(nbcap); read_log = HNSW_KAI(read_log); read_log_cap = HNSW_KAI(read_log_cap); }
     bool v_dirty = false; // the visited set has marks in it (the sorted traversal without a visited set -- oflags bit 3 -- leaves none)
     const bool novis = LEAN || (!LAT && (overlap_and_flags & 8) != 0);
     const SearchLds L = carve_lds(smem, k, cand_cap, dim, nbcap);
@@ -50,6 +67,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         if (layer != first_layer && v_dirty) { V.clear(lane); v_dirty = false; } // a fresh SearchLayer: new visited list (VisitedListPool.cs:74-106)
         int top_n = 0;
         const int rl_n0 = RL.n;
+        if constexpr (KA) max_edges0 = HNSW_KAI(max_edges0);
         const int max_edges = layer == 0 ? max_edges0 : (max_edges0 >> 1); // GraphData.MaxEdges :247-250
         const bool exact_only = (overlap_and_flags & 0x200) != 0; // the launch runs the exact two-heap traversal only (beams beyond 512 entries)
         bool exact = exact_only, order_tie = false;
@@ -74,6 +92,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
                     RL.n = rl_n0; // the same lists are read again
                     if (v_dirty) V.clear(lane);
                 }
+                if constexpr (KA) { cand_cap = HNSW_KAI(cand_cap); spill_cap = HNSW_KAI(spill_cap); spill = HNSW_KAI(spill) + (size_t)blockIdx.x * spill_cap; }
                 ok = traverse<METRIC, HASHED>(rows, row_sn, dim, sb, G, jb, k, cand_cap, spill, spill_cap, V, L, lane, top_n, evals, RL, nullptr, nullptr,
                                               LAT || overlap != 0);
                 v_dirty = true;
@@ -83,6 +102,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
             const long long ph_h0 = __builtin_readcyclecounter();
 #endif
             // the candidate heap's LDS area is idle now: the grouped heuristic borrows it
+            if constexpr (KA) cand_cap = HNSW_KAI(cand_cap);
             rc = relative_neighbor_pruning<METRIC, NS == 8>(rows, row_sn, dim, L.top, top_n, max_edges, L, lane, evals, !exact,
 #ifdef HNSW_NO_GROUPED
                                                             nullptr, 0);
@@ -114,6 +134,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
             exact = true;
         }
         if (!ok) break;
+        if constexpr (KA) { out_sel0 = HNSW_KAI(out_sel0); out_cnt0 = HNSW_KAI(out_cnt0); out_selU = HNSW_KAI(out_selU); out_cntU = HNSW_KAI(out_cntU); sel_stride = HNSW_KAI(sel_stride); }
         int *osel = layer == 0 ? out_sel0 + (size_t)job * sel_stride : out_selU + (size_t)(jb.aux + layer - 1) * sel_stride;
         for (int i = lane; i < rc; i += 64) osel[i] = L.acc[i];
         if (lane == 0) { if (layer == 0) out_cnt0[job] = rc; else out_cntU[jb.aux + layer - 1] = rc; }
@@ -124,6 +145,7 @@ __device__ __forceinline__ void insert_job(const float *__restrict__ rows, const
         wave_sync();
     }
     if (v_dirty_out) *v_dirty_out = v_dirty || LAT; // (the latency variants' memory wave marks as it goes)
+    if constexpr (KA) { out_flag = HNSW_KAI(out_flag); eval_counter = HNSW_KAI(eval_counter); read_log = HNSW_KAI(read_log); read_log_cap = HNSW_KAI(read_log_cap); }
     if (lane == 0) {
         out_flag[job] = ok ? (repeat ? 2 : 0) : 1; // 2: informational (a layer was answered by the exact traversal)
         if (read_log) read_log[(size_t)job * read_log_cap] = RL.n;
@@ -169,6 +191,7 @@ graph_insert_search_kernel(const float *__restrict__ rows, const double *__restr
     }
     bool v_dirty = true;
     for (;;) { // persistent, see graph_search_kernel
+        if constexpr (LAT) { job_counter = HNSW_KAI(job_counter); njobs = HNSW_KAI(njobs); order = HNSW_KAI(order); }
         int job = 0;
         if (lane == 0) job = atomicAdd(job_counter, 1);
         job = __builtin_amdgcn_readfirstlane(job);
