@@ -470,14 +470,15 @@ def main():
     traffic_note = "no PMC profile of this workload under profiles/"
     try:
         pm = json.loads(profile_file("pmc_traffic.json").read_text())
-        if pm.get("build_id") != build_id:   # counters of another build say nothing about this one's kernels: not quoted
-            traffic_note = (f"profiles/{profile_file('pmc_traffic.json').name} was measured on build {str(pm.get('build_id'))[:16]}, this library is build {build_id[:16]}: "
-                            "not quoted (tools/run_profiles_r5.sh re-measures)")
-            pm = {"configs": {}}
         for c in pm["configs"].values():
             w = c["workload"]
             if a.traversal == "device" and a.data == "uniform" and (w["n"], w["dim"], w["queries_per_gpu_per_step"], w["ef_search"], w["k"], w["max_edges"]) == \
                     (a.n, a.dim, per_gpu, a.ef_search, a.k, a.max_edges) and c["row_bytes_fetched"] == fetched_row_bytes:
+                measured_on = c.get("build_id", pm.get("build_id"))   # every configuration's passes carry the id of the library they ran on
+                if measured_on != build_id:   # counters of another build say nothing about this one's kernels: not quoted
+                    traffic_note = (f"profiles/{profile_file('pmc_traffic.json').name} holds this workload measured on build {str(measured_on)[:16]}, this library is build "
+                                    f"{build_id[:16]}: not quoted (tools/run_profiles_r5.sh re-measures)")
+                    continue
                 traffic = round(c["graph_search_kernel"]["traffic_bytes_per_launch"])
                 traffic_add = {k: c[k] for k in ("insert_search", "link_half") if k in c}
                 traffic_note = f"FETCH_SIZE x calibration + WRITE_SIZE, separate --pmc passes on this build (profiles/{profile_file('pmc_traffic.json').name})"

@@ -97,20 +97,26 @@ def counter(path, cname, kernel):
 
 
 traffic = {"round": 5, "build_id": None, "note": "FETCH_SIZE (KB) x 1024 x calibration factor of that row size + WRITE_SIZE (KB) x 1024, per launch; the counters tally "
-                                "memory-side requests of the L2s: Infinity-Cache hits are counted (guide, HBM section)", "configs": {}}
+                                "memory-side requests of the L2s: Infinity-Cache hits are counted (guide, HBM section). Every configuration carries the build id "
+                                "of the library its passes ran on (bench.py quotes a figure only for the running library's own id); the top-level build_id is "
+                                "the id of the passes installed last", "configs": {}}
+prev_traffic = {}
+if (dst / f"{r}_pmc_traffic.json").exists():   # a partial re-run keeps the other configurations' entries, each under the build id it was measured on
+    pt = json.load(open(dst / f"{r}_pmc_traffic.json"))
+    prev_traffic = {k: {"build_id": pt.get("build_id"), **v} for k, v in pt.get("configs", {}).items()}
 for cfg, rb in (("c2", 512), ("c3", 3072), ("c4", 512), ("c5", 128), ("c5L", 128)):
     fj, wj, bl = src / f"{cfg}_fetch.json", src / f"{cfg}_write.json", src / f"bench_{cfg}_fetch.log"
     if not (fj.exists() and wj.exists() and bl.exists()):
         continue
-    b = bench(bl)
+    b, bw = bench(bl), bench(src / f"bench_{cfg}_write.log") if (src / f"bench_{cfg}_write.log").exists() else None
     if not b:
         continue
-    if traffic["build_id"] not in (None, b.get("build_id")):
-        print(f"{cfg}: measured on build {str(b.get('build_id'))[:16]}, the set is stamped {traffic['build_id'][:16]}: skipped (re-run that pass)")
+    if bw and bw.get("build_id") != b.get("build_id"):
+        print(f"{cfg}: FETCH_SIZE pass on build {str(b.get('build_id'))[:16]}, WRITE_SIZE pass on {str(bw.get('build_id'))[:16]}: skipped (re-run both)")
         continue
     traffic["build_id"] = b.get("build_id")
     f = factor(rb)
-    e = {"workload": {k: b["config"][k] for k in ("n", "dim", "queries_per_gpu_per_step", "ef_search", "k", "max_edges")}, "row_bytes_fetched": rb,
+    e = {"build_id": b.get("build_id"), "workload": {k: b["config"][k] for k in ("n", "dim", "queries_per_gpu_per_step", "ef_search", "k", "max_edges")}, "row_bytes_fetched": rb,
          "calibration_factor": f}
     fs, ws = counter(fj, "FETCH_SIZE", "graph_search_kernel"), counter(wj, "WRITE_SIZE", "graph_search_kernel")
     alg = b["roofline"]["evals_per_launch"] * b["roofline"]["bytes_per_eval"]   # (no CPU leg under the profiler: rows measured by the device)
@@ -128,6 +134,10 @@ for cfg, rb in (("c2", 512), ("c3", 3072), ("c4", 512), ("c5", 128), ("c5L", 128
             e[part] = {"FETCH_SIZE_KB_total": fa["sum"], "WRITE_SIZE_KB_total": wa["sum"], "traffic_bytes_total": ta, "algorithmic_bytes_total": a,
                        "traffic_over_algorithmic": ta / a}
     traffic["configs"][cfg] = e
+for k, v in prev_traffic.items():
+    traffic["configs"].setdefault(k, v)
+if traffic["build_id"] is None and prev_traffic:
+    traffic["build_id"] = pt.get("build_id")
 json.dump(traffic, open(dst / f"{r}_pmc_traffic.json", "w"), indent=1)
 
 # ---- instruction issue of the product search kernels ----
