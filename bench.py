@@ -137,6 +137,31 @@ def recall_of(x, q, k, metric, got_ids):
     return float(np.mean([len(set(gt[i]) & set(got_ids[i])) / k for i in range(q.shape[0])]))
 
 
+def quote_pmc_traffic(path, workload, fetched_row_bytes, build_id):
+    """roofline.traffic from the committed PMC profile (tools/install_profiles_r5.py): quoted only for the very workload
+    (n, dim, queries per GPU per step, efSearch, k, MaxEdges) and row size it was measured on, and only when those passes ran on
+    the library that is running now -- every configuration carries the build id of its passes (files from before that carry one
+    id for the whole set).  -> (bytes per launch | None, {insert_search, link_half}, note)"""
+    note = "no PMC profile of this workload under profiles/"
+    try:
+        pm = json.loads(Path(path).read_text())
+    except Exception:
+        return None, {}, note
+    for c in pm.get("configs", {}).values():
+        w = c.get("workload", {})
+        if workload is None or tuple(w.get(k) for k in ("n", "dim", "queries_per_gpu_per_step", "ef_search", "k", "max_edges")) != tuple(workload) \
+                or c.get("row_bytes_fetched") != fetched_row_bytes:
+            continue
+        measured_on = c.get("build_id", pm.get("build_id"))
+        if measured_on != build_id:   # counters of another build say nothing about this one's kernels: not quoted
+            note = (f"profiles/{Path(path).name} holds this workload measured on build {str(measured_on)[:16]}, this library is build {build_id[:16]}: "
+                    "not quoted (tools/run_profiles_r5.sh re-measures)")
+            continue
+        return (round(c["graph_search_kernel"]["traffic_bytes_per_launch"]), {k: c[k] for k in ("insert_search", "link_half") if k in c},
+                f"FETCH_SIZE x calibration + WRITE_SIZE, separate --pmc passes on this build (profiles/{Path(path).name})")
+    return None, {}, note
+
+
 def cgroup_quota():
     """CPUs this process's cgroup may use (cpu.max quota / period), or None: what .NET clamps Environment.ProcessorCount to."""
     try:
@@ -456,9 +481,9 @@ def main():
         kname, t_evals, t_launches, k_ms = "slot_distance_kernel", st["timed_evals"], st["timed_launches"], st["kernel_ms"]
     kernel_s = k_ms / 1e3
     achieved = t_evals * st["row_bytes"] / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    # PMC traffic and the measured random-gather ceilings are collected in separate passes (tools/run_profiles_r3.sh; --pmc runs
+    # PMC traffic and the measured random-gather ceilings are collected in separate passes (tools/run_profiles_r5.sh; --pmc runs
     # cannot be combined with tracing) and committed under profiles/: quoted only for the very workload they were measured on
-    traffic, traffic_add, gather = None, {}, None
+    gather = None
     fetched_row_bytes = 128 if a.metric == "sq_euclid_i8" and a.dim <= 120 else st["row_bytes"]
     def profile_file(stem):
         for r in (PROFILE_ROUND, PROFILE_FALLBACK):
@@ -467,23 +492,8 @@ def main():
                 return f
         return ROOT / "profiles" / f"{PROFILE_ROUND}_{stem}"
     build_id = hnswindex.net_amd.lib.hnsw_mi355x_build_id().decode()
-    traffic_note = "no PMC profile of this workload under profiles/"
-    try:
-        pm = json.loads(profile_file("pmc_traffic.json").read_text())
-        for c in pm["configs"].values():
-            w = c["workload"]
-            if a.traversal == "device" and a.data == "uniform" and (w["n"], w["dim"], w["queries_per_gpu_per_step"], w["ef_search"], w["k"], w["max_edges"]) == \
-                    (a.n, a.dim, per_gpu, a.ef_search, a.k, a.max_edges) and c["row_bytes_fetched"] == fetched_row_bytes:
-                measured_on = c.get("build_id", pm.get("build_id"))   # every configuration's passes carry the id of the library they ran on
-                if measured_on != build_id:   # counters of another build say nothing about this one's kernels: not quoted
-                    traffic_note = (f"profiles/{profile_file('pmc_traffic.json').name} holds this workload measured on build {str(measured_on)[:16]}, this library is build "
-                                    f"{build_id[:16]}: not quoted (tools/run_profiles_r5.sh re-measures)")
-                    continue
-                traffic = round(c["graph_search_kernel"]["traffic_bytes_per_launch"])
-                traffic_add = {k: c[k] for k in ("insert_search", "link_half") if k in c}
-                traffic_note = f"FETCH_SIZE x calibration + WRITE_SIZE, separate --pmc passes on this build (profiles/{profile_file('pmc_traffic.json').name})"
-    except Exception:
-        pass
+    workload = (a.n, a.dim, per_gpu, a.ef_search, a.k, a.max_edges) if a.traversal == "device" and a.data == "uniform" else None
+    traffic, traffic_add, traffic_note = quote_pmc_traffic(profile_file("pmc_traffic.json"), workload, fetched_row_bytes, build_id)
     gather_same_table = None
     try:
         gj = json.loads(profile_file("gather_ceilings.json").read_text())
