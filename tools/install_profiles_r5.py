@@ -169,7 +169,13 @@ for cfg, what in (("c5", "C5-size: 10M x 96 int8 records, 12 500 queries per cal
                   "wave_time_executing": B["SQ_ACTIVE_INST_ANY"] / A["SQ_WAVE_CYCLES"],
                   "wave_time_waiting_for_issue": B["SQ_WAIT_INST_ANY"] / A["SQ_WAVE_CYCLES"],
                   "wave_time_waiting_on_memory_or_dependencies": 1.0 - (B["SQ_ACTIVE_INST_ANY"] + B["SQ_WAIT_INST_ANY"]) / A["SQ_WAVE_CYCLES"]})
+    bi = bench(src / f"bench_{cfg}_issue_a.log")
+    if bi:
+        e["build_id"] = bi.get("build_id")
     issue["kernels"][cfg] = e
+if (dst / f"{r}_issue_counters.json").exists():   # a partial re-run keeps the other configurations' entries (each names the build it ran on where known)
+    for k, v in json.load(open(dst / f"{r}_issue_counters.json")).get("kernels", {}).items():
+        issue["kernels"].setdefault(k, v)
 if issue["kernels"]:
     json.dump(issue, open(dst / f"{r}_issue_counters.json", "w"), indent=1)
     print("issue", {k: (round(v["avg_waves_per_simd"], 2), round(v.get("valu_pipe_busy_fraction", 0), 3), round(v.get("wave_time_waiting_on_memory_or_dependencies", 0), 3)) for k, v in issue["kernels"].items()})
