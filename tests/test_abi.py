@@ -37,6 +37,14 @@ def test_library_exports_every_declared_symbol(net):
         assert hasattr(net.lib, s), s
 
 
+def test_every_declared_entry_point_is_named_in_integration_md():
+    """INTEGRATION.md shows the reference-side binding for the calls a maintainer binds first and lists every other entry point
+    of the header by group (section 4): no export may be undocumented."""
+    text = (ROOT / "INTEGRATION.md").read_text()
+    missing = [s for s in _declared_symbols() if s not in text]
+    assert not missing, missing
+
+
 def test_library_is_at_the_reference_loader_path(net):
     # /root/reference/bindings/bindings.py:27-41
     assert net.LIB_PATH.parts[-4:] == ("artifacts", "native", "linux-x64", "HNSWIndex.Native.so")
