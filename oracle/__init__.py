@@ -45,6 +45,7 @@ def lib():
         L.orc_add.argtypes = [ct.c_void_p, _F, ct.c_int, _I]
         L.orc_add_batched.argtypes = [ct.c_void_p, _F, ct.c_int, _I, ct.c_int]
         L.orc_add_batched_mt.argtypes = [ct.c_void_p, _F, ct.c_int, _I, ct.c_int, ct.c_int]
+        L.orc_add_ticks.argtypes = [ct.c_void_p, _F, ct.c_int, _I, ct.c_int, ct.POINTER(ct.c_uint64)]
         L.orc_i8_pitch.argtypes = [ct.c_int]
         L.orc_i8_quantize.argtypes = [_F, ct.c_int, _I]
         L.orc_i8_quantize.restype = None
@@ -236,6 +237,15 @@ class OracleIndex:
         ids = np.empty(a.shape[0], dtype=np.int32)
         lib().orc_add_batched_mt(self._h, _pf(a), a.shape[0], _pi(ids), int(max_batch), int(threads))
         return ids
+
+    def add_ticks(self, vecs, slots=256):
+        """The per-layer tick schedule (orc_add_ticks; groundwork for DESIGN.md 4.3, not a product path yet): at most `slots`
+        items in flight, started in id order, one layer per item and tick.  -> (ids, {ticks, steps, max_in_flight, alone})"""
+        a = _f32(vecs).reshape(-1, self.dim)
+        ids = np.empty(a.shape[0], dtype=np.int32)
+        st = (ct.c_uint64 * 4)()
+        lib().orc_add_ticks(self._h, _pf(a), a.shape[0], _pi(ids), int(slots), st)
+        return ids, {"ticks": int(st[0]), "steps": int(st[1]), "max_in_flight": int(st[2]), "alone": int(st[3])}
 
     # ---- the exact-window schedule taken apart (tests/test_window_model.py) ----
     def alloc_only(self, vecs):

@@ -1,5 +1,5 @@
 /* tools/host_sanitize/oracle_main.c -- the CPU restatement (oracle/hnsw_oracle.c, test infrastructure) under
- * AddressSanitizer + UBSan: a small index through sequential Add, the batched schedule, KnnQuery on one and several
+ * AddressSanitizer + UBSan: a small index through sequential Add, the batched schedule, the tick schedule, KnnQuery on one and several
  * threads, RangeQuery, removals with slot reuse.  Built with the oracle's own source by tests/test_host_sanitizers.py:
  *   gcc -std=gnu11 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -ffp-contract=off -mavx2 -mfma \
  *       -Dorc_main_included oracle_main.c -lm -lpthread */
@@ -21,7 +21,12 @@ int main(void)
         if (!h) { printf("orc_create failed\n"); return 2; }
         orc_set_remove_max_candidates(h, 40);
         orc_add(h, x, 300, ids);
-        orc_add_batched_mt(h, x + 300 * D, 400, ids + 300, 128, 3);
+        orc_add_batched_mt(h, x + 300 * D, 250, ids + 300, 128, 3);
+        {
+            uint64_t st[4];
+            orc_add_ticks(h, x + 550 * D, 150, ids + 550, 32, st); /* collection size 64: the allocations of the call resize the arrays before its first tick */
+            if (st[2] > 32) { printf("tick schedule: %llu items in flight\n", (unsigned long long)st[2]); return 3; }
+        }
         orc_knn_query(h, q, Q, K, out_ids, out_d, 1);
         orc_knn_query(h, q, Q, K, out_ids, out_d, 4);
         int rm[120];
