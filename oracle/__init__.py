@@ -239,13 +239,14 @@ class OracleIndex:
         return ids
 
     def add_ticks(self, vecs, slots=256):
-        """The per-layer tick schedule (orc_add_ticks; groundwork for DESIGN.md 4.3, not a product path yet): at most `slots`
-        items in flight, started in id order, one layer per item and tick.  -> (ids, {ticks, steps, max_in_flight, alone})"""
+        """The tick schedule (orc_add_ticks; the CPU model behind DESIGN.md 4.3, not a product path): at most `slots` items in
+        flight, started in id order; a multi-layer item searches its top layer one tick ahead of the rest and links everything in
+        its last tick.  -> (ids, {ticks, steps (item-ticks), max_in_flight, alone, long_ticks})"""
         a = _f32(vecs).reshape(-1, self.dim)
         ids = np.empty(a.shape[0], dtype=np.int32)
-        st = (ct.c_uint64 * 4)()
+        st = (ct.c_uint64 * 5)()
         lib().orc_add_ticks(self._h, _pf(a), a.shape[0], _pi(ids), int(slots), st)
-        return ids, {"ticks": int(st[0]), "steps": int(st[1]), "max_in_flight": int(st[2]), "alone": int(st[3])}
+        return ids, {"ticks": int(st[0]), "steps": int(st[1]), "max_in_flight": int(st[2]), "alone": int(st[3]), "long_ticks": int(st[4])}
 
     # ---- the exact-window schedule taken apart (tests/test_window_model.py) ----
     def alloc_only(self, vecs):

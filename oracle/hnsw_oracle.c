@@ -1216,26 +1216,34 @@ ORC_API int orc_add_batched_mt(void *h, const float *v, int n, int *out_ids, int
 }
 
 /* ------------------------------------------------------------------------------------
- * Per-layer tick schedule -- NOT a reference code path and NOT (yet) a product path: groundwork for DESIGN.md 4.3.
+ * Tick schedule -- NOT a reference code path and NOT a product path: the CPU model behind DESIGN.md 4.3's analysis.
  * One more deterministic member of the outcome set of HNSWIndex.Add(List)'s Parallel.For (HNSWIndex.cs:70-78) on a host that
  * holds `slots` items in flight: ids are handed out at AddItem in start order (:57) and an item holds its thread -- and its own
  * OutEdgesLock (:60-63) -- from there to its last ConnectAtLayer, so any execution that STARTS items in id order with at most
  * `slots` of them between start and finish is an interleaving real threads can produce; the slots need not turn over together.
  * Time runs in ticks.  In a tick
  *   1. free slots are filled in id order: a starting item runs FindEntryPoint (GraphConnector.cs:174) on the graph as it stands;
- *   2. every item in flight searches ITS CURRENT layer on that same graph: SearchLayer + RelativeNeighborPruning (:189-190);
- *   3. every item steps down (next entry = selected[0], :216); in id order, the items that have searched layer 0 link ALL their
- *      layers, top down (:192-214), and leave their slots.
- * So a one-layer item takes one tick, an item on L layers L ticks, and a tick is as long as ONE traversal.  An item sees later
- * graph states on its lower layers -- as a slow thread does.  Its upper layers are linked with its last one: the writes of
- * ConnectAtLayer(layer) touch lists of that layer only and the searches of the layers below read none of them, so a thread
- * that links layer l just before it links layer l - 1 is indistinguishable from one that linked it earlier with the same
- * selection -- and no node is ever visible on an upper layer while its lower lists are still empty (linking per tick was tried
- * first: an item whose descent ends on such a half-linked node finds an empty list on the layer below and links to that one node;
- * recall@10 at 6 000 nodes 0.647 against 0.692 sequential, 0.684 for snapshot batches of 256).  An item whose level
- * exceeds the top layer starts only when nothing is in flight and is inserted alone (entry-point lock, GraphConnector.cs:27-41).
- * The number of slots grows with the graph by the batched schedule's rule.  slots == 1 is exactly orc_add.
- * stats (may be NULL): [0] ticks, [1] item-layer steps, [2] most items in flight in a tick, [3] items inserted alone.
+ *   2. every item in flight searches on that same graph (SearchLayer + RelativeNeighborPruning, :189-190; next entry =
+ *      selected[0], :216): an item on one layer that layer; an item on more its TOP layer in its first tick and all the layers
+ *      below, one after the other, in its second;
+ *   3. in id order, the items that have searched layer 0 link all their layers, top down (:192-214), and leave their slots.
+ * So every multi-layer item splits its top layer off into a tick of its own: one in sixteen items takes two ticks, and a tick is
+ * as long as ONE traversal unless it holds the second half of an item on three or more layers (one in 256).
+ * How far a link may wait, and why not further: ConnectAtLayer(l) writes lists of layer l only, the search of layer l - 1 reads none
+ * of them, and reads do not conflict with reads -- so the real execution "every layer-l read of the tick, then the item's link of
+ * layer l, then its search of layer l - 1, ..., then the tick's links of layer 0" respects every thread's program order and gives
+ * exactly this schedule's graph (links of different layers commute).  Hence the link of layer l may wait for the tick in which
+ * layer l - 1 is searched, and NO longer (the descents of the items starting a tick later read layer l and would have to see it).
+ * Two variants that take ALL layers apart were measured here first and dropped: linked tick by tick, a node is visible on an
+ * upper layer while its lists below are still empty -- the reference's own race; an item whose descent ends on such a node finds
+ * nothing below and links to that node alone: recall@10 0.647 against 0.692 sequential at 6 000 x 32, 0.470 against 0.478 at
+ * 100 000 x 32 even when only items on three or more layers are exposed; linked all at the end, recall is on par but an item on
+ * three layers links its top layer two ticks late, which is not an interleaving.  With the rule above every node becomes visible
+ * on all its layers at once AND every link is within its bound.
+ * An item whose level exceeds the top layer starts only when nothing is in flight and is inserted alone (entry-point lock,
+ * GraphConnector.cs:27-41).  The number of slots grows with the graph by the batched schedule's rule.  slots == 1 is exactly
+ * orc_add.  stats (may be NULL): [0] ticks, [1] item-ticks, [2] most items in flight in a tick, [3] items inserted alone,
+ * [4] ticks that hold the second half of an item on three or more layers (two traversals long or more).
  * ---------------------------------------------------------------------------------- */
 typedef struct { int id, layer, best; edges_t *sel; /* [max_layer + 1] */ } tick_item_t;
 static void link_layer(sctx_t *c, int id, int layer, edges_t sel) /* batch_link's body for one layer */
@@ -1273,7 +1281,7 @@ ORC_API int orc_add_ticks(void *h, const float *v, int n, int *out_ids, int slot
     tick_item_t *act = (tick_item_t *)malloc(sizeof(tick_item_t) * (size_t)slots);
     int na = 0, p = 0, finished = 0;
     const int before = ix->count - m; /* nodes linked before this call */
-    uint64_t st[4] = {0, 0, 0, 0};
+    uint64_t st[5] = {0, 0, 0, 0, 0};
     while (p < m || na > 0) {
         /* 1. starts, in id order */
         while (p < m) {
@@ -1303,25 +1311,35 @@ ORC_API int orc_add_ticks(void *h, const float *v, int n, int *out_ids, int slot
         st[0]++;
         st[1] += (uint64_t)na;
         if ((uint64_t)na > st[2]) st[2] = (uint64_t)na;
-        /* 2. searches: the graph is only read */
+        /* 2. searches: the graph is only read.  First tick of a multi-layer item: its top layer; otherwise everything below */
+        int long_job = 0;
         for (int i = 0; i < na; i++) {
-            nd_t *topc;
-            int cnt = search_layer(&c, act[i].best, act[i].layer, ix->max_candidates, item(ix, act[i].id), &topc);
-            act[i].sel[act[i].layer] = relative_neighbor_pruning(&c, topc, cnt, max_edges_at(ix, act[i].layer));
-            free(topc);
+            const int id = act[i].id, lvl = ix->nodes[id].max_layer;
+            const int first_tick = act[i].layer == lvl && lvl > 0;
+            const int stop = first_tick ? lvl : 0; /* lowest layer searched in this tick */
+            if (!first_tick && act[i].layer >= 1) long_job = 1; /* layers 1 and 0 (at least) in one job */
+            for (int layer = act[i].layer; layer >= stop; --layer) {
+                nd_t *topc;
+                int cnt = search_layer(&c, act[i].best, layer, ix->max_candidates, item(ix, id), &topc);
+                act[i].sel[layer] = relative_neighbor_pruning(&c, topc, cnt, max_edges_at(ix, layer));
+                free(topc);
+                act[i].best = act[i].sel[layer].buf[0];
+            }
+            act[i].layer = stop;
         }
-        /* 3. the step down; items done with layer 0 link all their layers, in id order (act is kept in id order) */
+        st[4] += (uint64_t)long_job;
+        /* 3. in id order (act is kept in id order): the items that have searched layer 0 link every layer, top down */
         int keep = 0;
         for (int i = 0; i < na; i++) {
+            const int id = act[i].id;
             if (act[i].layer == 0) {
-                for (int layer = ix->nodes[act[i].id].max_layer; layer >= 0; --layer) link_layer(&c, act[i].id, layer, act[i].sel[layer]);
+                for (int layer = ix->nodes[id].max_layer; layer >= 0; --layer) link_layer(&c, id, layer, act[i].sel[layer]);
                 free(act[i].sel);
                 finished++;
                 continue;
             }
             act[keep] = act[i];
-            act[keep].best = act[i].sel[act[i].layer].buf[0];
-            act[keep].layer--;
+            act[keep].layer--; /* `best` already is the entry of the next layer */
             keep++;
         }
         na = keep;

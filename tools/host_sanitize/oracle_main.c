@@ -23,7 +23,7 @@ int main(void)
         orc_add(h, x, 300, ids);
         orc_add_batched_mt(h, x + 300 * D, 250, ids + 300, 128, 3);
         {
-            uint64_t st[4];
+            uint64_t st[5];
             orc_add_ticks(h, x + 550 * D, 150, ids + 550, 32, st); /* collection size 64: the allocations of the call resize the arrays before its first tick */
             if (st[2] > 32) { printf("tick schedule: %llu items in flight\n", (unsigned long long)st[2]); return 3; }
         }
